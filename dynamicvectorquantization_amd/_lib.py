@@ -1,0 +1,99 @@
+"""ctypes binding of libdvq.so (include/dvq.h) -- the only bridge between the torch-facing
+modules of this package and the HIP kernels.
+
+There is NO fallback: if the shared library is missing or an entry point is absent the import
+of this module raises.  torch is imported first so that libdvq.so binds to the HIP runtime torch
+already loaded (same libamdhip64.so.7 SONAME) and can use torch's streams and device pointers.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libdvq.so")
+
+DVQ_OK = 0
+MODE_EXACT = 0
+MODE_FILTER = 1
+GATE_F32 = 0
+GATE_I64 = 1
+
+EXPORTS = (
+    "dvq_version", "dvq_last_error_string", "dvq_codebook_prep_bytes", "dvq_codebook_prepare_f32",
+    "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_embed_gather_f32",
+    "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_triple_f32",
+)
+
+
+class DvqError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (csrc/Makefile) into csrc/libdvq.so."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise DvqError(
+            "libdvq.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C %s` (hipcc --offload-arch=gfx950). There is no CPU fallback." % (LIB_PATH, CSRC))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise DvqError("libdvq.so does not export %s (stale build?)" % name)
+    vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+    lib.dvq_version.restype = i32
+    lib.dvq_last_error_string.restype = ctypes.c_char_p
+    lib.dvq_codebook_prep_bytes.restype = sz
+    lib.dvq_codebook_prep_bytes.argtypes = [i32, i32]
+    lib.dvq_codebook_prepare_f32.restype = i32
+    lib.dvq_codebook_prepare_f32.argtypes = [vp, i32, i32, vp, sz, vp]
+    lib.dvq_vq_assign_workspace_bytes.restype = sz
+    lib.dvq_vq_assign_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.dvq_vq_assign_nchw_f32.restype = i32
+    lib.dvq_vq_assign_nchw_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_embed_gather_f32.restype = i32
+    lib.dvq_embed_gather_f32.argtypes = [vp, i32, i32, vp, i64, vp, vp]
+    lib.dvq_entropy_gate_f32.restype = i32
+    lib.dvq_entropy_gate_f32.argtypes = [vp, i64, f32, vp, vp]
+    lib.dvq_route_select_dual_f32.restype = i32
+    lib.dvq_route_select_dual_f32.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.dvq_route_select_triple_f32.restype = i32
+    lib.dvq_route_select_triple_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != DVQ_OK:
+        msg = lib.dvq_last_error_string().decode("utf-8", "replace")
+        raise DvqError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise DvqError("%s is on %s: the dvq kernels run on the GPU only (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

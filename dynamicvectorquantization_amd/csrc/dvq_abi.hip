@@ -1,0 +1,178 @@
+// dvq_abi.hip -- the extern "C" boundary of libdvq.so (see include/dvq.h).
+// Argument validation + launch only: no allocation, no synchronisation, no torch types.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/dvq.h"
+#include "dvq_common.h"
+
+#define DVQ_VERSION 100   // 0.1.0
+
+static thread_local char g_err[512] = "";
+
+void dvq_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// launchers implemented next to their kernels
+int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st);
+int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st);
+int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
+                     int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
+                     hipStream_t st);
+int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
+                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
+                      void *ws_extra, hipStream_t st);
+size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
+bool dvq_filter_supported(int D, int HW, int K, long N);
+int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
+                             float *loss, hipStream_t st);
+int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
+                            const float *h_median, const float *h_fine, int B, int C, int hc, int wc,
+                            float *h_out, long long *indices, float *cmask, hipStream_t st);
+int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate, hipStream_t st);
+int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
+                            hipStream_t st);
+
+static int hip_rc(int rc, const char *what)
+{
+    if (rc == 0) return DVQ_OK;
+    dvq_set_error("%s: HIP error %d (%s)", what, rc, hipGetErrorString((hipError_t)rc));
+    return DVQ_EHIP;
+}
+
+static bool dim_ok(int D) { return D == 64 || D == 128 || D == 256; }
+
+extern "C" {
+
+int dvq_version(void) { return DVQ_VERSION; }
+const char *dvq_last_error_string(void) { return g_err; }
+
+size_t dvq_codebook_prep_bytes(int K, int D)
+{
+    if (K <= 0 || D <= 0) return 0;
+    // f32 tile images + norms + f16 section (images of the filter kernel: 2 B per element + 16 B
+    // of per-code metadata), rounded up generously so the layout can grow without an ABI change
+    size_t f32 = dvq_prep_f16_offset(K, D);
+    size_t f16 = (size_t)dvq_num_tiles(K) * 32 * ((size_t)D * 2 + 16) + 4096;
+    return ((f32 + f16 + 255) / 256) * 256;
+}
+
+int dvq_codebook_prepare_f32(const float *codebook, int K, int D, void *prep, size_t prep_bytes,
+                             void *stream)
+{
+    if (!codebook || !prep || K <= 0) { dvq_set_error("dvq_codebook_prepare_f32: null pointer or K <= 0"); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_codebook_prepare_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (prep_bytes < dvq_codebook_prep_bytes(K, D)) { dvq_set_error("dvq_codebook_prepare_f32: prep buffer %zu < %zu bytes", prep_bytes, dvq_codebook_prep_bytes(K, D)); return DVQ_EWORKSPACE; }
+    if (((uintptr_t)prep & 255) != 0) { dvq_set_error("dvq_codebook_prepare_f32: prep must be 256-byte aligned"); return DVQ_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dvq_launch_prep_f32(codebook, K, D, prep, st);
+    if (rc) return hip_rc(rc, "codebook_prep_f32");
+    rc = dvq_launch_prep_f16(codebook, K, D, prep, st);
+    return hip_rc(rc, "codebook_prep_f16");
+}
+
+size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode)
+{
+    if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) return 0;
+    long N = (long)B * HW;
+    size_t partials = ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    size_t extra = (mode == DVQ_MODE_FILTER) ? dvq_filter_ws_extra_bytes(D, HW, K, N) : 0;
+    return partials + extra + 256;
+}
+
+int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *prep,
+                           const float *mask, int B, int D, int HW, int K, float beta,
+                           float *zq, int64_t *codes, float *loss,
+                           void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    if (!z || !codebook || !prep || !codes) { dvq_set_error("dvq_vq_assign_nchw_f32: null pointer"); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_vq_assign_nchw_f32: B=%d HW=%d K=%d must be positive", B, HW, K); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_vq_assign_nchw_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("dvq_vq_assign_nchw_f32: unknown mode %d", mode); return DVQ_EINVAL; }
+    if ((size_t)B * HW * D >= ((size_t)1 << 40)) { dvq_set_error("dvq_vq_assign_nchw_f32: tensor too large"); return DVQ_EUNSUPPORTED; }
+    const long N = (long)B * HW;
+    if (loss && !ws) { dvq_set_error("dvq_vq_assign_nchw_f32: loss requested without workspace"); return DVQ_EINVAL; }
+    if ((loss || mode == DVQ_MODE_FILTER) && (!ws || ws_bytes < dvq_vq_assign_workspace_bytes(B, D, HW, K, mode))) {
+        dvq_set_error("dvq_vq_assign_nchw_f32: workspace %zu < %zu bytes", ws_bytes, dvq_vq_assign_workspace_bytes(B, D, HW, K, mode));
+        return DVQ_EWORKSPACE;
+    }
+    if (ws && ((uintptr_t)ws & 255) != 0) { dvq_set_error("dvq_vq_assign_nchw_f32: workspace must be 256-byte aligned"); return DVQ_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    double *partials = loss ? (double *)ws : nullptr;
+    size_t partials_bytes = ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    int nparts;
+    int rc;
+    if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
+        rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
+                               (char *)ws + partials_bytes, st);
+        if (rc < 0 && rc != -1000) return rc;            // already reported
+        if (rc) return hip_rc(rc, "vq_assign_filter");
+        nparts = (int)((N + 127) / 128);
+    } else {
+        rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
+                              (long long *)codes, partials, st);
+        if (rc) return hip_rc(rc, "vq_assign_exact");
+        nparts = (int)((N + 127) / 128);
+    }
+    if (loss) {
+        rc = dvq_launch_loss_finalize(partials, nparts, 1.0 / ((double)N * D), beta, loss, st);
+        if (rc) return hip_rc(rc, "vq_loss_finalize");
+    }
+    return DVQ_OK;
+}
+
+int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx, int64_t n,
+                         float *out, void *stream)
+{
+    if (!codebook || !idx || !out) { dvq_set_error("dvq_embed_gather_f32: null pointer"); return DVQ_EINVAL; }
+    if (K <= 0 || D <= 0 || n < 0) { dvq_set_error("dvq_embed_gather_f32: bad sizes"); return DVQ_EINVAL; }
+    if (D % 4 != 0) { dvq_set_error("dvq_embed_gather_f32: D=%d must be a multiple of 4", D); return DVQ_EUNSUPPORTED; }
+    if (n == 0) return DVQ_OK;
+    return hip_rc(dvq_launch_embed_gather(codebook, K, D, (const long long *)idx, (long)n, out, (hipStream_t)stream), "embed_gather");
+}
+
+int dvq_entropy_gate_f32(const float *entropy, int64_t n, float thr, int64_t *gate, void *stream)
+{
+    if (!entropy || !gate) { dvq_set_error("dvq_entropy_gate_f32: null pointer"); return DVQ_EINVAL; }
+    if (n < 0) { dvq_set_error("dvq_entropy_gate_f32: n < 0"); return DVQ_EINVAL; }
+    if (n == 0) return DVQ_OK;
+    return hip_rc(dvq_launch_entropy_gate(entropy, (long)n, thr, (long long *)gate, (hipStream_t)stream), "entropy_gate");
+}
+
+static int route_args_ok(const char *fn, const void *gate, int gate_dtype, const float *a, const float *b,
+                         int B, int C, int hc, int wc, float *h_out, int64_t *indices, float *cmask)
+{
+    if (!gate || !a || !b || !h_out || !indices || !cmask) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if (gate_dtype != DVQ_GATE_F32 && gate_dtype != DVQ_GATE_I64) { dvq_set_error("%s: gate_dtype %d", fn, gate_dtype); return DVQ_EINVAL; }
+    if (B <= 0 || C <= 0 || hc <= 0 || wc <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    return DVQ_OK;
+}
+
+int dvq_route_select_dual_f32(const void *gate, int gate_dtype, const float *h_coarse,
+                              const float *h_fine, int B, int C, int hc, int wc,
+                              float *h_out, int64_t *indices, float *cmask, void *stream)
+{
+    int rc = route_args_ok("dvq_route_select_dual_f32", gate, gate_dtype, h_coarse, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    if (rc) return rc;
+    if (wc % 2 != 0) { dvq_set_error("dvq_route_select_dual_f32: wc=%d must be even (rows move as 16-byte pieces)", wc); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_route_select(2, gate_dtype == DVQ_GATE_I64, gate, h_coarse, nullptr, h_fine, B, C, hc, wc,
+                                          h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_dual");
+}
+
+int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h_coarse,
+                                const float *h_median, const float *h_fine, int B, int C, int hc,
+                                int wc, float *h_out, int64_t *indices, float *cmask, void *stream)
+{
+    int rc = route_args_ok("dvq_route_select_triple_f32", gate, gate_dtype, h_coarse, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    if (rc) return rc;
+    if (!h_median) { dvq_set_error("dvq_route_select_triple_f32: null h_median"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_route_select(3, gate_dtype == DVQ_GATE_I64, gate, h_coarse, h_median, h_fine, B, C, hc, wc,
+                                          h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_triple");
+}
+
+}  // extern "C"

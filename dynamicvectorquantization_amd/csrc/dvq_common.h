@@ -1,0 +1,72 @@
+// dvq_common.h -- shared device helpers and the codebook "prep" buffer layout (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define DVQ_CODE_TILE 32  // codes per MFMA tile (rows of a 32x32 MFMA)
+
+// ---------------------------------------------------------------------------------------------
+// Prep buffer (built once per codebook by dvq_codebook_prepare_f32), all offsets in bytes,
+// T = ceil(K/32) code tiles:
+//   [f32 tile images]  T x (32*D + 64) floats.  Image of tile t:
+//        img[kg][c][p], kg < D/8, c < 32, p < 8  =  E[32t + c][8kg + 2(p&3) + (p>>2)]
+//        (lane (c, h) of a wave reads its 4 next f32-MFMA A operands k = 8kg + {0,2,4,6} + h with
+//         one ds_read_b128 at float offset (kg*32 + c)*8 + 4h), then en[32] (exact ATen-order
+//        squared norms of the tile's codes; +inf... no: 0 for padded codes) and 32 floats of padding.
+//   [en]               Kpad floats (Kpad = 32T): all squared norms, same values.
+//   [f16 section]      used by the filter kernel, see vq_assign_filter.hip.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int dvq_num_tiles(int K) { return (K + DVQ_CODE_TILE - 1) / DVQ_CODE_TILE; }
+__host__ __device__ inline size_t dvq_tile_floats(int D) { return (size_t)32 * D + 64; }
+__host__ __device__ inline size_t dvq_prep_f32_tiles_bytes(int K, int D)
+{
+    return (size_t)dvq_num_tiles(K) * dvq_tile_floats(D) * sizeof(float);
+}
+__host__ __device__ inline size_t dvq_prep_en_offset(int K, int D) { return dvq_prep_f32_tiles_bytes(K, D); }
+__host__ __device__ inline size_t dvq_prep_f16_offset(int K, int D)
+{
+    return dvq_prep_en_offset(K, D) + (size_t)dvq_num_tiles(K) * 32 * sizeof(float);
+}
+
+// async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc_lane,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void *gsrc_lane, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc_lane,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+
+// ATen-order squared norm pieces (see oracle/dvq_oracle.c): explicit roundings, never contracted.
+__device__ __forceinline__ float sq_rn(float x) { return __fmul_rn(x, x); }
+
+// torch CPU argmin step over candidates visited in ascending index:
+// take if d < best, or d is NaN and best is not.
+__device__ __forceinline__ bool argmin_take(float d, float best)
+{
+    return !(d >= best) && (best == best);
+}
+
+// merge two (distance, index) candidates of disjoint ascending scans
+__device__ __forceinline__ void argmin_merge(float &d, int &i, float d2, int i2)
+{
+    bool n1 = d != d, n2 = d2 != d2;
+    bool other;
+    if (n1 || n2)
+        other = n2 && (!n1 || i2 < i);
+    else
+        other = (d2 < d) || (d2 == d && i2 < i);
+    if (other) { d = d2; i = i2; }
+}
+
+// per-launch host-side error plumbing (dvq_abi.hip)
+void dvq_set_error(const char *fmt, ...);

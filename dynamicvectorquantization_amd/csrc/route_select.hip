@@ -1,0 +1,181 @@
+// route_select.hip -- dual / triple granularity router select ("scatter/gather") for gfx950.
+//
+// Replaces the routing tails of the reference encoders in eval mode:
+//   modules/dynamic_modules/EncoderDual.py:134-149   (argmax, x2 repeat_interleave, where, mask)
+//   modules/dynamic_modules/EncoderTriple.py:148-176 (argmax, x4/x2 repeat_interleave, 3 wheres, mask)
+//   modules/dynamic_modules/RouterDual.py:53-57      (entropy threshold gate)
+// One pass: every output float4 reads exactly one source (the branch that won its cell), so HBM
+// traffic is the algorithmic 1 read + 1 write per element; the reference materialises two
+// upsampled copies and reads all branches.  Pure data movement -> HBM-bound, no LDS needed:
+// each thread moves 16 B, consecutive lanes consecutive addresses.
+#include "dvq_common.h"
+
+template <int G, bool I64>
+__device__ __forceinline__ int gate_argmax(const void *gate, size_t cell)
+{
+    // torch.argmax semantics: first maximal value wins, NaN counts as the maximum
+    if (I64) {
+        const long long *g = (const long long *)gate + cell * G;
+        long long best = g[0];
+        int bi = 0;
+#pragma unroll
+        for (int i = 1; i < G; ++i) {
+            long long v = g[i];
+            if (v > best) { best = v; bi = i; }
+        }
+        return bi;
+    } else {
+        const float *g = (const float *)gate + cell * G;
+        float best = g[0];
+        int bi = 0;
+#pragma unroll
+        for (int i = 1; i < G; ++i) {
+            float v = g[i];
+            if ((v > best) || (v != v && best == best)) { best = v; bi = i; }
+        }
+        return bi;
+    }
+}
+
+// G = 2: dual (fine grid = 2x coarse); G = 3: triple (fine grid = 4x coarse, median 2x).
+// Work item = one float4 of one row of plane p of image b, p in [0, C]: planes 0..C-1 are the
+// feature channels, plane C is the codebook_mask plane (whose items also emit `indices`).
+template <int G, bool I64>
+__global__ __launch_bounds__(256) void route_select_kernel(
+    const void *__restrict__ gate, const float *__restrict__ h_coarse,
+    const float *__restrict__ h_median, const float *__restrict__ h_fine,
+    int B, int C, int hc, int wc,
+    float *__restrict__ h_out, long long *__restrict__ indices, float *__restrict__ cmask)
+{
+    constexpr int SC = (G == 2) ? 2 : 4;          // fine pixels per coarse cell edge
+    const int H = SC * hc, W = SC * wc, W4 = W / 4;
+    const size_t per_plane = (size_t)H * W4;
+    const size_t total = (size_t)B * (C + 1) * per_plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t bp = i / per_plane;
+        const int rem = (int)(i - bp * per_plane);
+        const int b = (int)(bp / (C + 1)), p = (int)(bp - (size_t)b * (C + 1));
+        const int y = rem / W4, x = (rem - y * W4) * 4;
+        const int cy = y / SC;
+        // grain of the (up to two) coarse cells this float4 touches
+        const int cx0 = x / SC, cx1 = (x + 3) / SC;
+        const size_t cell0 = ((size_t)b * hc + cy) * wc + cx0;
+        const int g0 = gate_argmax<G, I64>(gate, cell0);
+        const int g1 = (cx1 != cx0) ? gate_argmax<G, I64>(gate, cell0 + 1) : g0;
+        if (p == C) {
+            f32x4 m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int g = ((x + j) / SC == cx0) ? g0 : g1;
+                m[j] = (G == 2) ? (g == 0 ? 0.25f : 1.0f)
+                                : (g == 0 ? 0.0625f : (g == 1 ? 0.25f : 1.0f));
+            }
+            *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
+            if (y % SC == 0) {
+                if (x % SC == 0) indices[cell0] = g0;
+                if (cx1 != cx0) indices[cell0 + 1] = g1;
+            }
+            continue;
+        }
+        const size_t plane = (size_t)b * C + p;
+        const size_t o = (plane * H + y) * W + x;
+        f32x4 v;
+        const bool all_fine = (g0 == G - 1) && (g1 == G - 1);
+        if (all_fine) {
+            v = *(const f32x4 *)(h_fine + o);
+        } else {
+            f32x4 f = {0.f, 0.f, 0.f, 0.f};
+            if (g0 == G - 1 || g1 == G - 1) f = *(const f32x4 *)(h_fine + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = x + j;
+                const int g = (xx / SC == cx0) ? g0 : g1;
+                float s;
+                if (g == 0)
+                    s = h_coarse[(plane * hc + cy) * wc + xx / SC];
+                else if (G == 3 && g == 1)
+                    s = h_median[(plane * (2 * hc) + y / 2) * (2 * wc) + xx / 2];
+                else
+                    s = f[j];
+                v[j] = s;
+            }
+        }
+        *(f32x4 *)(h_out + o) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void entropy_gate_kernel(const float *__restrict__ ent, long n,
+                                                           float thr, long long *__restrict__ gate)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        float e = ent[i];
+        longlong2 g;
+        g.x = (e <= thr) ? 1 : 0;
+        g.y = (e > thr) ? 1 : 0;
+        *(longlong2 *)(gate + 2 * i) = g;
+    }
+}
+
+// out[n, :] = E[idx[n], :], D % 4 == 0; invalid index -> NaN row
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float *__restrict__ E, int K, int D,
+                                                           const long long *__restrict__ idx, long n,
+                                                           float *__restrict__ out)
+{
+    const int D4 = D / 4;
+    const size_t total = (size_t)n * D4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t row = i / D4;
+        int q = (int)(i - row * D4);
+        long long j = idx[row];
+        f32x4 v;
+        if (j >= 0 && j < K) {
+            v = *(const f32x4 *)(E + (size_t)j * D + 4 * q);
+        } else {
+            float nanv = __builtin_nanf("");
+            v = (f32x4){nanv, nanv, nanv, nanv};
+        }
+        *(f32x4 *)(out + row * D + 4 * q) = v;
+    }
+}
+
+static int grid_for(size_t items)
+{
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;     // 256 CUs x 16 resident 256-thread blocks
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
+                            const float *h_median, const float *h_fine, int B, int C, int hc, int wc,
+                            float *h_out, long long *indices, float *cmask, hipStream_t st)
+{
+    const int SC = (G == 2) ? 2 : 4;
+    size_t items = (size_t)B * (C + 1) * (SC * hc) * (SC * wc / 4);
+    dim3 grid(grid_for(items)), block(256);
+    if (G == 2 && gate_i64)
+        hipLaunchKernelGGL((route_select_kernel<2, true>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    else if (G == 2)
+        hipLaunchKernelGGL((route_select_kernel<2, false>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    else if (gate_i64)
+        hipLaunchKernelGGL((route_select_kernel<3, true>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    else
+        hipLaunchKernelGGL((route_select_kernel<3, false>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    return (int)hipGetLastError();
+}
+
+int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(entropy_gate_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, ent, n, thr, gate);
+    return (int)hipGetLastError();
+}
+
+int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)n * (D / 4))), dim3(256), 0, st, E, K, D, idx, n, out);
+    return (int)hipGetLastError();
+}

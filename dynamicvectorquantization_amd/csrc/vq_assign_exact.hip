@@ -1,0 +1,279 @@
+// vq_assign_exact.hip -- bit-exact nearest-codebook assignment on the fp32 matrix cores (gfx950).
+//
+// Replaces VQEmbedding.compute_distances + find_nearest_embedding + embed and the
+// VectorQuantize2.forward glue around them (reference modules/vector_quantization/
+// quantize2_mask.py:29-55,157-191; quantize_vqgan.py:271-312).
+//
+// Arithmetic contract (what torch-CPU produces, pinned by oracle/ + tests/golden):
+//   dot   = sequential k = 0..D-1 fp32 FMA chain from 0.  v_mfma_f32_32x32x2_f32 IS that chain,
+//           two k per instruction (D = fma(a1,b1, fma(a0,b0, C)), one rounding per product), so
+//           D/2 chained MFMAs give 32x32 bit-exact dots.
+//   xn,en = ATen-order sum of squares (32 strided partials, fixed combine order)
+//   d     = fl(fl(xn + en) - 2 dot);  argmin first index, NaN = minimum
+//   z_q   = fl(z + fl(e - z))
+//
+// Mapping: MFMA rows (A operand) = 32 codes, columns (B operand) = 32 tokens; lane (c, h) holds
+// token column c and, in the accumulator, 16 code rows {(r&3) + 8(r>>2) + 4h}, so the running
+// argmin is lane-local and only the two lane halves are merged at the end.
+// A wave keeps its 32 tokens' D channels in registers (D/2 VGPRs, read straight from NCHW: lanes
+// 0-31 / 32-63 read two 128-B runs of consecutive tokens per load) and streams the codebook as
+// prepared 32-code LDS tile images (double-buffered global->LDS DMA, one barrier per tile).
+// Compute-bound on the fp32 MFMA rate (2*K*D flop per token).
+#include "dvq_common.h"
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
+    const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
+    const float *__restrict__ mask, int HW, int K, long N,
+    float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials)
+{
+    constexpr int S = D / 2;                         // MFMA steps (2 k each)
+    constexpr int TILE_FLOATS = 32 * D + 64;
+    constexpr int CHUNKS_PER_WAVE = (32 * D * 4 / 1024) / 4;   // 1-KiB DMA pieces per wave per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * TILE_FLOATS (+ 4 doubles)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
+    const bool valid = n < N;
+    const long nn = valid ? n : N - 1;
+    const long b = nn / HW;
+    const int hw = (int)(nn - b * HW);
+    const size_t zbase = ((size_t)b * D + h) * HW + hw;      // channel k = 2s + h at zbase + 2s*HW
+    const float *zp = z + zbase;
+
+    float zr[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) zr[s] = zp[(size_t)2 * s * HW];
+
+    auto stage = [&](int t, float *buf) {
+        const char *src = (const char *)(tiles + (size_t)t * TILE_FLOATS);
+#pragma unroll
+        for (int i = 0; i < CHUNKS_PER_WAVE; ++i) {
+            int chunk = wave * CHUNKS_PER_WAVE + i;
+            glds16(src + chunk * 1024 + lane * 16, (char *)buf + chunk * 1024);
+        }
+        if (wave == 0) glds4(src + 32 * D * 4 + lane * 4, (char *)buf + 32 * D * 4);
+    };
+
+    const int T = dvq_num_tiles(K);
+    stage(0, lds);
+
+    // ---- xn: ATen-order sum of squares of this token (both lanes of a token get the same value)
+    float xn;
+    {
+        float p[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float a = sq_rn(zr[q]);
+#pragma unroll
+            for (int j = 1; j < S / 16; ++j) a = __fadd_rn(a, sq_rn(zr[q + 16 * j]));
+            p[q] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[q] = __shfl_xor(p[q], 32);
+        float t[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            // a[m], m = l + 8g: even m lives in the h = 0 lane's p[m/2], odd m in the h = 1 lane's
+            float a4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int m = l + 8 * g;
+                float mine = p[m >> 1], other = o[m >> 1];
+                a4[g] = ((m & 1) == h) ? mine : other;
+            }
+            t[l] = __fadd_rn(__fadd_rn(__fadd_rn(a4[0], a4[1]), a4[2]), a4[3]);
+        }
+        xn = t[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t[l]);
+    }
+
+    float best = __builtin_inff();
+    int bidx = 0x7fffffff;
+
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // tile t landed; everyone is done with tile t-1
+        float *buf = lds + (t & 1) * TILE_FLOATS;
+        if (t + 1 < T) stage(t + 1, lds + ((t + 1) & 1) * TILE_FLOATS);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float *ap = buf + c * 8 + h * 4;
+#pragma unroll
+        for (int kg = 0; kg < D / 8; ++kg) {
+            f32x4 a = *(const f32x4 *)(ap + kg * 256);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], zr[kg * 4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], zr[kg * 4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], zr[kg * 4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], zr[kg * 4 + 3], acc, 0, 0, 0);
+        }
+        const float *entile = buf + 32 * D + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 en4 = *(const f32x4 *)(entile + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int r = g * 4 + q;
+                int code = t * 32 + q + 8 * g + 4 * h;
+                float bias = __fadd_rn(xn, en4[q]);
+                float d = __builtin_fmaf(-2.0f, acc[r], bias);   // fl(bias - 2 dot), 2 dot exact
+                bool take = argmin_take(d, best) && (code < K);
+                best = take ? d : best;
+                bidx = take ? code : bidx;
+            }
+        }
+    }
+
+    {   // merge the two lane halves of each token
+        float ob = __shfl_xor(best, 32);
+        int oi = __shfl_xor(bidx, 32);
+        argmin_merge(best, bidx, ob, oi);
+    }
+    const int code = (bidx == 0x7fffffff) ? 0 : bidx;    // every distance +inf -> index 0
+    if (valid && h == 0) codes[n] = (long long)code;
+
+    // ---- z_q = z + (e - z), loss partial sum((e - z)^2 * m)
+    float lsum = 0.0f;
+    if (zq != nullptr || partials != nullptr) {
+        const float *ep = E + (size_t)code * D + h;
+        const float m = (mask != nullptr) ? mask[nn] : 1.0f;
+        float *zqp = zq ? zq + zbase : nullptr;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {          // fully unrolled: zr[] must stay in registers
+            float e = ep[2 * s];
+            float diff = __fsub_rn(e, zr[s]);
+            if (zqp != nullptr && valid) zqp[(size_t)2 * s * HW] = __fadd_rn(zr[s], diff);
+            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+        }
+        if (!valid) lsum = 0.0f;
+    }
+    if (partials != nullptr) {
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off);
+        __syncthreads();                       // all waves are done with the tile buffers
+        double *red = (double *)lds;
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// loss[0] = mean, loss[1] = fl(fl(beta*mean) + mean)   (quantize2_mask.py:175, quantize_vqgan.py:291)
+__global__ void vq_loss_finalize_kernel(const double *__restrict__ partials, int nparts,
+                                        double inv_numel, float beta, float *__restrict__ loss)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float mean = (float)(red[0] * inv_numel);
+        loss[0] = mean;
+        loss[1] = __fadd_rn(__fmul_rn(beta, mean), mean);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// codebook prep: f32 tile images + exact-order norms
+// ---------------------------------------------------------------------------------------------
+__global__ void codebook_prep_f32_kernel(const float *__restrict__ E, int K, int D,
+                                         float *__restrict__ tiles, float *__restrict__ en_all)
+{
+    const int T = dvq_num_tiles(K);
+    const size_t tile_floats = dvq_tile_floats(D);
+    const size_t total = (size_t)T * tile_floats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int t = (int)(i / tile_floats);
+        int r = (int)(i - (size_t)t * tile_floats);
+        float v = 0.0f;
+        if (r < 32 * D) {
+            int kg = r / 256, c = (r >> 3) & 31, p = r & 7;
+            int k = kg * 8 + 2 * (p & 3) + (p >> 2);
+            int code = t * 32 + c;
+            if (code < K) v = E[(size_t)code * D + k];
+        } else if (r < 32 * D + 32) {
+            int code = t * 32 + (r - 32 * D);
+            if (code < K) {
+                // ATen-order sum of squares (oracle/dvq_oracle.c: dvq_oracle_sumsq)
+                const float *e = E + (size_t)code * D;
+                float a[32];
+                for (int m = 0; m < 32; ++m) a[m] = 0.0f;
+                for (int k0 = 0; k0 < D; k0 += 32)
+                    for (int m = 0; m < 32; ++m) a[m] = __fadd_rn(a[m], sq_rn(e[k0 + m]));
+                float s = 0.0f;
+                for (int l = 0; l < 8; ++l) {
+                    float tl = __fadd_rn(__fadd_rn(__fadd_rn(a[l], a[l + 8]), a[l + 16]), a[l + 24]);
+                    s = (l == 0) ? tl : __fadd_rn(s, tl);
+                }
+                v = s;
+            }
+            en_all[t * 32 + (r - 32 * D)] = v;
+        }
+        tiles[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (called from dvq_abi.hip)
+// ---------------------------------------------------------------------------------------------
+int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st)
+{
+    float *tiles = (float *)prep;
+    float *en_all = (float *)((char *)prep + dvq_prep_en_offset(K, D));
+    size_t total = (size_t)dvq_num_tiles(K) * dvq_tile_floats(D);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(codebook_prep_f32_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, tiles, en_all);
+    return (int)hipGetLastError();
+}
+
+template <int D>
+static int launch_exact(const float *z, const float *tiles, const float *E, const float *mask,
+                        int HW, int K, long N, float *zq, long long *codes, double *partials,
+                        hipStream_t st)
+{
+    static bool attr_set = false;
+    const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_set = true;
+    }
+    int blocks = (int)((N + 127) / 128);
+    hipLaunchKernelGGL(vq_assign_exact_kernel<D>, dim3(blocks), dim3(256), shmem, st,
+                       z, tiles, E, mask, HW, K, N, zq, codes, partials);
+    return (int)hipGetLastError();
+}
+
+int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
+                     int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
+                     hipStream_t st)
+{
+    const float *tiles = prep;
+    switch (D) {
+    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
+    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
+    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
+    default:  return -1000;
+    }
+}
+
+int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
+                             float *loss, hipStream_t st)
+{
+    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nparts,
+                       inv_numel, beta, loss);
+    return (int)hipGetLastError();
+}

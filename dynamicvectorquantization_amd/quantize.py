@@ -1,0 +1,395 @@
+"""Drop-in quantizers backed by the HIP kernels of libdvq.so.
+
+Mirrors (constructor kwargs, forward signature, return structure, state_dict keys):
+  * VQEmbedding / VectorQuantize2  -- reference modules/vector_quantization/quantize2_mask.py:10-210
+    (also covers quantize2.py: identical class without the mask argument)
+  * VectorQuantizer2               -- reference modules/vector_quantization/quantize_vqgan.py:213-341
+so a reference YAML selects them by changing only the `target:` string, e.g.
+  target: dynamicvectorquantization_amd.quantize.VectorQuantize2
+
+The NCHW->NHWC copy, the [N, K] distance matrix, argmin, embedding gather, masked loss,
+straight-through add and the copy back of the reference are ONE kernel launch here
+(`dvq_vq_assign_nchw_f32`) reading z once from NCHW and writing z_q once.  Code indices equal the
+reference CPU path bit for bit, z_q too (two fp32 roundings), the loss to 1e-5 relative.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+from torch import nn
+from torch.nn import functional as F
+
+from . import _lib
+
+_lib_handle = _lib.lib
+
+
+class _CodebookPrep:
+    """Per-codebook device buffers of the assign kernels (tile images, exact norms), rebuilt
+    whenever the codebook tensor changes (version counter / storage / device)."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+        self.ws = None
+        self.ws_key = None
+
+    def get(self, codebook):
+        K, D = codebook.shape
+        key = (codebook.data_ptr(), codebook._version, K, D, codebook.device)
+        if key != self.key:
+            nbytes = _lib_handle.dvq_codebook_prep_bytes(K, D)
+            if nbytes == 0:
+                raise _lib.DvqError("unsupported codebook shape K=%d D=%d" % (K, D))
+            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != codebook.device:
+                self.buf = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
+            _lib.check(_lib_handle.dvq_codebook_prepare_f32(
+                codebook.data_ptr(), K, D, self.buf.data_ptr(), self.buf.numel(),
+                _lib.stream_ptr(codebook.device)), "dvq_codebook_prepare_f32")
+            self.key = key
+        return self.buf
+
+    def workspace(self, B, D, HW, K, mode, device):
+        key = (B, D, HW, K, mode, device)
+        if key != self.ws_key:
+            nbytes = _lib_handle.dvq_vq_assign_workspace_bytes(B, D, HW, K, mode)
+            self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.ws_key = key
+        return self.ws
+
+
+def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=True,
+              mode=_lib.MODE_FILTER, out=None):
+    """z [B, D, *spatial] f32 cuda, codebook [K, D] -> (zq or None, codes [B, *spatial] i64, loss[2] or None).
+
+    loss[0] = mean((e - z)^2 * mask), loss[1] = beta*mean + mean.  `out` may carry preallocated
+    (zq, codes, loss) tensors (used by the benchmark / graph capture)."""
+    z = _lib.require_cuda_f32(z, "z")
+    codebook = _lib.require_cuda_f32(codebook, "codebook")
+    B, D = z.shape[0], z.shape[1]
+    HW = 1
+    for s in z.shape[2:]:
+        HW *= s
+    K = codebook.shape[0]
+    if codebook.shape[1] != D:
+        raise ValueError("codebook dim %d != feature dim %d" % (codebook.shape[1], D))
+    if mask is not None:
+        mask = _lib.require_cuda_f32(mask, "codebook_mask")
+        if mask.numel() != B * HW:
+            raise ValueError("codebook_mask has %d elements, expected B*H*W = %d" % (mask.numel(), B * HW))
+    if out is not None:
+        zq, codes, loss = out
+    else:
+        zq = torch.empty_like(z) if want_zq else None
+        codes = torch.empty((B,) + tuple(z.shape[2:]), dtype=torch.int64, device=z.device)
+        loss = torch.empty(2, dtype=torch.float32, device=z.device) if want_loss else None
+    ws = prep.workspace(B, D, HW, K, mode, z.device)
+    with torch.cuda.device(z.device):
+        pbuf = prep.get(codebook)
+        _lib.check(_lib_handle.dvq_vq_assign_nchw_f32(
+            z.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
+            _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), ws.data_ptr(), ws.numel(), mode,
+            _lib.stream_ptr(z.device)), "dvq_vq_assign_nchw_f32")
+    return zq, codes, loss
+
+
+def embed_gather(codebook, idx):
+    """codebook[idx] (nn.Embedding forward) through dvq_embed_gather_f32."""
+    codebook = _lib.require_cuda_f32(codebook, "codebook")
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    idx = idx.contiguous()
+    K, D = codebook.shape
+    out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=codebook.device)
+    with torch.cuda.device(codebook.device):
+        _lib.check(_lib_handle.dvq_embed_gather_f32(codebook.data_ptr(), K, D, idx.data_ptr(), idx.numel(),
+                                                    out.data_ptr(), _lib.stream_ptr(codebook.device)),
+                   "dvq_embed_gather_f32")
+    return out
+
+
+class _VQStraightThrough(torch.autograd.Function):
+    """Forward = the fused kernel.  Backward = what autograd derives from the reference graph
+    (quantize2_mask.py:172-182 / quantize_vqgan.py:290-298): identity through z + (z_q - z).detach(),
+    plus the commitment-loss gradients 2 c (z - e) m / numel on z (c = coefficient of the
+    (z_q.detach() - z)^2 term) and 2 c' (e - z) m / numel scattered onto the codebook rows."""
+
+    @staticmethod
+    def forward(ctx, z, weight, mask, prep, K, coef_z, coef_e, mode):
+        codebook = weight[:K]
+        # beta*mean + mean is the same fp32 number whichever addend carries beta (legacy or not)
+        zq, codes, loss = vq_assign(z, codebook, prep, mask, beta=(coef_z if coef_e == 1.0 else coef_e), mode=mode)
+        ctx.save_for_backward(z, weight, mask, codes)
+        ctx.K, ctx.coef_z, ctx.coef_e = K, coef_z, coef_e
+        ctx.mark_non_differentiable(codes)
+        return zq, loss[1], codes
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _g_codes):
+        z, weight, mask, codes = ctx.saved_tensors
+        B, D = z.shape[0], z.shape[1]
+        e = F.embedding(codes.reshape(B, -1), weight[:ctx.K]).permute(0, 2, 1).reshape(z.shape)
+        diff = z - e
+        if mask is not None:
+            diff = diff * mask.reshape(B, 1, *z.shape[2:])
+        scale = 2.0 / z.numel()
+        gz = g_zq
+        gw = None
+        if g_loss is not None:
+            if ctx.needs_input_grad[0]:
+                gz = (g_zq if g_zq is not None else 0) + g_loss * (ctx.coef_z * scale) * diff
+            if ctx.needs_input_grad[1]:
+                gw = torch.zeros_like(weight)
+                ge = (-(g_loss * (ctx.coef_e * scale)) * diff).reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D)
+                gw.index_add_(0, codes.reshape(-1), ge)
+        return gz, gw, None, None, None, None, None, None
+
+
+class VQEmbedding(nn.Embedding):
+    """EMA codebook; same parameters/buffers as the reference class (quantize2_mask.py:10-132):
+    weight [K+1, D] (row K is the padding row), cluster_size_ema [K], embed_ema [K, D]."""
+
+    def __init__(self, n_embed, embed_dim, ema=True, decay=0.99, restart_unused_codes=True, eps=1e-5):
+        super().__init__(n_embed + 1, embed_dim, padding_idx=n_embed)
+        self.ema = ema
+        self.decay = decay
+        self.eps = eps
+        self.restart_unused_codes = restart_unused_codes
+        self.n_embed = n_embed
+        if self.ema:
+            _ = [p.requires_grad_(False) for p in self.parameters()]
+            self.register_buffer('cluster_size_ema', torch.zeros(n_embed))
+            self.register_buffer('embed_ema', self.weight[:-1, :].detach().clone())
+        self._prep = _CodebookPrep()
+
+    @property
+    def codes(self):
+        """the K live codebook rows (weight[:-1], quantize2_mask.py:31)"""
+        return self.weight[:-1, :]
+
+    @torch.no_grad()
+    def compute_distances(self, inputs):
+        """Dense [.., K] distances (quantize2_mask.py:29-48).  Only get_soft_codes needs the full
+        matrix; it is evaluated with torch ops (hipBLASLt), tolerance-level, not by the kernel."""
+        codebook_t = self.weight[:-1, :].t()
+        embed_dim = codebook_t.shape[0]
+        assert inputs.shape[-1] == embed_dim
+        flat = inputs.reshape(-1, embed_dim)
+        d = torch.addmm(flat.pow(2.).sum(dim=1, keepdim=True) + codebook_t.pow(2.).sum(dim=0, keepdim=True),
+                        flat, codebook_t, alpha=-2.0)
+        return d.reshape(*inputs.shape[:-1], -1)
+
+    @torch.no_grad()
+    def find_nearest_embedding(self, inputs):
+        """inputs [..., D] channel-last -> indices [...] (quantize2_mask.py:50-55), by the kernel."""
+        flat = inputs.reshape(-1, inputs.shape[-1])
+        _, codes, _ = vq_assign(flat.contiguous(), self.codes, self._prep, want_zq=False, want_loss=False)
+        return codes.reshape(inputs.shape[:-1])
+
+    @torch.no_grad()
+    def _tile_with_noise(self, x, target_n):
+        B, embed_dim = x.shape
+        n_repeats = (target_n + B - 1) // B
+        std = x.new_ones(embed_dim) * 0.01 / math.sqrt(embed_dim)
+        x = x.repeat(n_repeats, 1)
+        return x + torch.rand_like(x) * std
+
+    @torch.no_grad()
+    def _update_buffers(self, vectors, idxs):
+        """Training-mode EMA statistics (quantize2_mask.py:66-105).  The reference builds a dense
+        one-hot [K, N] matrix and multiplies; here the same sums are a bincount and an index_add
+        (summation order differs: tolerance-level parity), followed by the same collectives."""
+        n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
+        vectors = vectors.reshape(-1, embed_dim)
+        idxs = idxs.reshape(-1)
+        n_vectors = vectors.shape[0]
+        cluster_size = torch.bincount(idxs, minlength=n_embed).to(vectors.dtype)
+        vectors_sum_per_cluster = vectors.new_zeros(n_embed, embed_dim).index_add_(0, idxs, vectors)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(vectors_sum_per_cluster, op=dist.ReduceOp.SUM)
+            dist.all_reduce(cluster_size, op=dist.ReduceOp.SUM)
+        self.cluster_size_ema.mul_(self.decay).add_(cluster_size, alpha=1 - self.decay)
+        self.embed_ema.mul_(self.decay).add_(vectors_sum_per_cluster, alpha=1 - self.decay)
+        if self.restart_unused_codes:
+            if n_vectors < n_embed:
+                vectors = self._tile_with_noise(vectors, n_embed)
+            n_vectors = vectors.shape[0]
+            _vectors_random = vectors[torch.randperm(n_vectors, device=vectors.device)][:n_embed]
+            if dist.is_available() and dist.is_initialized():
+                dist.broadcast(_vectors_random, 0)
+            usage = (self.cluster_size_ema.view(-1, 1) >= 1).float()
+            self.embed_ema.mul_(usage).add_(_vectors_random * (1 - usage))
+            self.cluster_size_ema.mul_(usage.view(-1))
+            self.cluster_size_ema.add_(torch.ones_like(self.cluster_size_ema) * (1 - usage).view(-1))
+
+    @torch.no_grad()
+    def _update_embedding(self):
+        n_embed = self.weight.shape[0] - 1
+        n = self.cluster_size_ema.sum()
+        normalized_cluster_size = n * (self.cluster_size_ema + self.eps) / (n + n_embed * self.eps)
+        self.weight[:-1, :] = self.embed_ema / normalized_cluster_size.reshape(-1, 1)
+
+    def forward(self, inputs):
+        """inputs [..., D] -> (embeds [..., D], idxs [...]) (quantize2_mask.py:117-128)."""
+        embed_idxs = self.find_nearest_embedding(inputs)
+        if self.training and self.ema:
+            self._update_buffers(inputs, embed_idxs)
+        embeds = self.embed(embed_idxs)
+        if self.ema and self.training:
+            self._update_embedding()
+        return embeds, embed_idxs
+
+    def embed(self, idxs):
+        if idxs.is_cuda and not (torch.is_grad_enabled() and self.weight.requires_grad):
+            return embed_gather(self.weight, idxs)
+        return super().forward(idxs)
+
+
+class VectorQuantize2(nn.Module):
+    """Reference modules/vector_quantization/quantize2_mask.py:135-210 (and quantize2.py:135)."""
+
+    def __init__(self, codebook_size, codebook_dim=None, accept_image_fmap=True, commitment_beta=0.25,
+                 decay=0.99, restart_unused_codes=True, channel_last=False):
+        super().__init__()
+        self.accept_image_fmap = accept_image_fmap
+        self.beta = commitment_beta
+        self.channel_last = channel_last
+        self.restart_unused_codes = restart_unused_codes
+        self.codebook = VQEmbedding(codebook_size, codebook_dim, decay=decay,
+                                    restart_unused_codes=restart_unused_codes)
+        self.codebook.weight.data.uniform_(-1.0 / codebook_size, 1.0 / codebook_size)
+        self.assign_mode = _lib.MODE_FILTER
+
+    def forward(self, x, codebook_mask=None, *ignorewargs, **ignorekwargs):
+        need_transpose = not self.channel_last and not self.accept_image_fmap
+        if self.accept_image_fmap:
+            if x.dim() != 4:
+                raise ValueError("accept_image_fmap=True expects x [B, C, H, W]")
+            z = x                                        # NCHW read in place by the kernel
+        elif need_transpose:                             # x is [B, D, N]: already channel-major
+            z = x
+        else:                                            # channel_last: x [B, ..., D] -> tokens [N, D]
+            z = x.reshape(-1, x.shape[-1])
+        K = self.codebook.n_embed
+        mask = None
+        if codebook_mask is not None:
+            mask = codebook_mask
+            if mask.dtype != torch.float32:
+                mask = mask.float()
+        zq, loss, codes = _VQStraightThrough.apply(z, self.codebook.weight, mask, self.codebook._prep, K,
+                                                   float(self.beta), 1.0, self.assign_mode)
+        if self.training and self.codebook.ema:
+            with torch.no_grad():
+                if self.accept_image_fmap or need_transpose:     # channel-major -> token rows
+                    ztok = z.reshape(z.shape[0], z.shape[1], -1).permute(0, 2, 1)
+                else:
+                    ztok = z
+                self.codebook._update_buffers(ztok, codes.reshape(-1))
+                self.codebook._update_embedding()
+        if self.accept_image_fmap or need_transpose:
+            x_q = zq
+            x_code = codes                               # [B, H, W] / [B, N]
+        else:
+            x_q = zq.reshape(x.shape)
+            x_code = codes.reshape(x.shape[:-1])
+            if x_code.dim() > 2:                         # 'h ... d -> h (...) d' (quantize2_mask.py:167)
+                x_code = x_code.reshape(x.shape[0], -1)
+        return x_q, loss, (None, None, x_code)
+
+    @torch.no_grad()
+    def get_soft_codes(self, x, temp=1.0, stochastic=False):
+        distances = self.codebook.compute_distances(x)
+        soft_code = F.softmax(-distances / temp, dim=-1)
+        if stochastic:
+            soft_code_flat = soft_code.reshape(-1, soft_code.shape[-1])
+            code = torch.multinomial(soft_code_flat, 1)
+            code = code.reshape(*soft_code.shape[:-1])
+        else:
+            code = distances.argmin(dim=-1)
+        return soft_code, code
+
+    def get_codebook_entry(self, indices, *kwargs):
+        return self.codebook.embed(indices)
+
+
+class VectorQuantizer2(nn.Module):
+    """Reference modules/vector_quantization/quantize_vqgan.py:213-341 (taming-style quantizer,
+    used by the fixed-granularity VQModel with beta=0.25, remap=None, legacy=False)."""
+
+    def __init__(self, n_e, e_dim, beta, remap=None, unknown_index="random", sane_index_shape=False,
+                 legacy=True):
+        super().__init__()
+        self.n_e = n_e
+        self.e_dim = e_dim
+        self.beta = beta
+        self.legacy = legacy
+        self.embedding = nn.Embedding(self.n_e, self.e_dim)
+        self.embedding.weight.data.uniform_(-1.0 / self.n_e, 1.0 / self.n_e)
+        self.remap = remap
+        if self.remap is not None:
+            import numpy as np
+            self.register_buffer("used", torch.tensor(np.load(self.remap)))
+            self.re_embed = self.used.shape[0]
+            self.unknown_index = unknown_index
+            if self.unknown_index == "extra":
+                self.unknown_index = self.re_embed
+                self.re_embed = self.re_embed + 1
+        else:
+            self.re_embed = n_e
+        self.sane_index_shape = sane_index_shape
+        self._prep = _CodebookPrep()
+        self.assign_mode = _lib.MODE_FILTER
+
+    def remap_to_used(self, inds):
+        ishape = inds.shape
+        assert len(ishape) > 1
+        inds = inds.reshape(ishape[0], -1)
+        used = self.used.to(inds)
+        match = (inds[:, :, None] == used[None, None, ...]).long()
+        new = match.argmax(-1)
+        unknown = match.sum(2) < 1
+        if self.unknown_index == "random":
+            new[unknown] = torch.randint(0, self.re_embed, size=new[unknown].shape).to(device=new.device)
+        else:
+            new[unknown] = self.unknown_index
+        return new.reshape(ishape)
+
+    def unmap_to_all(self, inds):
+        ishape = inds.shape
+        assert len(ishape) > 1
+        inds = inds.reshape(ishape[0], -1)
+        used = self.used.to(inds)
+        if self.re_embed > self.used.shape[0]:
+            inds[inds >= self.used.shape[0]] = 0
+        back = torch.gather(used[None, :][inds.shape[0] * [0], :], 1, inds)
+        return back.reshape(ishape)
+
+    def forward(self, z, temp=None, rescale_logits=False, return_logits=False):
+        assert temp is None or temp == 1.0, "Only for interface compatible with Gumbel"
+        assert rescale_logits is False, "Only for interface compatible with Gumbel"
+        assert return_logits is False, "Only for interface compatible with Gumbel"
+        if z.dim() != 4:
+            raise ValueError("VectorQuantizer2 expects z [B, C, H, W]")
+        # legacy=False: beta*mean((zq.detach()-z)^2) + mean((zq-z.detach())^2); legacy=True swaps beta
+        coef_z, coef_e = (1.0, float(self.beta)) if self.legacy else (float(self.beta), 1.0)
+        z_q, loss, codes = _VQStraightThrough.apply(z, self.embedding.weight, None, self._prep, self.n_e,
+                                                    coef_z, coef_e, self.assign_mode)
+        min_encoding_indices = codes.reshape(-1)
+        if self.remap is not None:
+            min_encoding_indices = min_encoding_indices.reshape(z.shape[0], -1)
+            min_encoding_indices = self.remap_to_used(min_encoding_indices)
+            min_encoding_indices = min_encoding_indices.reshape(-1, 1)
+        if self.sane_index_shape:
+            min_encoding_indices = min_encoding_indices.reshape(z_q.shape[0], z_q.shape[2], z_q.shape[3])
+        return z_q, loss, (None, None, min_encoding_indices)
+
+    def get_codebook_entry(self, indices, shape=None):
+        if self.remap is not None:
+            indices = indices.reshape(shape[0], -1)
+            indices = self.unmap_to_all(indices)
+            indices = indices.reshape(-1)
+        z_q = embed_gather(self.embedding.weight, indices) if indices.is_cuda else self.embedding(indices)
+        if shape is not None:
+            z_q = z_q.view(shape)
+            z_q = z_q.permute(0, 3, 1, 2).contiguous()
+        return z_q

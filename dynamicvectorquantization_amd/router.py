@@ -1,0 +1,178 @@
+"""Drop-in routers and the routing tail ("scatter/gather") backed by libdvq.so.
+
+Mirrors
+  * DualGrainFixedEntropyRouter, DualGrainFeatureRouter -- reference modules/dynamic_modules/RouterDual.py:6-57
+  * TripleGrainFeatureRouter                            -- reference modules/dynamic_modules/RouterTriple.py:6-56
+  * route_select_dual / route_select_triple             -- the eval-mode tails of
+    DualGrainEncoder.forward (EncoderDual.py:134-156) and TripleGrainEncoder.forward (EncoderTriple.py:148-183)
+Same constructor kwargs (including the reference's misspelt `fine_grain_ratito`), forward
+signatures, return structures and state_dict keys (`gate.*`, `feature_norm_{fine,median,coarse}.*`).
+
+The entropy gate and both selects are HIP kernels (one launch each).  The feature routers' gate
+MLP (GroupNorm -> AvgPool -> concat -> Linear/SiLU/Linear) is a small dense GEMM and stays on
+PyTorch-ROCm (MIOpen / hipBLASLt) -- SURVEY.md section 8 row a8/a9, fused version is row f4.
+"""
+import json
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_lib_handle = _lib.lib
+
+
+def entropy_gate(entropy, threshold):
+    """[...] f32 entropy -> [..., 2] int64 gate = cat[(ent <= thr), (ent > thr)] (RouterDual.py:54-56)."""
+    entropy = _lib.require_cuda_f32(entropy, "entropy")
+    gate = torch.empty(tuple(entropy.shape) + (2,), dtype=torch.int64, device=entropy.device)
+    with torch.cuda.device(entropy.device):
+        _lib.check(_lib_handle.dvq_entropy_gate_f32(entropy.data_ptr(), entropy.numel(), float(threshold),
+                                                    gate.data_ptr(), _lib.stream_ptr(entropy.device)),
+                   "dvq_entropy_gate_f32")
+    return gate
+
+
+def _gate_arg(gate, G):
+    if not gate.is_cuda:
+        raise _lib.DvqError("gate is on %s: the dvq kernels run on the GPU only" % gate.device)
+    if gate.dim() != 4 or gate.shape[-1] != G:
+        raise ValueError("gate must be [B, h, w, %d], got %s" % (G, tuple(gate.shape)))
+    if gate.dtype == torch.int64:
+        return gate.contiguous(), _lib.GATE_I64
+    if gate.dtype != torch.float32:
+        gate = gate.float()
+    return gate.contiguous(), _lib.GATE_F32
+
+
+def route_select_dual(gate, h_coarse, h_fine, out=None):
+    """gate [B, hc, wc, 2] (router output, f32 logits or int64), h_coarse [B, C, hc, wc],
+    h_fine [B, C, 2hc, 2wc] -> dict(h_dual, indices, codebook_mask, gate) exactly as
+    DualGrainEncoder.forward returns it in eval mode (EncoderDual.py:151-156):
+    indices [B, hc, wc] int64 (0 coarse / 1 fine), codebook_mask [B, 1, 2hc, 2wc] f32 (0.25 / 1.0),
+    gate permuted to [B, 2, hc, wc]."""
+    g, gdt = _gate_arg(gate, 2)
+    h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
+    h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
+    B, C, hc, wc = h_coarse.shape
+    if tuple(h_fine.shape) != (B, C, 2 * hc, 2 * wc) or tuple(g.shape[:3]) != (B, hc, wc):
+        raise ValueError("shape mismatch: gate %s h_coarse %s h_fine %s" %
+                         (tuple(gate.shape), tuple(h_coarse.shape), tuple(h_fine.shape)))
+    if out is not None:
+        h_dual, indices, cmask = out
+    else:
+        h_dual = torch.empty_like(h_fine)
+        indices = torch.empty((B, hc, wc), dtype=torch.int64, device=h_fine.device)
+        cmask = torch.empty((B, 1, 2 * hc, 2 * wc), dtype=torch.float32, device=h_fine.device)
+    with torch.cuda.device(h_fine.device):
+        _lib.check(_lib_handle.dvq_route_select_dual_f32(
+            g.data_ptr(), gdt, h_coarse.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
+            h_dual.data_ptr(), indices.data_ptr(), cmask.data_ptr(), _lib.stream_ptr(h_fine.device)),
+            "dvq_route_select_dual_f32")
+    return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
+
+
+def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
+    """gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
+    -> dict(h_triple, indices, codebook_mask, gate) as TripleGrainEncoder.forward (EncoderTriple.py:178-183);
+    mask values 0.0625 / 0.25 / 1.0."""
+    g, gdt = _gate_arg(gate, 3)
+    h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
+    h_median = _lib.require_cuda_f32(h_median, "h_median")
+    h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
+    B, C, hc, wc = h_coarse.shape
+    if (tuple(h_median.shape) != (B, C, 2 * hc, 2 * wc) or tuple(h_fine.shape) != (B, C, 4 * hc, 4 * wc)
+            or tuple(g.shape[:3]) != (B, hc, wc)):
+        raise ValueError("shape mismatch: gate %s h_coarse %s h_median %s h_fine %s" %
+                         (tuple(gate.shape), tuple(h_coarse.shape), tuple(h_median.shape), tuple(h_fine.shape)))
+    if out is not None:
+        h_triple, indices, cmask = out
+    else:
+        h_triple = torch.empty_like(h_fine)
+        indices = torch.empty((B, hc, wc), dtype=torch.int64, device=h_fine.device)
+        cmask = torch.empty((B, 1, 4 * hc, 4 * wc), dtype=torch.float32, device=h_fine.device)
+    with torch.cuda.device(h_fine.device):
+        _lib.check(_lib_handle.dvq_route_select_triple_f32(
+            g.data_ptr(), gdt, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
+            h_triple.data_ptr(), indices.data_ptr(), cmask.data_ptr(), _lib.stream_ptr(h_fine.device)),
+            "dvq_route_select_triple_f32")
+    return {"h_triple": h_triple, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
+
+
+class DualGrainFixedEntropyRouter(nn.Module):
+    """RouterDual.py:46-57.  threshold = json[str(int(100 - ratio*100))]."""
+
+    def __init__(self, json_path, fine_grain_ratito):
+        super().__init__()
+        with open(json_path, "r", encoding="utf-8") as f:
+            content = json.load(f)
+        self.fine_grain_threshold = content["{}".format(str(int(100 - fine_grain_ratito * 100)))]
+
+    def forward(self, h_fine=None, h_coarse=None, entropy=None):
+        return entropy_gate(entropy, self.fine_grain_threshold)
+
+
+def _make_gate(gate_type, width, splits, allow_relu):
+    if gate_type == "1layer-fc":
+        return nn.Linear(width, splits)
+    if gate_type == "2layer-fc-SiLu":
+        return nn.Sequential(nn.Linear(width, width), nn.SiLU(inplace=True), nn.Linear(width, splits))
+    if allow_relu and gate_type == "2layer-fc-ReLu":
+        return nn.Sequential(nn.Linear(width, width), nn.ReLU(inplace=True), nn.Linear(width, splits))
+    raise NotImplementedError()
+
+
+def _make_norm(normalization_type, num_channels):
+    if normalization_type == "none":
+        return nn.Identity()
+    if "group" in normalization_type:  # like "group-32"
+        num_groups = int(normalization_type.split("-")[-1])
+        return nn.GroupNorm(num_groups=num_groups, num_channels=num_channels, eps=1e-6, affine=True)
+    raise NotImplementedError()
+
+
+class DualGrainFeatureRouter(nn.Module):
+    """RouterDual.py:6-43: GroupNorm both branches, 2x2 average-pool the fine one, concat channels,
+    NHWC, gate MLP -> logits [B, hc, wc, 2]."""
+
+    def __init__(self, num_channels, normalization_type="none", gate_type="1layer-fc"):
+        super().__init__()
+        self.gate_pool = nn.AvgPool2d(2, 2)
+        self.gate_type = gate_type
+        self.gate = _make_gate(gate_type, num_channels * 2, 2, allow_relu=False)
+        self.num_splits = 2
+        self.normalization_type = normalization_type
+        self.feature_norm_fine = _make_norm(normalization_type, num_channels)
+        self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
+
+    def forward(self, h_fine, h_coarse, entropy=None):
+        h_fine = self.feature_norm_fine(h_fine)
+        h_coarse = self.feature_norm_coarse(h_coarse)
+        avg_h_fine = self.gate_pool(h_fine)
+        h_logistic = torch.cat([h_coarse, avg_h_fine], dim=1).permute(0, 2, 3, 1)
+        return self.gate(h_logistic)
+
+
+class TripleGrainFeatureRouter(nn.Module):
+    """RouterTriple.py:6-56: three GroupNorms, 4x4 / 2x2 pools, concat -> MLP -> logits [B, hc, wc, 3]."""
+
+    def __init__(self, num_channels, normalization_type="none", gate_type="1layer-fc"):
+        super().__init__()
+        self.gate_median_pool = nn.AvgPool2d(2, 2)
+        self.gate_fine_pool = nn.AvgPool2d(4, 4)
+        self.num_splits = 3
+        self.gate_type = gate_type
+        self.gate = _make_gate(gate_type, num_channels * 3, 3, allow_relu=True)
+        self.normalization_type = normalization_type
+        self.feature_norm_fine = _make_norm(normalization_type, num_channels)
+        self.feature_norm_median = _make_norm(normalization_type, num_channels)
+        self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
+
+    def forward(self, h_fine, h_median, h_coarse, entropy=None):
+        h_fine = self.feature_norm_fine(h_fine)
+        h_median = self.feature_norm_median(h_median)
+        h_coarse = self.feature_norm_coarse(h_coarse)
+        avg_h_fine = self.gate_fine_pool(h_fine)
+        avg_h_median = self.gate_median_pool(h_median)
+        h_logistic = torch.cat([h_coarse, avg_h_median, avg_h_fine], dim=1).permute(0, 2, 3, 1)
+        return self.gate(h_logistic)

@@ -1,0 +1,117 @@
+/*
+ * dvq.h -- C ABI of libdvq.so: the MI355X (gfx950) implementation of the DQ-VAE
+ * vector-quantization hot path.
+ *
+ * The reference (Corleone-Huang/DynamicVectorQuantization) is pure Python and
+ * has no FFI of its own; each entry point below replaces the listed PyTorch op
+ * sequence of the reference, and is what a ctypes binding in the reference
+ * would call (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); nothing is allocated or freed inside;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
+ *     are stream-ordered, never synchronise, and are re-entrant;
+ *   - return value: DVQ_OK (0) or a negative DVQ_E* code; the message of the
+ *     last failure on the calling thread is dvq_last_error_string();
+ *   - tensors are dense, C-contiguous, float32 unless stated; code indices and
+ *     grain indices are int64 (the reference's dtype).
+ */
+#ifndef DVQ_H_
+#define DVQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVQ_OK            0
+#define DVQ_EINVAL       (-1)  /* bad argument (null pointer, non-positive size, ...) */
+#define DVQ_EUNSUPPORTED (-2)  /* shape outside what the kernels implement            */
+#define DVQ_EWORKSPACE   (-3)  /* workspace / prep buffer too small                   */
+#define DVQ_EHIP         (-4)  /* HIP runtime error on launch                         */
+
+/* assign modes */
+#define DVQ_MODE_EXACT   0  /* every (token, code) distance by the exact fp32 MFMA chain     */
+#define DVQ_MODE_FILTER  1  /* fp16-MFMA filter with a rigorous error bound; every token that  */
+                            /* is not provably decided is re-evaluated by the exact chain.     */
+                            /* Output is identical to DVQ_MODE_EXACT.                          */
+
+/* gate dtypes for the router select */
+#define DVQ_GATE_F32 0
+#define DVQ_GATE_I64 1
+
+int dvq_version(void);
+const char *dvq_last_error_string(void);
+
+/*
+ * Codebook preparation -- run once per codebook (weights change only in training).
+ * Replaces: codebook_t.pow(2).sum(0)  (quantize2_mask.py:31,40) /
+ *           torch.sum(embedding.weight**2, dim=1) (quantize_vqgan.py:281)
+ * and lays the codebook out as the LDS tile images the assign kernels stream.
+ *   codebook [K, D] (for VQEmbedding pass weight[:-1]); prep: >= dvq_codebook_prep_bytes(K, D)
+ */
+size_t dvq_codebook_prep_bytes(int K, int D);
+int dvq_codebook_prepare_f32(const float *codebook, int K, int D,
+                             void *prep, size_t prep_bytes, void *stream);
+
+/*
+ * Nearest-codebook assignment + quantised latents + commitment-loss sum.
+ * Replaces: VectorQuantize2.forward (quantize2_mask.py:157-191: NCHW->NHWC copy,
+ *           VQEmbedding.compute_distances :29-48, find_nearest_embedding :50-55,
+ *           embed :130-132, masked loss :172-179, straight-through :182, NHWC->NCHW :187-189)
+ *           and VectorQuantizer2.forward (quantize_vqgan.py:271-312).
+ *   z        [B, D, HW]        (NCHW feature map, HW = H*W; HW == 1 is the flat [N, D] case)
+ *   codebook [K, D], prep from dvq_codebook_prepare_f32 of the SAME codebook
+ *   mask     nullable [B, HW]  (codebook_mask [B,1,H,W])
+ *   zq       nullable [B, D, HW]   z + (e - z), two fp32 roundings like the reference
+ *   codes    [B, HW] int64         first-index argmin, NaN = minimum (torch CPU semantics)
+ *   loss     nullable [2] f32: loss[0] = mean((e-z)^2*mask), loss[1] = fl(fl(beta*mean)+mean)
+ *   ws       >= dvq_vq_assign_workspace_bytes(...)
+ * Distances follow the reference's fp32 arithmetic bit for bit: sequential-k FMA
+ * chain, ATen-order norms, d = fl(fl(xn+en) - 2 dot).
+ */
+size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode);
+int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *prep,
+                           const float *mask, int B, int D, int HW, int K, float beta,
+                           float *zq, int64_t *codes, float *loss,
+                           void *ws, size_t ws_bytes, int mode, void *stream);
+
+/* nn.Embedding gather (quantize2_mask.py:130-132, get_codebook_entry :207-210):
+ * out[n, :] = codebook[idx[n], :];  an index outside [0, K) writes NaNs to that row. */
+int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx,
+                         int64_t n, float *out, void *stream);
+
+/* DualGrainFixedEntropyRouter.forward (RouterDual.py:53-57):
+ * gate[i, 0] = entropy[i] <= thr, gate[i, 1] = entropy[i] > thr, int64. */
+int dvq_entropy_gate_f32(const float *entropy, int64_t n, float thr, int64_t *gate,
+                         void *stream);
+
+/*
+ * Routing tail of DualGrainEncoder.forward in eval mode (EncoderDual.py:134-149):
+ * argmax over the 2 gate values, nearest x2 upsample of h_coarse, select, codebook_mask.
+ *   gate [B, hc, wc, 2] (DVQ_GATE_F32 logits or DVQ_GATE_I64)
+ *   h_coarse [B, C, hc, wc], h_fine [B, C, 2hc, 2wc]
+ *   h_out [B, C, 2hc, 2wc], indices [B, hc, wc] int64, cmask [B, 1, 2hc, 2wc] (0.25 / 1.0)
+ */
+int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
+                              const float *h_coarse, const float *h_fine,
+                              int B, int C, int hc, int wc,
+                              float *h_out, int64_t *indices, float *cmask, void *stream);
+
+/*
+ * Routing tail of TripleGrainEncoder.forward in eval mode (EncoderTriple.py:148-176).
+ *   gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
+ *   cmask values 0.0625 / 0.25 / 1.0
+ */
+int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
+                                const float *h_coarse, const float *h_median,
+                                const float *h_fine, int B, int C, int hc, int wc,
+                                float *h_out, int64_t *indices, float *cmask, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVQ_H_ */

@@ -1,0 +1,368 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs, against the golden vectors captured from the reference, and -- at BASELINE.json's
+full sizes -- through size-independent properties.  Bar: code indices, grain indices, routed
+features and z_q BIT-EXACT; loss within 1e-5 relative (north_star tolerance)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _cases as C
+
+pytestmark = pytest.mark.gpu
+
+MODES = [0, 1]   # DVQ_MODE_EXACT, DVQ_MODE_FILTER -- must produce identical outputs
+
+
+def _vq2(dev, E, mode):
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    K, D = E.shape
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    vq.assign_mode = mode
+    return vq
+
+
+def _run_vq2(dev, z, E, mask, mode):
+    vq = _vq2(dev, E, mode)
+    with torch.no_grad():
+        xq, loss, (a, b, codes) = vq(torch.from_numpy(z).to(dev),
+                                     codebook_mask=None if mask is None else torch.from_numpy(mask).to(dev))
+    assert a is None and b is None and codes.dtype == torch.int64
+    return xq.cpu().numpy(), float(loss), codes.cpu().numpy()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", C.VQ2_FULL + C.VQ2_CRC)
+def test_vq2_golden(dev, name, mode):
+    """reference golden vectors: cfg-2/3 shapes, tie-stress default-init codebook, K=16384, 16x16"""
+    g = C.load(name)
+    z, E, mask = C.vq2_inputs(g)
+    xq, loss, codes = _run_vq2(dev, z, E, mask, mode)
+    assert codes.shape == (int(g["B"]), int(g["H"]), int(g["W"]))
+    if "codes" in g:
+        assert np.array_equal(codes, g["codes"].astype(np.int64))
+    else:
+        assert np.array_equal(codes[0], g["codes_image0"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(codes), g["codes_crc"])       # int64 codes, bit-exact
+    assert np.array_equal(C.per_image_crc(xq), g["zq_crc"])             # z_q bit-exact
+    assert C.loss_close(loss, g["loss"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", C.VQGAN)
+def test_vqgan_golden(dev, name, mode):
+    """BASELINE configs[0]: fixed-granularity VectorQuantizer2, 16x16x256, K=1024, B=4"""
+    from dynamicvectorquantization_amd.quantize import VectorQuantizer2
+    g = C.load(name)
+    z, E = C.vqgan_inputs(g)
+    m = VectorQuantizer2(int(g["K"]), int(g["D"]), beta=0.25, legacy=bool(g["legacy"]),
+                         sane_index_shape=bool(g["sane"])).to(dev).eval()
+    m.embedding.weight.data.copy_(torch.from_numpy(E))
+    m.assign_mode = mode
+    with torch.no_grad():
+        zq, loss, (p, me, idx) = m(torch.from_numpy(z).to(dev))
+    assert p is None and me is None and idx.dtype == torch.int64
+    assert tuple(idx.shape) == tuple(g["idx_shape"])
+    assert np.array_equal(idx.cpu().numpy(), g["codes"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(zq.cpu().numpy()), g["zq_crc"])
+    assert C.loss_close(float(loss), g["loss"])
+    with pytest.raises(AssertionError):
+        m(torch.from_numpy(z).to(dev), temp=0.5)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_special_values(dev, mode):
+    """duplicated code rows (first index), NaN / +-inf tokens (NaN = minimum), zero and -0 tokens"""
+    g = C.load("vq2_tiny_full")
+    xq, loss, codes = _run_vq2(dev, g["z"], g["codebook"], g["mask"], mode)
+    assert np.array_equal(codes, g["codes"])
+    assert np.array_equal(xq, g["zq"], equal_nan=True)
+    assert C.loss_close(loss, g["loss"])
+    # 2-D mask branch (quantize2_mask.py:177) on image 1 only
+    vq = _vq2(dev, g["codebook"], mode)
+    with torch.no_grad():
+        xq1, loss1, (_, _, c1) = vq(torch.from_numpy(g["z"][1:]).to(dev),
+                                    codebook_mask=torch.from_numpy(g["mask"][1:, 0].reshape(1, 64)).to(dev))
+    assert np.array_equal(c1.cpu().numpy(), g["codes_img1"]) and C.loss_close(float(loss1), g["loss_img1_flatmask"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("shape", [(1, 1, 1, 33), (3, 5, 7, 100), (2, 8, 8, 1000), (1, 3, 3, 31), (5, 1, 1, 64)])
+def test_ragged_shapes_vs_oracle(dev, oracle_mod, shape, mode):
+    """token counts that are not multiples of the 32/128-token tiles, K not a multiple of 32, K < 32"""
+    from dynamicvectorquantization_amd import synth
+    B, H, W, K = shape
+    E = synth.codebook_trained(K, 256, seed=800 + K)
+    z = synth.z_tokens(E, B, H, W, 810 + K)
+    mask = np.where(synth.bernoulli(820 + K, (B, 1, H, W), 0.5), 1.0, 0.0625).astype(np.float32)
+    xq, loss, codes = _run_vq2(dev, z, E, mask, mode)
+    o = oracle_mod.vq_assign_nchw(z, E, mask)
+    assert np.array_equal(codes.reshape(B, -1), o["codes"])
+    assert np.array_equal(xq, o["zq"])
+    assert C.loss_close(loss, oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("D", [64, 128])
+def test_other_dims_vs_oracle(dev, oracle_mod, D, mode):
+    from dynamicvectorquantization_amd import synth
+    E = synth.codebook_trained(512, D, seed=900 + D)
+    z = synth.z_tokens(E, 2, 16, 16, 910 + D)
+    xq, loss, codes = _run_vq2(dev, z, E, None, mode)
+    o = oracle_mod.vq_assign_nchw(z, E, None)
+    assert np.array_equal(codes.reshape(2, -1), o["codes"]) and np.array_equal(xq, o["zq"])
+    assert C.loss_close(loss, oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_near_tie_adversarial(dev, oracle_mod, mode):
+    """tokens placed (almost) exactly between two codes, duplicated / nearly duplicated codes,
+    huge and tiny magnitudes: the cases where an approximate filter must fall back to the exact chain"""
+    from dynamicvectorquantization_amd import synth
+    K, D = 256, 256
+    E = synth.codebook_trained(K, D, seed=61)
+    E[100] = E[40]                                             # exact duplicate
+    E[101] = E[41] * (1 + np.float32(2 ** -22))                # 1-ulp-scale near duplicate
+    E[102:110] = E[50] + synth.normal(62, (8, D), 0, 1e-6)     # tight cluster
+    z = synth.z_tokens(E, 2, 16, 16, 63)
+    zt = z.transpose(0, 2, 3, 1)
+    zt[0, 0, :, :] = ((E[0:16] + E[16:32]) * np.float32(0.5))           # midpoints
+    zt[0, 1, :, :] = E[40:56]                                            # on a code (one duplicated)
+    zt[0, 2, :, :] = E[96:112]
+    zt[0, 3, :, :] = E[0:16] * np.float32(1e4)                           # large magnitude
+    zt[0, 4, :, :] = E[0:16] * np.float32(1e-6)                          # tiny magnitude
+    zt[0, 5, :, :] = E[0:16] * np.float32(3e38 / 1e4)                    # overflow territory
+    z = np.ascontiguousarray(zt.transpose(0, 3, 1, 2))
+    xq, loss, codes = _run_vq2(dev, z, E, None, mode)
+    o = oracle_mod.vq_assign_nchw(z, E, None)
+    assert np.array_equal(codes.reshape(2, -1), o["codes"])
+    assert np.array_equal(xq, o["zq"], equal_nan=True)
+
+
+def test_channel_last_and_sequence_layouts(dev, oracle_mod):
+    """accept_image_fmap=False: channel_last [B, N, D] (flat tokens) and [B, D, N] inputs"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    K, D = 128, 256
+    E = synth.codebook_trained(K, D, seed=66)
+    z = synth.z_tokens(E, 2, 4, 8, 67)                        # [2, D, 4, 8]
+    o = oracle_mod.vq_assign_nchw(z, E, None)
+    zs = torch.from_numpy(z.reshape(2, D, 32)).to(dev)
+    for kw, x in ((dict(accept_image_fmap=False, channel_last=True), zs.permute(0, 2, 1).contiguous()),
+                  (dict(accept_image_fmap=False, channel_last=False), zs)):
+        vq = VectorQuantize2(K, D, **kw).to(dev).eval()
+        vq.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+        with torch.no_grad():
+            xq, loss, (_, _, codes) = vq(x)
+        assert tuple(xq.shape) == tuple(x.shape) and tuple(codes.shape) == (2, 32)
+        assert np.array_equal(codes.cpu().numpy(), o["codes"])
+        xq_cm = xq.permute(0, 2, 1) if kw["channel_last"] else xq
+        assert np.array_equal(xq_cm.cpu().numpy().reshape(z.shape), o["zq"])
+        assert C.loss_close(float(loss), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+
+
+def test_codebook_entry_and_nearest(dev, oracle_mod):
+    from dynamicvectorquantization_amd import synth
+    K, D = 1024, 256
+    E = synth.codebook_trained(K, D)
+    vq = _vq2(dev, E, 1)
+    idx = torch.from_numpy(synth.randint(5, (2, 32, 32), K)).to(dev)
+    zq = vq.get_codebook_entry(idx)                           # [B, H, W, D] like the reference
+    assert tuple(zq.shape) == (2, 32, 32, D)
+    assert np.array_equal(zq.cpu().numpy(), E[idx.cpu().numpy()])
+    emb, ids = vq.codebook(zq)                                # VQEmbedding.forward on channel-last input
+    assert np.array_equal(ids.cpu().numpy(), idx.cpu().numpy()) and np.array_equal(emb.cpu().numpy(), zq.cpu().numpy())
+    # codebook edits are picked up (prep cache keyed on the tensor version)
+    with torch.no_grad():
+        vq.codebook.weight[:-1].mul_(0.5)
+    z = synth.z_tokens(E, 1, 8, 8, 6)
+    with torch.no_grad():
+        _, _, (_, _, c) = vq(torch.from_numpy(z).to(dev))
+    o = oracle_mod.vq_assign_nchw(z, E * np.float32(0.5), None)
+    assert np.array_equal(c.cpu().numpy().reshape(1, -1), o["codes"])
+
+
+def test_entropy_router_golden(dev, golden_dir):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    g = C.load("entropy_router")
+    ent = synth.entropy_map(int(g["seed"]), int(g["B"]), 16, 16)
+    js = os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json")
+    for ratio in (0.5, 0.3, 0.85):
+        r = DualGrainFixedEntropyRouter(js, ratio)
+        e2 = ent.copy()
+        e2[0, 0, 0] = np.float32(r.fine_grain_threshold)
+        gate = r(entropy=torch.from_numpy(e2).to(dev))
+        assert gate.dtype == torch.int64 and tuple(gate.shape) == (int(g["B"]), 16, 16, 2)
+        assert np.array_equal(gate.cpu().numpy(), g["gate_r%02d" % int(ratio * 100)].astype(np.int64))
+
+
+def test_route_select_dual_golden(dev):
+    from dynamicvectorquantization_amd.router import route_select_dual
+    g = C.load("route_dual_B2")
+    gate, hc, hf = C.route_dual_inputs(g)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for gt, suffix in ((gate, ""), (g["logits"], "_logits")):     # int64 gate; f32 logits with ties / NaN
+        out = route_select_dual(t(gt), t(hc), t(hf))
+        assert out["indices"].dtype == torch.int64 and out["codebook_mask"].dtype == torch.float32
+        assert tuple(out["gate"].shape) == (2, 2, 16, 16) and tuple(out["codebook_mask"].shape) == (2, 1, 32, 32)
+        assert np.array_equal(out["indices"].cpu().numpy(), g["indices" + suffix].astype(np.int64))
+        assert np.array_equal(out["codebook_mask"].cpu().numpy(), g["cmask" + suffix])
+        assert np.array_equal(C.per_image_crc(out["h_dual"].cpu().numpy()), g["h_crc" + suffix])
+
+
+def test_route_select_triple_golden(dev):
+    from dynamicvectorquantization_amd.router import route_select_triple
+    g = C.load("route_triple_B2")
+    lg, hc, hm, hf = C.route_triple_inputs(g)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = route_select_triple(t(lg), t(hc), t(hm), t(hf))
+    assert np.array_equal(out["indices"].cpu().numpy(), g["indices"].astype(np.int64))
+    assert np.array_equal(out["codebook_mask"].cpu().numpy(), g["cmask"])
+    assert np.array_equal(C.per_image_crc(out["h_triple"].cpu().numpy()), g["h_crc"])
+    assert tuple(out["gate"].shape) == (2, 3, 8, 8)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 1, 2), (3, 5, 3, 6), (2, 256, 16, 16)])
+def test_route_select_shapes_vs_oracle(dev, oracle_mod, shape):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import route_select_dual, route_select_triple
+    B, Cc, hc_, wc_ = shape
+    t = lambda a: torch.from_numpy(a).to(dev)
+    hf, hc = synth.features(1, B, Cc, 2 * hc_, 2 * wc_), synth.features(2, B, Cc, hc_, wc_)
+    gate = synth.grain_gate_dual(3, B, hc_, wc_)
+    out = route_select_dual(t(gate), t(hc), t(hf))
+    o = oracle_mod.route_select_dual(gate, hc, hf)
+    for k in ("h_dual", "indices", "codebook_mask"):
+        assert np.array_equal(out[k].cpu().numpy(), o[k]), k
+    hf, hm = synth.features(4, B, Cc, 4 * hc_, 4 * wc_), synth.features(5, B, Cc, 2 * hc_, 2 * wc_)
+    lg = synth.grain_logits_triple(6, B, hc_, wc_)
+    out = route_select_triple(t(lg), t(hc), t(hm), t(hf))
+    o = oracle_mod.route_select_triple(lg, hc, hm, hf)
+    for k in ("h_triple", "indices", "codebook_mask"):
+        assert np.array_equal(out[k].cpu().numpy(), o[k]), k
+
+
+@pytest.mark.parametrize("which", ["dual", "triple"])
+def test_feature_router_logits(dev, which):
+    """feature routers run on PyTorch-ROCm (GroupNorm, exp, k=512/768 GEMM: not bit-reproducible):
+    logits within 1e-4, grain indices equal wherever the reference margin exceeds 1e-3"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    g = C.load("feature_router_" + which)
+    B, Cc = int(g["B"]), 256
+    r = (DualGrainFeatureRouter if which == "dual" else TripleGrainFeatureRouter)(256, "group-32", "2layer-fc-SiLu")
+    sd = {k: torch.from_numpy(synth.seeded_param(int(g["seed"]), i, k, tuple(v.shape)))
+          for i, (k, v) in enumerate(r.state_dict().items())}
+    r.load_state_dict(sd)
+    r = r.to(dev).eval()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    with torch.no_grad():
+        if which == "dual":
+            lg = r(h_fine=t(synth.features(3002, B, Cc, 32, 32)), h_coarse=t(synth.features(3012, B, Cc, 16, 16)))
+        else:
+            lg = r(h_fine=t(synth.features(3004, B, Cc, 32, 32)), h_median=t(synth.features(3014, B, Cc, 16, 16)),
+                   h_coarse=t(synth.features(3024, B, Cc, 8, 8)))
+    ref = g["logits"]
+    got = lg.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < 1e-4, "logit max-abs-diff %.3g" % np.max(np.abs(got - ref))
+    srt = np.sort(ref, axis=-1)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert np.array_equal(got.argmax(-1)[clear], ref.argmax(-1)[clear])
+
+
+def test_encode_dual_end_to_end(dev, oracle_mod, golden_dir):
+    """BASELINE configs[2] shape at B=4: entropy router -> select -> VectorQuantize2 (encode glue)"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    B, K, D = 4, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hc = synth.z_tokens(E, B, 32, 32, 2103), synth.z_tokens(E, B, 16, 16, 2113)
+    ent = synth.entropy_map(5103, B, 16, 16)
+    r = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    vq = _vq2(dev, E, 1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    with torch.no_grad():
+        quant, emb_loss, info, grain, gate = encode_dual(r, vq, t(hf), t(hc), entropy=t(ent))
+    og = oracle_mod.entropy_gate(ent, r.fine_grain_threshold)
+    osel = oracle_mod.route_select_dual(og, hc, hf)
+    o = oracle_mod.vq_assign_nchw(osel["h_dual"], E, osel["codebook_mask"])
+    assert np.array_equal(grain.cpu().numpy(), osel["indices"]) and tuple(gate.shape) == (B, 2, 16, 16)
+    assert np.array_equal(info[2].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(quant.cpu().numpy(), o["zq"])
+    assert C.loss_close(float(emb_loss), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    c = info[2].cpu().numpy()
+    coarse = osel["indices"] == 0                               # all 2x2 codes of a coarse cell are equal
+    for dy in (0, 1):
+        for dx in (0, 1):
+            assert np.array_equal(c[:, dy::2, dx::2][coarse], c[:, 0::2, 0::2][coarse])
+
+
+def test_encode_triple_end_to_end(dev, oracle_mod):
+    """BASELINE configs[3] shape at B=2 (per-rank slice of the 8-GPU job)"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_triple
+    B, K, D = 2, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hm, hc = (synth.z_tokens(E, B, 32, 32, 2104), synth.z_tokens(E, B, 16, 16, 2114),
+                  synth.z_tokens(E, B, 8, 8, 2124))
+    lg = synth.grain_logits_triple(4104, B, 8, 8)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    router = lambda h_fine, h_median, h_coarse, entropy=None: t(lg)
+    vq = _vq2(dev, E, 1)
+    with torch.no_grad():
+        quant, emb_loss, info, grain, gate = encode_triple(router, vq, t(hf), t(hm), t(hc))
+    osel = oracle_mod.route_select_triple(lg, hc, hm, hf)
+    o = oracle_mod.vq_assign_nchw(osel["h_triple"], E, osel["codebook_mask"])
+    assert np.array_equal(grain.cpu().numpy(), osel["indices"])
+    assert np.array_equal(info[2].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(quant.cpu().numpy(), o["zq"])
+    assert C.loss_close(float(emb_loss), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_full_size_properties_cfg3(dev, oracle_mod, mode):
+    """BASELINE configs[2] at full size (B=256, 32x32x256, K=1024): properties that need no dense
+    CPU run -- (1) encode -> gather -> re-encode is idempotent with z_q == e, (2) exact and filter
+    modes agree, (3) a random sample of tokens equals the oracle, (4) loss equals the mean of
+    (z_q - z)^2 recomputed by torch."""
+    from dynamicvectorquantization_amd import synth
+    B, K, D = 256, 1024, 256
+    E = synth.codebook_trained(K, D)
+    vq = _vq2(dev, E, mode)
+    z = torch.from_numpy(synth.z_tokens(E, B, 32, 32, 2003)).to(dev)
+    with torch.no_grad():
+        xq, loss, (_, _, codes) = vq(z)
+        e = vq.get_codebook_entry(codes).permute(0, 3, 1, 2).contiguous()
+        xq2, loss2, (_, _, codes2) = vq(e)
+    assert torch.equal(codes2, codes) and torch.equal(xq2, e) and float(loss2) == 0.0
+    assert float(torch.max(torch.abs(xq - e))) <= 1e-5            # z + (e - z) vs e
+    ref_loss = (1.25 * torch.mean((e.double() - z.double()) ** 2)).item()
+    assert abs(float(loss) - ref_loss) <= 1e-5 * ref_loss
+    g = C.load("vq2_cfg3_B256_crc")
+    assert np.array_equal(C.per_image_crc(codes.cpu().numpy()), g["codes_crc"])
+    sample = np.arange(0, B, 37)
+    zs = z[sample].cpu().numpy()
+    o = oracle_mod.vq_assign_nchw(zs, E, None)
+    assert np.array_equal(codes[sample].cpu().numpy().reshape(len(sample), -1), o["codes"])
+    assert np.array_equal(xq[sample].cpu().numpy(), o["zq"])
+
+
+def test_autograd_straight_through(dev):
+    """gradient = identity through z_q plus the commitment term 2*beta*(z - e)*m/numel"""
+    from dynamicvectorquantization_amd import synth
+    K, D = 64, 256
+    E = synth.codebook_trained(K, D, seed=3)
+    vq = _vq2(dev, E, 1)
+    z = torch.from_numpy(synth.z_tokens(E, 1, 4, 4, 4)).to(dev).requires_grad_(True)
+    mask = torch.full((1, 1, 4, 4), 0.25, device=dev)
+    xq, loss, (_, _, codes) = vq(z, codebook_mask=mask)
+    (xq.sum() + 3.0 * loss).backward()
+    e = vq.get_codebook_entry(codes).permute(0, 3, 1, 2)
+    expect = 1.0 + 3.0 * 0.25 * 2.0 * (z.detach() - e) * mask / z.numel()
+    assert torch.allclose(z.grad, expect, rtol=1e-5, atol=1e-8)

@@ -1,0 +1,109 @@
+"""CPU: the oracle (oracle/dvq_oracle.c) against every golden vector captured from the reference."""
+import numpy as np
+import pytest
+
+from tests import _cases as C
+
+
+@pytest.mark.parametrize("name", C.VQ2_FULL + C.VQ2_CRC[:1])
+def test_vq2_oracle_matches_reference(oracle_mod, name):
+    g = C.load(name)
+    z, E, mask = C.vq2_inputs(g)
+    o = oracle_mod.vq_assign_nchw(z, E, mask)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    codes = o["codes"].reshape(B, H, W)
+    if "codes" in g:
+        assert np.array_equal(codes, g["codes"].astype(np.int64))
+    else:
+        assert np.array_equal(codes[0], g["codes_image0"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(codes), g["codes_crc"])
+    assert np.array_equal(C.per_image_crc(o["zq"]), g["zq_crc"])          # z_q bit-exact
+    loss = oracle_mod.vq_loss(o["sqerr"], o["numel"], float(g["beta"]))
+    assert C.loss_close(loss, g["loss"])
+
+
+@pytest.mark.parametrize("name", C.VQGAN)
+def test_vqgan_oracle_matches_reference(oracle_mod, name):
+    g = C.load(name)
+    z, E = C.vqgan_inputs(g)
+    o = oracle_mod.vq_assign_nchw(z, E, None)
+    assert np.array_equal(o["codes"].reshape(g["idx_shape"]), g["codes"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(o["zq"]), g["zq_crc"])
+    loss = oracle_mod.vq_loss(o["sqerr"], o["numel"], float(g["beta"]), legacy=bool(g["legacy"]))
+    assert C.loss_close(loss, g["loss"])
+
+
+def test_tiny_full_special_values(oracle_mod):
+    """duplicates (first index wins), NaN / +-inf tokens, zero tokens -- explicit inputs/outputs"""
+    g = C.load("vq2_tiny_full")
+    o = oracle_mod.vq_assign_nchw(g["z"], g["codebook"], g["mask"])
+    assert np.array_equal(o["codes"].reshape(g["codes"].shape), g["codes"])
+    assert np.array_equal(o["zq"], g["zq"], equal_nan=True)
+    assert g["codes"][0, 0, 0] == 3 and g["codes"][0, 0, 1] == 0      # tie -> first; NaN row -> 0
+    o1 = oracle_mod.vq_assign_nchw(g["z"][1:], g["codebook"], g["mask"][1:])
+    loss = oracle_mod.vq_loss(o1["sqerr"], o1["numel"], 0.25)
+    assert C.loss_close(loss, g["loss_img1_flatmask"])
+    o0 = oracle_mod.vq_assign_nchw(g["z"], g["codebook"], g["mask"])
+    assert C.loss_close(oracle_mod.vq_loss(o0["sqerr"], o0["numel"], 0.25), g["loss"])
+
+
+def test_entropy_gate(oracle_mod, golden_dir):
+    import json
+    import os
+    from dynamicvectorquantization_amd import synth
+    g = C.load("entropy_router")
+    ent = synth.entropy_map(int(g["seed"]), int(g["B"]), 16, 16)
+    assert C.crc(ent) == g["ent_crc"]
+    with open(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json")) as f:
+        table = json.load(f)
+    assert table["50"] == 1.6777750253677368
+    for ratio in (0.5, 0.3, 0.85):
+        key = "r%02d" % int(ratio * 100)
+        thr = table[str(int(100 - ratio * 100))]
+        assert thr == float(g["thr_" + key])
+        e2 = ent.copy()
+        e2[0, 0, 0] = np.float32(thr)                                  # == thr -> coarse
+        gate = oracle_mod.entropy_gate(e2, thr)
+        assert np.array_equal(gate, g["gate_" + key].astype(np.int64))
+        assert gate[0, 0, 0, 0] == 1 and gate[0, 0, 0, 1] == 0
+
+
+def test_route_select_dual(oracle_mod):
+    g = C.load("route_dual_B2")
+    gate, hc, hf = C.route_dual_inputs(g)
+    o = oracle_mod.route_select_dual(gate, hc, hf)
+    assert np.array_equal(o["indices"], g["indices"].astype(np.int64))
+    assert np.array_equal(o["codebook_mask"], g["cmask"]) and o["codebook_mask"].dtype == np.float32
+    assert np.array_equal(C.per_image_crc(o["h_dual"]), g["h_crc"])
+    o = oracle_mod.route_select_dual(g["logits"], hc, hf)               # f32 logits with ties and NaN
+    assert np.array_equal(o["indices"], g["indices_logits"].astype(np.int64))
+    assert np.array_equal(o["codebook_mask"], g["cmask_logits"])
+    assert np.array_equal(C.per_image_crc(o["h_dual"]), g["h_crc_logits"])
+
+
+def test_route_select_triple(oracle_mod):
+    g = C.load("route_triple_B2")
+    lg, hc, hm, hf = C.route_triple_inputs(g)
+    o = oracle_mod.route_select_triple(lg, hc, hm, hf)
+    assert np.array_equal(o["indices"], g["indices"].astype(np.int64))
+    assert np.array_equal(o["codebook_mask"], g["cmask"])
+    assert np.array_equal(C.per_image_crc(o["h_triple"]), g["h_crc"])
+    assert set(np.unique(o["codebook_mask"])) <= {0.0625, 0.25, 1.0}
+
+
+def test_oracle_properties(oracle_mod):
+    """idempotence: quantising z_q's winning rows again returns the same codes with distance ~0;
+    coarse 2x2 cells (bit-identical inputs) get identical codes."""
+    from dynamicvectorquantization_amd import synth
+    K, D = 256, 256
+    E = synth.codebook_trained(K, D, seed=71)
+    idx = synth.randint(72, (1, 16, 16), K)
+    z = np.ascontiguousarray(E[idx].transpose(0, 3, 1, 2))
+    o = oracle_mod.vq_assign_nchw(z, E, None, want_dmin=True)
+    assert np.array_equal(o["codes"].reshape(1, 16, 16), idx)
+    assert np.array_equal(o["zq"], z)
+    zc = synth.normal(73, (1, D, 8, 8))
+    zr = zc.repeat(2, axis=2).repeat(2, axis=3)
+    o = oracle_mod.vq_assign_nchw(zr, E, None)
+    c = o["codes"].reshape(16, 16)
+    assert np.array_equal(c[0::2, 0::2], c[1::2, 1::2]) and np.array_equal(c[0::2, 0::2], c[0::2, 1::2])
