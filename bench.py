@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the DQ-VAE vector-quantization hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch that is already resident in HBM:
+    entropy-threshold gate -> dual-granularity route select (+ codebook_mask)
+    -> VQ nearest-codebook assignment (codes, z_q, masked commitment loss)
+on BASELINE.json configs[2] (dqvae-entropy-dual-r05: B=256 per GPU, 32x32x256 latents, K=1024).
+The 1x1 quant_conv between select and VQ is a vendor GEMM outside the path
+and is not run.  With N > 1 ranks every rank encodes its own 256 images (weak scaling) and the
+step ends with the RCCL all-gather of the emitted code / grain indices.
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--codes", type=int, default=1024)
+    ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(E, B_gpu, target_s):
+    """the oracle (explicit-order C restatement of what the reference's torch-CPU path computes)
+    timed on this box's host cores on a bounded sample of the same workload"""
+    from dynamicvectorquantization_amd import synth
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    probe_b = 2
+    hf = synth.z_tokens(E, probe_b, 32, 32, 2903)
+    mask = np.ones((probe_b, 1, 32, 32), np.float32)
+    oracle.vq_assign_nchw(hf[:1], E, mask[:1])                       # warm
+    t0 = time.perf_counter()
+    oracle.vq_assign_nchw(hf, E, mask)
+    per_img = (time.perf_counter() - t0) / probe_b
+    nb = int(max(4, min(B_gpu, target_s / max(per_img, 1e-6))))
+    hf = synth.z_tokens(E, nb, 32, 32, 2903)
+    hc = synth.z_tokens(E, nb, 16, 16, 2913)
+    ent = synth.entropy_map(5903, nb, 16, 16)
+    t0 = time.perf_counter()
+    gate = oracle.entropy_gate(ent, 1.6777750253677368)
+    sel = oracle.route_select_dual(gate, hc, hf)
+    oracle.vq_assign_nchw(sel["h_dual"], E, sel["codebook_mask"])
+    dt = time.perf_counter() - t0
+    return {"value": nb / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images of the same workload (gate + select + VQ assign), oracle C port with "
+                      "OpenMP over tokens + AVX2 FMA chains, %.1f s" % (nb, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dynamicvectorquantization_amd import _lib, synth
+    from dynamicvectorquantization_amd.encode import all_gather_codes
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    from dynamicvectorquantization_amd.router import entropy_gate, route_select_dual
+
+    B, K, D, H, W = a.batch, a.codes, 256, 32, 32
+    mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
+    E_np = synth.codebook_trained(K, D)
+    off = rank * B
+    h_fine = torch.from_numpy(synth.z_tokens(E_np, B, H, W, 2903, image_offset=off)).to(dev)
+    h_coarse = torch.from_numpy(synth.z_tokens(E_np, B, H // 2, W // 2, 2913, image_offset=off)).to(dev)
+    ent = torch.from_numpy(synth.entropy_map(5903, B, H // 2, W // 2, image_offset=off)).to(dev)
+    E = torch.from_numpy(E_np).to(dev)
+    thr = 1.6777750253677368                       # imagenet_train JSON, key "50" (ratio 0.5)
+    prep = _CodebookPrep()
+    # preallocated outputs: the step allocates nothing
+    h_dual = torch.empty_like(h_fine)
+    grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
+    cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    zq = torch.empty_like(h_fine)
+    codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        gate = entropy_gate(ent, thr)
+        route_select_dual(gate, h_coarse, h_fine, out=(h_dual, grain, cmask))
+        if i is not None:
+            ev[i][0].record()
+        vq_assign(h_dual, E, prep, cmask, beta=0.25, mode=mode, out=(zq, codes, loss))
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            return all_gather_codes(codes, grain, loss[0] * (B * H * W * D), B * H * W * D, K, B * world)
+        return codes, grain, loss[0]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    N = B * H * W
+    alg_bytes = N * (D * 4 * 2 + 8 + 4) + K * D * 4          # z read + z_q write + int64 code + mask, codebook once
+    alg_flops = 2.0 * K * D * N
+    gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+    tfs = alg_flops / (kern_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a.mode, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if a.mode == "filter":
+        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}
+    else:
+        roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
+    roof.update({"kernel": "vq_assign (%s)" % a.mode, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                 "algorithmic_flops": alg_flops, "hbm_gbps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                 "fp32_tflops_equiv": tfs})
+    if rank == 0:
+        out = {
+            "metric": "images encoded/sec (VQ hot path: gate + route select + VQ assign), 256x256 inputs, K=%d" % K,
+            "value": B * world * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, "
+                                   "K=%d, entropy gate + dual route select + VectorQuantize2 assign "
+                                   "(quant_conv not in the path)" % (B, K),
+                       "global_batch": B * world, "assign_mode": a.mode,
+                       "parallelism": "image-parallel x%d, RCCL all-gather of codes" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(E_np, B, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
