@@ -23,7 +23,8 @@ GATE_I64 = 1
 
 EXPORTS = (
     "dvq_version", "dvq_last_error_string", "dvq_codebook_prep_bytes", "dvq_codebook_prepare_f32",
-    "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_embed_gather_f32",
+    "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_fallback_count_offset",
+    "dvq_embed_gather_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_triple_f32",
 )
 
@@ -59,6 +60,8 @@ def _load():
     lib.dvq_codebook_prepare_f32.argtypes = [vp, i32, i32, vp, sz, vp]
     lib.dvq_vq_assign_workspace_bytes.restype = sz
     lib.dvq_vq_assign_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.dvq_vq_assign_fallback_count_offset.restype = sz
+    lib.dvq_vq_assign_fallback_count_offset.argtypes = [i32, i32, i32, i32]
     lib.dvq_vq_assign_nchw_f32.restype = i32
     lib.dvq_vq_assign_nchw_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, i32, vp]
     lib.dvq_embed_gather_f32.restype = i32

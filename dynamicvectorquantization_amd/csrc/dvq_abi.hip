@@ -29,6 +29,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
                       void *ws_extra, hipStream_t st);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
+int dvq_filter_nparts(long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
                              float *loss, hipStream_t st);
 int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
@@ -46,6 +47,13 @@ static int hip_rc(int rc, const char *what)
 }
 
 static bool dim_ok(int D) { return D == 64 || D == 128 || D == 256; }
+
+// loss partials: pass 1 / exact blocks (<= 2 ceil(N/128)), resolver blocks (<= max(32, ceil(N/128)))
+static size_t partials_bytes_for(long N)
+{
+    size_t count = 3 * (size_t)((N + 127) / 128) + 32;
+    return (count * sizeof(double) + 255) / 256 * 256;
+}
 
 extern "C" {
 
@@ -80,9 +88,17 @@ size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode)
 {
     if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) return 0;
     long N = (long)B * HW;
-    size_t partials = ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    size_t partials = partials_bytes_for(N);
     size_t extra = (mode == DVQ_MODE_FILTER) ? dvq_filter_ws_extra_bytes(D, HW, K, N) : 0;
     return partials + extra + 256;
+}
+
+size_t dvq_vq_assign_fallback_count_offset(int B, int D, int HW, int K)
+{
+    (void)D; (void)K;
+    if (B <= 0 || HW <= 0) return 0;
+    long N = (long)B * HW;
+    return partials_bytes_for(N);
 }
 
 int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *prep,
@@ -104,15 +120,14 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     if (ws && ((uintptr_t)ws & 255) != 0) { dvq_set_error("dvq_vq_assign_nchw_f32: workspace must be 256-byte aligned"); return DVQ_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     double *partials = loss ? (double *)ws : nullptr;
-    size_t partials_bytes = ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    size_t partials_bytes = partials_bytes_for(N);
     int nparts;
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
                                (char *)ws + partials_bytes, st);
-        if (rc < 0 && rc != -1000) return rc;            // already reported
         if (rc) return hip_rc(rc, "vq_assign_filter");
-        nparts = (int)((N + 127) / 128);
+        nparts = dvq_filter_nparts(N);
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
                               (long long *)codes, partials, st);

@@ -25,7 +25,8 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
     const float *__restrict__ mask, int HW, int K, long N,
-    float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials)
+    float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
+    const int *__restrict__ list, const int *__restrict__ list_count)
 {
     constexpr int S = D / 2;                         // MFMA steps (2 k each)
     constexpr int TILE_FLOATS = 32 * D + 64;
@@ -35,9 +36,20 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
-    const bool valid = n < N;
-    const long nn = valid ? n : N - 1;
+    // tokens: the dense range [0, N), or (pass 2 of the filter path) the entries of a work list
+    long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
+    bool valid = n < N;
+    long nn = valid ? n : N - 1;
+    if (list != nullptr) {
+        const int cnt = *list_count;
+        if ((long)blockIdx.x * 128 >= cnt) {             // block-uniform: nothing queued for this block
+            if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
+            return;
+        }
+        valid = n < cnt;
+        n = list[valid ? n : 0];
+        nn = n;
+    }
     const long b = nn / HW;
     const int hw = (int)(nn - b * HW);
     const size_t zbase = ((size_t)b * D + h) * HW + hw;      // channel k = 2s + h at zbase + 2s*HW
@@ -242,7 +254,7 @@ int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st
 template <int D>
 static int launch_exact(const float *z, const float *tiles, const float *E, const float *mask,
                         int HW, int K, long N, float *zq, long long *codes, double *partials,
-                        hipStream_t st)
+                        const int *list, const int *list_count, hipStream_t st)
 {
     static bool attr_set = false;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
@@ -253,8 +265,21 @@ static int launch_exact(const float *z, const float *tiles, const float *E, cons
     }
     int blocks = (int)((N + 127) / 128);
     hipLaunchKernelGGL(vq_assign_exact_kernel<D>, dim3(blocks), dim3(256), shmem, st,
-                       z, tiles, E, mask, HW, K, N, zq, codes, partials);
+                       z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count);
     return (int)hipGetLastError();
+}
+
+// pass 2 of the filter path: the tokens listed in list[0 .. *list_count)
+int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
+                          int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
+                          const int *list, const int *list_count, hipStream_t st)
+{
+    switch (D) {
+    case 64:  return launch_exact<64>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
+    case 128: return launch_exact<128>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
+    case 256: return launch_exact<256>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
+    default:  return -1000;
+    }
 }
 
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
@@ -263,9 +288,9 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
 {
     const float *tiles = prep;
     switch (D) {
-    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
-    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
-    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, st);
+    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
+    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
+    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
     default:  return -1000;
     }
 }

@@ -57,6 +57,18 @@ class _CodebookPrep:
             self.ws_key = key
         return self.ws
 
+    def fallback_count(self):
+        """(tokens queued for the resolver, tokens sent to the full exact pass) of the last
+        filter-mode call on this workspace (syncs)"""
+        if self.ws_key is None:
+            return (0, 0)
+        B, D, HW, K, mode, _dev = self.ws_key
+        if mode != _lib.MODE_FILTER:
+            return (0, 0)
+        off = _lib_handle.dvq_vq_assign_fallback_count_offset(B, D, HW, K)
+        c = self.ws[off:off + 8].view(torch.int32).tolist()
+        return (int(c[0]), int(c[1]))
+
 
 def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=True,
               mode=_lib.MODE_FILTER, out=None):

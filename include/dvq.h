@@ -79,6 +79,12 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
                            float *zq, int64_t *codes, float *loss,
                            void *ws, size_t ws_bytes, int mode, void *stream);
 
+/* Diagnostic: byte offset inside the workspace of two int32 counters of the last DVQ_MODE_FILTER
+ * call on that workspace: [0] tokens queued for the resolver (best and runner-up closer than the
+ * error bound), [1] tokens handed to the full exact pass (non-finite / unscalable tokens,
+ * overflow).  Read them after the stream has drained. */
+size_t dvq_vq_assign_fallback_count_offset(int B, int D, int HW, int K);
+
 /* nn.Embedding gather (quantize2_mask.py:130-132, get_codebook_entry :207-210):
  * out[n, :] = codebook[idx[n], :];  an index outside [0, K) writes NaNs to that row. */
 int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx,
