@@ -6,6 +6,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DVQ_CODE_TILE 32  // codes per MFMA tile (rows of a 32x32 MFMA)
 
@@ -30,6 +33,18 @@ __host__ __device__ inline size_t dvq_prep_en_offset(int K, int D) { return dvq_
 __host__ __device__ inline size_t dvq_prep_f16_offset(int K, int D)
 {
     return dvq_prep_en_offset(K, D) + (size_t)dvq_num_tiles(K) * 32 * sizeof(float);
+}
+
+// XCD-aware block remap (bijective for any grid size): consecutive tiles go to ONE XCD, so the
+// adjacent pieces of a DRAM row / the shared operands are requested close together in time by
+// one L2.  blockIdx % 8 labels the blocks that share an XCD (dispatch is round-robin); this is a
+// speed heuristic only -- any placement gives the same results.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
 }
 
 // async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16

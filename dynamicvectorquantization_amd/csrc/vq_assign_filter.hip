@@ -111,21 +111,32 @@ __global__ __launch_bounds__(1024) void codebook_meta_kernel(const float *__rest
 
 __global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__restrict__ E, int K, int D,
                                                                 const DvqF16Meta *__restrict__ meta,
-                                                                _Float16 *__restrict__ img)
+                                                                const float *__restrict__ en_all,
+                                                                char *__restrict__ img)
 {
+    // tile t = [fp16 image: D/16 x 1 KiB][tail 256 B: en[32] (raw norms; +inf for codes >= K), pad[32]]
     const float sb = meta->scale_b;
     const int S16 = D / 16;
-    const size_t per_tile = (size_t)S16 * 512;
+    const size_t img_halves = (size_t)S16 * 512;
+    const size_t per_tile = img_halves + 128;              // in 2-byte units
     const size_t total = (size_t)dvq_num_tiles(K) * per_tile;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         int t = (int)(i / per_tile);
         int r = (int)(i - (size_t)t * per_tile);
-        int s = r >> 9, lane = (r >> 3) & 63, j = r & 7;
-        int code = t * 32 + (lane & 31);
-        int k = 16 * s + 8 * (lane >> 5) + j;
-        float v = (code < K) ? E[(size_t)code * D + k] * sb : 0.0f;
-        img[i] = (_Float16)v;       // round to nearest even
+        char *tile = img + (size_t)t * per_tile * 2;
+        if (r < (int)img_halves) {
+            int s = r >> 9, lane = (r >> 3) & 63, j = r & 7;
+            int code = t * 32 + (lane & 31);
+            int k = 16 * s + 8 * (lane >> 5) + j;
+            float v = (code < K) ? E[(size_t)code * D + k] * sb : 0.0f;
+            ((_Float16 *)tile)[r] = (_Float16)v;           // round to nearest even
+        } else if (((r - (int)img_halves) & 1) == 0) {
+            int q = (r - (int)img_halves) >> 1;            // float index in the tail, 0..63
+            int code = t * 32 + q;
+            float v = (q < 32) ? ((code < K) ? en_all[code] : __builtin_inff()) : 0.0f;
+            ((float *)(tile + img_halves * 2))[q] = v;
+        }
     }
 }
 
@@ -161,82 +172,118 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
 
 // ---------------------------------------------------------------------------------------------
 // pass 1
-//   workgroup = 4 waves x 32 tokens (consecutive hw positions); two workgroups per CU.
-//   A wave keeps its 32 tokens twice in registers: fp32 (D/2 VGPRs, read once from NCHW, reused
-//   for z_q so z is never re-read) and scaled fp16 MFMA B fragments (D/4 VGPRs).
-//   The fp16 codebook streams through LDS in stages of 2 tiles (64 codes), double-buffered by
-//   global->LDS DMA, one barrier per stage; the accumulator of every tile is seeded from LDS with
-//   -2^(a+b-1) en_j so the MFMA output is the score itself.
+//   workgroup = 4 waves x 32 tokens (consecutive hw positions); FOUR workgroups per CU (<= 128
+//   VGPRs): latency of LDS reads, DMA and HBM is hidden by the other three waves of each SIMD.
+//   A wave converts its 32 tokens once to fp16 MFMA B fragments (D/4 VGPRs, no scaling of z: fp16
+//   holds |z| up to 65504, smaller magnitudes are covered by the computed residual norm) while it
+//   accumulates the exact xn; the fp32 values are NOT kept: the epilogue re-reads the wave's z
+//   tile (last-level-cache resident) for z_q.
+//   The fp16 codebook streams through LDS tile by tile (global->LDS DMA, double buffer); the
+//   accumulator of every tile is seeded from LDS with -2^(b-1) en_j so the MFMA output is the score.
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
+__global__ __launch_bounds__(512, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
-    const float *__restrict__ en_all, const float *__restrict__ E, const float *__restrict__ mask,
+    const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
     char *__restrict__ records, int rec_cap)
 {
+    constexpr int NW = 8;                                    // waves per workgroup (256 tokens)
     constexpr int S16 = D / 16;
-    constexpr int TILE_BYTES = S16 * 1024;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-    constexpr int CHUNKS_PER_WAVE = S16 / 4;                 // 1-KiB DMA pieces per wave per tile
+    constexpr int IMG_BYTES = S16 * 1024;                    // fp16 image of one 32-code tile
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;             // + raw-norm tail, in the prep buffer
+    constexpr int CHUNKS = S16;                              // 1-KiB DMA pieces per tile
+    constexpr int CPW = (CHUNKS + NW - 1) / NW;              // pieces per wave (some waves idle if < NW)
+    constexpr int PER_TILE = CPW + 1;                        // DMA ops one wave issues per tile
+    constexpr int NBUF = 4;                                  // tile ring: compute / landed / 2 in flight
+    constexpr int SB = (S16 < 4) ? S16 : 4;                  // k-steps per load batch (8*SB values/lane)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [2][STAGE_BYTES] fp16 tiles | [2 buf][4 wave][2 tile][32] accumulator seeds
-    float *seedbuf = (float *)(lds + 2 * STAGE_BYTES);
+    // [NBUF][IMG_BYTES] fp16 tiles | [NBUF][NW][64] raw norms (per-wave copy) | [2][NW][32] seeds
+    float *enraw = (float *)(lds + NBUF * IMG_BYTES);
+    float *seedbuf = enraw + NBUF * NW * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int T = dvq_num_tiles(K);
-    const int NS = (T + 1) / 2;
-    const int meta_ok = meta->ok;
     const float sB = meta->scale_b;
 
-    auto stage = [&](int st, int bufi) {
+    auto issue = [&](int t) {                                // PER_TILE DMA ops in every wave
+        const char *src = img + (size_t)t * TILE_STRIDE;
+        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = 2 * st + i;
-            if (t < T) {
-                const char *src = img + (size_t)t * TILE_BYTES;
-                char *dst = lds + bufi * STAGE_BYTES + i * TILE_BYTES;
-#pragma unroll
-                for (int q = 0; q < CHUNKS_PER_WAVE; ++q) {
-                    int chunk = wave * CHUNKS_PER_WAVE + q;
-                    glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
-                }
-            }
+        for (int q = 0; q < CPW; ++q) {
+            int chunk = wave * CPW + q;
+            if (chunk >= CHUNKS) chunk = CHUNKS - 1;         // D < 128: surplus waves repeat a piece
+            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
         }
+        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
     };
-    stage(0, 0);
+    issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
 
-    const long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
-    const bool valid = n < N;
-    const long nn = valid ? n : N - 1;
-    const long bimg = nn / HW;
-    const int hw = (int)(nn - bimg * HW);
-    const size_t zbase = ((size_t)bimg * D + 8 * h) * HW + hw;   // channel 16s + 8h + j at + (16s+j)*HW
-    const float *zp = z + zbase;
-    float zf[S16][8];
-#pragma unroll
-    for (int s = 0; s < S16; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) zf[s][j] = zp[(size_t)(16 * s + j) * HW];
+    // token of this lane; -1 = past the end (loads are clamped to the last token)
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int n_raw = (tile_id * NW + wave) * 32 + c;
+    const int n = (n_raw < N) ? n_raw : -1;
+    auto token_base = [&]() -> size_t {
+        const long nn = (n >= 0) ? n : N - 1;
+        const long bimg = nn / HW;
+        const int hw = (int)(nn - bimg * HW);
+        return ((size_t)bimg * D + 8 * h) * HW + hw;           // channel 16s + 8h + j at + (16s+j)*HW
+    };
 
-    // exact ATen-order xn: a[m], m = i mod 32 = 16(s&1) + 8h + j for channel i = 16s + 8h + j
-    float xn, amax = 0.0f;
+    // ---- prologue: one pass over the token's channels, SB k-steps at a time:
+    //      exact ATen-order xn partials a[m] (m = i mod 32 = 16(s&1) + 8h + j), |z| max,
+    //      fp16 fragments and the squared norm of their rounding residual
+    f16x8 zh[S16];
+    float xn, thr2W;
     {
+        const float *zp = z + token_base();
         float pa[2][8];
+        float amax = 0.0f, zeta2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                float a = sq_rn(zf[p][j]);
-#pragma unroll
-                for (int s = p + 2; s < S16; s += 2) a = __fadd_rn(a, sq_rn(zf[s][j]));
-                pa[p][j] = a;
+        for (int s0 = 0; s0 < S16; s0 += SB) {
+            if (s0 > 0) {
+                // the next batch's addresses are made to depend on this batch's results, otherwise
+                // the scheduler issues every load first and spills the raw values
+                unsigned dep;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(dep)
+                             : "v"(zeta2), "v"(amax), "v"(pa[0][0]), "v"(pa[0][1]), "v"(pa[0][2]), "v"(pa[0][3]),
+                               "v"(pa[0][4]), "v"(pa[0][5]), "v"(pa[0][6]), "v"(pa[0][7]), "v"(pa[1][0]),
+                               "v"(pa[1][1]), "v"(pa[1][2]), "v"(pa[1][3]), "v"(pa[1][4]), "v"(pa[1][5]),
+                               "v"(pa[1][6]), "v"(pa[1][7]));
+                zp += dep;
             }
+            float zf[SB][8];
 #pragma unroll
-            for (int s = 0; s < S16; ++s) amax = vmax_raw(amax, fabsf(zf[s][j]));
+            for (int q = 0; q < SB; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zf[q][j] = zp[(size_t)(16 * (s0 + q) + j) * HW];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int s = s0 + q;
+                u32x4 packed;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {             // two channels -> one v_cvt_pk_f16_f32 (RNE)
+                    const float v0 = zf[q][2 * j2], v1 = zf[q][2 * j2 + 1];
+                    const float q0 = sq_rn(v0), q1 = sq_rn(v1);
+                    pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
+                    pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
+                    amax = vmax_raw(amax, fabsf(v0));
+                    amax = vmax_raw(amax, fabsf(v1));
+                    f32x2 vv = {v0, v1};
+                    f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    packed[j2] = __builtin_bit_cast(unsigned, hh);
+                    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
+                    zeta2 = __builtin_fmaf(r0, r0, zeta2);
+                    zeta2 = __builtin_fmaf(r1, r1, zeta2);
+                }
+                zh[s] = __builtin_bit_cast(f16x8, packed);
+            }
+            asm volatile("" ::: "memory");                   // keep the batches apart (register budget)
         }
         float t8[8];
 #pragma unroll
@@ -251,109 +298,67 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         xn = t8[0];
 #pragma unroll
         for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
-    }
-    const bool bad = !(xn < __builtin_inff()) || !meta_ok;      // NaN / Inf / overflowing squares
-    // wave-uniform scale from the largest finite magnitude of the wave's 32 tokens
-    float sA;
-    {
-        float am = bad ? 0.0f : amax;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-        int a_exp = 0;
-        if (am > 0.0f) {
-            int e;
-            (void)frexpf(am, &e);
-            a_exp = 15 - e;                                      // 2^a max|z| in [2^14, 2^15)
-        }
-        a_exp = a_exp > 100 ? 100 : (a_exp < -100 ? -100 : a_exp);
-        sA = ldexpf(1.0f, a_exp);
-    }
-    f16x8 zh[S16];
-    float zeta2 = 0.0f;                      // this lane's share of ||2^a z - zh||^2
-#pragma unroll
-    for (int s = 0; s < S16; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = zf[s][j] * sA;
-            _Float16 hv = (_Float16)v;
-            zh[s][j] = hv;
-            float r = v - (float)hv;         // exact
-            zeta2 = __builtin_fmaf(r, r, zeta2);
-        }
-    float thr2W;
-    {
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
         zeta2 += __shfl_xor(zeta2, 32);
+        // NaN / Inf / squares overflowing fp32 / beyond fp16 range -> not decidable here
+        bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok;
         const float zeta = sqrtf(zeta2) * 1.001f;
         const float Rh = sqrtf(xn) * 1.00001f;
-        const float sAB = sA * sB;
         const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
-        const float zn = sA * Rh + zeta;                 // >= ||zh||
+        const float zn = Rh + zeta;                      // >= ||zh||
         const float ehn = sB * emax + etamax;            // >= ||eh_j||
         float Wv = zeta * ehn + zn * etamax
-                   + GAMMA_P * (zn * ehn + 0.5f * sAB * enmax)
-                   + PACK_E * sAB * (Rh * emax + 0.5f * enmax)
-                   + sAB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
+                   + GAMMA_P * (zn * ehn + 0.5f * sB * enmax)
+                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
+                   + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
         thr2W = 2.0f * Wv * 1.001f;
+        // seeds must stay far from the padding value and from overflow: 2^(b-1) max en < 1e37
+        bad = bad || !((0.5f * sB * enmax) < 1.0e37f);
+        if (bad) thr2W = __builtin_nanf("");             // NaN threshold = "not decidable here"
     }
 
-    // accumulator seeds -2^(a+b-1) en_j: lane (i = lane>>5, c) owns row c of tile i of the stage;
-    // the raw norm is fetched one stage ahead and scaled only when it is written to LDS.
-    // Padded codes (>= K) get a huge negative FINITE seed: they never win, and packing the register
-    // index into the low mantissa bits cannot turn them into NaNs (it would for -inf).
-    const float seed_scale = -0.5f * sA * sB;
+    // accumulator seeds -2^(b-1) en_j, wave-private in LDS, prepared from the raw norms that travel
+    // with the tile.  Padded codes (>= K, raw norm +inf) get a huge negative FINITE seed: they never
+    // win, and packing the register index into the low mantissa bits cannot turn them into NaNs.
+    const float seed_scale = -0.5f * sB;
     constexpr float SEED_PAD = -3.0e38f;
-    auto seed_raw = [&](int st) -> float {
-        int code = (2 * st + h) * 32 + c;
-        return (code < K) ? en_all[code] : __builtin_inff();
-    };
-    float *my_seed = seedbuf + wave * 64 + lane;                  // + buf * 256
-    my_seed[0] = fmaxf(seed_raw(0) * seed_scale, SEED_PAD);
-    float raw_next = (NS > 1) ? seed_raw(1) : 0.0f;
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
     int t1 = 0;
 
-    for (int st = 0; st < NS; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                    // stage st and its seeds landed; stage st-1 fully consumed
-        const int bufi = st & 1;
-        if (st + 1 < NS) {
-            my_seed[((st + 1) & 1) * 256] = fmaxf(raw_next * seed_scale, SEED_PAD);
-            stage(st + 1, (st + 1) & 1);
-            if (st + 2 < NS) raw_next = seed_raw(st + 2);
+    for (int t = 0; t < T; ++t) {
+        // this wave's DMA of tiles <= t+1 has landed (only tile t+2 may still be in flight) ...
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... and everybody else's; tile t-1 consumed
+        asm volatile("" ::: "memory");
+        if (t + 3 < T) issue(t + 3);                         // into the ring slot of tile t-1
+        if (lane < 32) {                                     // this wave's seeds for tile t
+            float raw = enraw[((t & (NBUF - 1)) * NW + wave) * 64 + c];
+            seedbuf[((t & 1) * NW + wave) * 32 + c] = fmaxf(raw * seed_scale, SEED_PAD);
+        }
+        const char *tile = lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16;
+        const float *seeds = seedbuf + ((t & 1) * NW + wave) * 32 + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = 2 * st + i;
-            if (t < T) {
-                const char *tile = lds + bufi * STAGE_BYTES + i * TILE_BYTES + lane * 16;
-                const float *seeds = seedbuf + bufi * 256 + wave * 64 + i * 32 + 4 * h;
-                f32x16 acc;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
-                }
-                f16x8 a0 = *(const f16x8 *)(tile);
-                f16x8 a1 = *(const f16x8 *)(tile + 1024);
-#pragma unroll
-                for (int s = 0; s < S16; s += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, zh[s], acc, 0, 0, 0);
-                    if (s + 2 < S16) a0 = *(const f16x8 *)(tile + (s + 2) * 1024);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, zh[s + 1], acc, 0, 0, 0);
-                    if (s + 3 < S16) a1 = *(const f16x8 *)(tile + (s + 3) * 1024);
-                }
-                const float om = m1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-                    m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
-                    m1 = vmax_raw(m1, g);
-                }
-                t1 = (m1 != om) ? t : t1;
-            }
+        for (int s = 0; s < S16; ++s) {
+            f16x8 a = *(const f16x8 *)(tile + s * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
         }
+        const float om = m1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
+            m1 = vmax_raw(m1, g);
+        }
+        t1 = (m1 != om) ? t : t1;
     }
 
     // ---- merge the two lane halves; provisional winner; final / queued / exact-list
@@ -373,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         thr = best - thr2W;
         final_ok = (best - second) > thr2W;
     }
-    // seeds must stay far from the padding value and from overflow: 2^(a+b-1) max en < 1e37
-    const bool seeds_ok = (0.5f * sA * sB * meta->enmax) < 1.0e37f;
-    bool hopeless = bad || !seeds_ok || !(code < K) || !(thr == thr);   // -> exact list
+    const bool valid = n >= 0;
+    const size_t zbase = token_base();
+    bool hopeless = !(code < K) || !(thr == thr);                 // NaN threshold -> exact list
     int slot = -1;
     if (valid && !hopeless && !final_ok) {                        // queue for the resolver
         if (h == 0) slot = atomicAdd(&counters[0], 1);
@@ -384,56 +389,63 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     }
     if (valid && hopeless && h == 0) {
         int pos = atomicAdd(&counters[1], 1);
-        exact_list[pos] = (int)n;
+        exact_list[pos] = n;
     }
-    if (slot >= 0) {
-        char *rec = records + (size_t)slot * rec_bytes(D);
+    char *rec = (slot >= 0) ? records + (size_t)slot * rec_bytes(D) : nullptr;
+    if (rec != nullptr) {
 #pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
-            f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
-            f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
-            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
-            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
-        }
+        for (int s = 0; s < S16; ++s) *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
         if (h == 0) {
             RecMeta rm;
-            rm.n = (int)n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
+            rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
             rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
             *(RecMeta *)(rec + (size_t)D * 6) = rm;
         }
     }
-    // ---- provisional (usually final) outputs: code, z_q = z + (e - z), loss term
+    // ---- provisional (usually final) outputs: code, z_q = z + (e - z), loss term; z is re-read
     float lsum = 0.0f;
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
-        if (zq != nullptr || partials != nullptr) {
+        if (zq != nullptr || partials != nullptr || rec != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
+            const float *zp = z + zbase;
             float *zqp = zq ? zq + zbase : nullptr;
             const float m = (mask != nullptr) ? mask[n] : 1.0f;
 #pragma unroll
-            for (int s0 = 0; s0 < S16; s0 += 4) {        // gathers issued 4 k-steps (8 x 16 B) at a time
-                f32x4 eg[4][2];
+            for (int s0 = 0; s0 < S16; s0 += SB) {
+                if (s0 > 0) {                                // same trick: one batch at a time
+                    unsigned dep;
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(dep) : "v"(lsum));
+                    zp += dep;
+                    ep += dep;
+                }
+                float zf[SB][8];
+                f32x4 eg[SB][2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (s0 + q < S16) {
-                        eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
-                        eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
-                    }
+                for (int q = 0; q < SB; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) zf[q][j] = zp[(size_t)(16 * (s0 + q) + j) * HW];
+                    eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
+                    eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < SB; ++q) {
                     const int s = s0 + q;
-                    if (s < S16) {
+                    if (rec != nullptr) {
+                        f32x4 lo = {zf[q][0], zf[q][1], zf[q][2], zf[q][3]};
+                        f32x4 hi = {zf[q][4], zf[q][5], zf[q][6], zf[q][7]};
+                        *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
+                        *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
+                    }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float e = eg[q][j >> 2][j & 3];
-                            float diff = __fsub_rn(e, zf[s][j]);
-                            if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[s][j], diff);
-                            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        float e = eg[q][j >> 2][j & 3];
+                        float diff = __fsub_rn(e, zf[q][j]);
+                        if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[q][j], diff);
+                        lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
                     }
                 }
+                asm volatile("" ::: "memory");
             }
         }
     }
@@ -445,7 +457,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         double *red = (double *)lds;
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
-        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red[w];
+            partials[blockIdx.x] = tot;
+        }
     }
 }
 
@@ -468,12 +485,15 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     int *__restrict__ counters, int *__restrict__ exact_list, const char *__restrict__ records, int rec_cap)
 {
     constexpr int S16 = D / 16;
-    constexpr int TILE_BYTES = S16 * 1024;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int IMG_BYTES = S16 * 1024;
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;
     constexpr int CHUNKS_PER_WAVE = S16 / 4;
+    constexpr int PER_TILE = CHUNKS_PER_WAVE + 1;
+    constexpr int NBUF = 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [2][STAGE_BYTES] tiles | cand[RES_CAND] | best[RES_SLOTS] u64 | misc ints
-    unsigned *cand = (unsigned *)(lds + 2 * STAGE_BYTES);
+    // [NBUF][IMG_BYTES] tiles | [NBUF][4][64] raw norms | cand[RES_CAND] | best[RES_SLOTS] u64 | misc
+    float *enraw = (float *)(lds + NBUF * IMG_BYTES);
+    unsigned *cand = (unsigned *)(enraw + NBUF * 4 * 64);
     unsigned long long *best = (unsigned long long *)(cand + RES_CAND);
     int *misc = (int *)(best + RES_SLOTS);            // [0] candidate count, [1] rewrite count
     int *rewrite = misc + 4;                          // [RES_SLOTS] slots whose winner changed
@@ -489,24 +509,20 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         return;
     }
     const int T = dvq_num_tiles(K);
-    const int NS = (T + 1) / 2;
 
-    auto stage = [&](int st, int bufi) {
+    auto issue = [&](int t) {
+        const char *src = img + (size_t)t * TILE_STRIDE;
+        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = 2 * st + i;
-            if (t < T) {
-                const char *src = img + (size_t)t * TILE_BYTES;
-                char *dst = lds + bufi * STAGE_BYTES + i * TILE_BYTES;
-#pragma unroll
-                for (int q = 0; q < CHUNKS_PER_WAVE; ++q) {
-                    int chunk = wave * CHUNKS_PER_WAVE + q;
-                    glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
-                }
-            }
+        for (int q = 0; q < CHUNKS_PER_WAVE; ++q) {
+            int chunk = wave * CHUNKS_PER_WAVE + q;
+            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
         }
+        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * 4 + wave) * 64);
     };
-    stage(0, 0);
+    issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
 
@@ -521,40 +537,37 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const float nss = rm.seed_scale;                  // -2^(a+b-1) of the token's pass-1 wave
 
     // ---- enumerate: every code whose approximate score reaches best - 2W
-    for (int st = 0; st < NS; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < T; ++t) {
+        if (t + 2 < T && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int bufi = st & 1;
-        if (st + 1 < NS) stage(st + 1, (st + 1) & 1);
+        if (t + 3 < T) issue(t + 3);
+        const char *tile = lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16;
+        const float *enr = enraw + ((t & (NBUF - 1)) * 4 + wave) * 64 + 4 * h;
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = 2 * st + i;
-            if (t < T) {
-                const char *tile = lds + bufi * STAGE_BYTES + i * TILE_BYTES + lane * 16;
-                f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int s = 0; s < S16; ++s) {
+            f16x8 a = *(const f16x8 *)(tile + s * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
+        }
+        unsigned hits = 0;
 #pragma unroll
-                for (int s = 0; s < S16; ++s) {
-                    f16x8 a = *(const f16x8 *)(tile + s * 1024);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
-                }
-                unsigned hits = 0;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 en4 = *(const f32x4 *)(enr + 8 * g4);          // rows 8g + 4h + q; +inf for padding
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float en = (code < K) ? en_all[code] : __builtin_inff();
-                    float g = __builtin_fmaf(en, nss, acc[r]);
-                    hits |= (g >= thr) ? (1u << r) : 0u;
-                }
-                while (hits) {
-                    int r = __builtin_ctz(hits);
-                    hits &= hits - 1;
-                    int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    int pos = atomicAdd(&misc[0], 1);
-                    if (pos < RES_CAND) cand[pos] = ((unsigned)slot_l << 20) | (unsigned)code;
-                }
+            for (int q = 0; q < 4; ++q) {
+                float g = __builtin_fmaf(en4[q], nss, acc[4 * g4 + q]);
+                hits |= (g >= thr) ? (1u << (4 * g4 + q)) : 0u;
             }
+        }
+        while (hits) {
+            int r = __builtin_ctz(hits);
+            hits &= hits - 1;
+            int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int pos = atomicAdd(&misc[0], 1);
+            if (pos < RES_CAND) cand[pos] = ((unsigned)slot_l << 20) | (unsigned)code;
         }
     }
     __syncthreads();
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const f32x4 *ev = (const f32x4 *)(E + (size_t)code * D);
         const float xn = ((const RecMeta *)(r2 + (size_t)D * 6))->xn;
         float acc = 0.0f;
-#pragma unroll 4
+#pragma unroll 16
         for (int q = 0; q < D / 4; ++q) {
             f32x4 a = zv[q], b = ev[q];
             acc = __builtin_fmaf(a[0], b[0], acc);
@@ -678,19 +691,19 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
     DvqF16Meta *meta = (DvqF16Meta *)base;
-    _Float16 *img = (_Float16 *)(base + 256);
+    char *img = base + 256;
     const float *en_all = (const float *)((char *)prep + dvq_prep_en_offset(K, D));
     hipLaunchKernelGGL(codebook_meta_kernel, dim3(1), dim3(1024), 0, st, E, K, D, en_all, meta);
-    size_t total = (size_t)dvq_num_tiles(K) * (D / 16) * 512;
+    size_t total = (size_t)dvq_num_tiles(K) * ((size_t)(D / 16) * 512 + 128);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(codebook_prep_f16_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, img);
+    hipLaunchKernelGGL(codebook_prep_f16_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all, img);
     hipLaunchKernelGGL(codebook_eta_kernel, dim3((K + 255) / 256), dim3(256), 0, st, E, K, D, meta);
     return (int)hipGetLastError();
 }
 
-// partials layout: [pass 1: ceil(N/128)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
-int dvq_filter_nparts(long N) { return 2 * (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
+// partials layout: [pass 1: ceil(N/256)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
+int dvq_filter_nparts(long N) { return (int)((N + 255) / 256) + (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
 
 template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
@@ -699,8 +712,8 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
                          char *records, int cap, hipStream_t st)
 {
     static bool attr_set = false;
-    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 2 * 256 * sizeof(float);
-    const size_t shmem2 = 4 * (size_t)(D / 16) * 1024 + RES_CAND * 4 + RES_SLOTS * 8 + 16 + RES_SLOTS * 4;
+    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 8 * 64 * sizeof(float) + 2 * 8 * 32 * sizeof(float);
+    const size_t shmem2 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + RES_CAND * 4 + RES_SLOTS * 8 + 16 + RES_SLOTS * 4;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem1);
@@ -708,9 +721,9 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2);
         attr_set = true;
     }
-    const int nb1 = (int)((N + 127) / 128);
-    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                       en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
+    const int nb1 = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(512), shmem1, st, z, img, meta,
+                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), shmem2, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
                        exact_list, records, cap);
@@ -740,7 +753,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     default:  return -1000;
     }
     if (rc) return rc;
-    double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
+    double *partials3 = partials ? partials + (N + 255) / 256 + cap / RES_SLOTS : nullptr;
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
                                  exact_list, counters + 1, st);
 }
