@@ -51,7 +51,7 @@ static bool dim_ok(int D) { return D == 64 || D == 128 || D == 256; }
 // loss partials: pass 1 / exact blocks (<= 2 ceil(N/128)), resolver blocks (<= max(32, ceil(N/128)))
 static size_t partials_bytes_for(long N)
 {
-    size_t count = 3 * (size_t)((N + 127) / 128) + 32;
+    size_t count = 6 * (size_t)((N + 127) / 128) + 160;    // resolver: one per 32 queued-token slots
     return (count * sizeof(double) + 255) / 256 * 256;
 }
 

@@ -28,6 +28,8 @@
 //   reference side, d = fl(fl(xn+en) - 2 dotc), dotc the D-term fp32 chain:
 //                                 <= 2^(a+b) [u(1+u)(xn+en) + (u + gamma_D)(1+gamma_D) ||z|| ||e_j||]
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
+#include <stdlib.h>
+
 #include "dvq_common.h"
 
 struct DvqF16Meta {
@@ -44,8 +46,8 @@ static constexpr float GAMMA_P = 1.2207031e-4f;   // 2^-13
 static constexpr float PACK_E = 1.93e-6f;         // 2^-19 (1 + margin)
 static constexpr float REF_XN = 1.2e-7f;          // 2u
 static constexpr float REF_RE = 1.6e-5f;          // u + gamma_256 (D <= 256)
-static constexpr int RES_SLOTS = 128;             // resolver: queued tokens per workgroup
-static constexpr int RES_CAND = 1024;             // resolver: candidate pairs per workgroup
+static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per workgroup
+static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup
 
 // record of one queued token (written by pass 1, read by the resolver)
 //   [zh: D*2 B in fragment order s,h,8][zf: D*4 B in channel order][meta 32 B]
@@ -181,22 +183,22 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
 //   The fp16 codebook streams through LDS tile by tile (global->LDS DMA, double buffer); the
 //   accumulator of every tile is seeded from LDS with -2^(b-1) en_j so the MFMA output is the score.
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(512, 2) void vq_assign_filter_kernel(
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap)
+    char *__restrict__ records, int rec_cap, int stagger_sleeps)
 {
-    constexpr int NW = 8;                                    // waves per workgroup (256 tokens)
+    // NW waves per workgroup (32 tokens each); 16/NW workgroups per CU
     constexpr int S16 = D / 16;
     constexpr int IMG_BYTES = S16 * 1024;                    // fp16 image of one 32-code tile
     constexpr int TILE_STRIDE = IMG_BYTES + 256;             // + raw-norm tail, in the prep buffer
     constexpr int CHUNKS = S16;                              // 1-KiB DMA pieces per tile
     constexpr int CPW = (CHUNKS + NW - 1) / NW;              // pieces per wave (some waves idle if < NW)
     constexpr int PER_TILE = CPW + 1;                        // DMA ops one wave issues per tile
-    constexpr int NBUF = 4;                                  // tile ring: compute / landed / 2 in flight
+    constexpr int NBUF = (NW == 8) ? 4 : 2;                  // tile ring (LDS budget: 160 KiB / CU)
     constexpr int SB = (S16 < 4) ? S16 : 4;                  // k-steps per load batch (8*SB values/lane)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // [NBUF][IMG_BYTES] fp16 tiles | [NBUF][NW][64] raw norms (per-wave copy) | [2][NW][32] seeds
@@ -220,9 +222,20 @@ __global__ __launch_bounds__(512, 2) void vq_assign_filter_kernel(
         }
         glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
     };
+    // phase stagger (speed only): the workgroups that share a CU start at different times so that
+    // the HBM-bound prologue/epilogue of one overlaps the matrix-core-bound code loop of another
+    if (stagger_sleeps > 0) {
+        const int slots = 256 * (16 / NW);
+        if ((int)blockIdx.x < slots) {
+            const int k = ((int)blockIdx.x >> 8) * stagger_sleeps;
+            for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     issue(0);
-    if (T > 1) issue(1);
-    if (T > 2) issue(2);
+    if (NBUF > 2) {
+        if (T > 1) issue(1);
+        if (T > 2) issue(2);
+    }
 
     // token of this lane; -1 = past the end (loads are clamped to the last token)
     const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -327,12 +340,19 @@ __global__ __launch_bounds__(512, 2) void vq_assign_filter_kernel(
     int t1 = 0;
 
     for (int t = 0; t < T; ++t) {
-        // this wave's DMA of tiles <= t+1 has landed (only tile t+2 may still be in flight) ...
-        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                        // ... and everybody else's; tile t-1 consumed
-        asm volatile("" ::: "memory");
-        if (t + 3 < T) issue(t + 3);                         // into the ring slot of tile t-1
+        if (NBUF > 2) {
+            // this wave's DMA of tiles <= t+1 has landed (only tile t+2 may still be in flight) ...
+            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // ... and everybody else's; tile t-1 consumed
+            asm volatile("" ::: "memory");
+            if (t + 3 < T) issue(t + 3);                     // into the ring slot of tile t-1
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 1 < T) issue(t + 1);
+        }
         if (lane < 32) {                                     // this wave's seeds for tile t
             float raw = enraw[((t & (NBUF - 1)) * NW + wave) * 64 + c];
             seedbuf[((t & 1) * NW + wave) * 32 + c] = fmaxf(raw * seed_scale, SEED_PAD);
@@ -461,13 +481,17 @@ __global__ __launch_bounds__(512, 2) void vq_assign_filter_kernel(
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[w];
-            partials[blockIdx.x] = tot;
+            partials[blockIdx.x * (NW / 4)] = tot;          // one slot per 128 tokens is reserved
+            if (NW == 8) partials[2 * blockIdx.x + 1] = 0.0;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// resolver: queued tokens, RES_SLOTS per workgroup (wave w owns slots 32w .. 32w+31)
+// resolver: queued tokens, RES_SLOTS (= 32, one MFMA column set) per workgroup.  The queue is short
+// (a few % of the tokens), so the work is spread for LATENCY: the four waves of a workgroup share
+// the same 32 tokens and each takes every fourth code tile, reading its A fragments straight from
+// the L2-resident prep image (no LDS ring, no barrier in the loop).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long order_key(float d, int code)
 {
@@ -487,16 +511,11 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     constexpr int S16 = D / 16;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
-    constexpr int CHUNKS_PER_WAVE = S16 / 4;
-    constexpr int PER_TILE = CHUNKS_PER_WAVE + 1;
-    constexpr int NBUF = 4;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [NBUF][IMG_BYTES] tiles | [NBUF][4][64] raw norms | cand[RES_CAND] | best[RES_SLOTS] u64 | misc
-    float *enraw = (float *)(lds + NBUF * IMG_BYTES);
-    unsigned *cand = (unsigned *)(enraw + NBUF * 4 * 64);
-    unsigned long long *best = (unsigned long long *)(cand + RES_CAND);
-    int *misc = (int *)(best + RES_SLOTS);            // [0] candidate count, [1] rewrite count
-    int *rewrite = misc + 4;                          // [RES_SLOTS] slots whose winner changed
+    __shared__ unsigned cand[RES_CAND];
+    __shared__ unsigned long long best[RES_SLOTS];
+    __shared__ int misc[4];                           // [0] candidate count, [1] rewrite count
+    __shared__ int rewrite[RES_SLOTS];
+    __shared__ double red[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,65 +528,48 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         return;
     }
     const int T = dvq_num_tiles(K);
-
-    auto issue = [&](int t) {
-        const char *src = img + (size_t)t * TILE_STRIDE;
-        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
-#pragma unroll
-        for (int q = 0; q < CHUNKS_PER_WAVE; ++q) {
-            int chunk = wave * CHUNKS_PER_WAVE + q;
-            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
-        }
-        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * 4 + wave) * 64);
-    };
-    issue(0);
-    if (T > 1) issue(1);
-    if (T > 2) issue(2);
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
 
-    const int slot_l = wave * 32 + c;                 // local slot of this lane's token column
-    const bool live = base + slot_l < total;
-    const char *rec = records + (size_t)(live ? base + slot_l : base) * rec_bytes(D);
+    const bool live = base + c < total;
+    const char *rec = records + (size_t)(live ? base + c : base) * rec_bytes(D);
     f16x8 zh[S16];
 #pragma unroll
     for (int s = 0; s < S16; ++s) zh[s] = *(const f16x8 *)(rec + (s * 2 + h) * 16);
     const RecMeta rm = *(const RecMeta *)(rec + (size_t)D * 6);
     const float thr = live ? rm.thr : __builtin_inff();
-    const float nss = rm.seed_scale;                  // -2^(a+b-1) of the token's pass-1 wave
+    const float nss = rm.seed_scale;                  // -2^(b-1)
+    __syncthreads();
 
     // ---- enumerate: every code whose approximate score reaches best - 2W
-    for (int t = 0; t < T; ++t) {
-        if (t + 2 < T && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 3 < T) issue(t + 3);
-        const char *tile = lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16;
-        const float *enr = enraw + ((t & (NBUF - 1)) * 4 + wave) * 64 + 4 * h;
+    for (int t = wave; t < T; t += 4) {
+        const char *tile = img + (size_t)t * TILE_STRIDE;
+        const float *enr = (const float *)(tile + IMG_BYTES) + 4 * h;
+        f16x8 a[S16];
+#pragma unroll
+        for (int s = 0; s < S16; ++s) a[s] = *(const f16x8 *)(tile + s * 1024 + lane * 16);
+        f32x4 en4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) en4[g4] = *(const f32x4 *)(enr + 8 * g4);   // rows 8g + 4h + q
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            f16x8 a = *(const f16x8 *)(tile + s * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < S16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], zh[s], acc, 0, 0, 0);
         unsigned hits = 0;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 en4 = *(const f32x4 *)(enr + 8 * g4);          // rows 8g + 4h + q; +inf for padding
+        for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float g = __builtin_fmaf(en4[q], nss, acc[4 * g4 + q]);
+                float g = __builtin_fmaf(en4[g4][q], nss, acc[4 * g4 + q]);       // +inf norm = padding
                 hits |= (g >= thr) ? (1u << (4 * g4 + q)) : 0u;
             }
-        }
         while (hits) {
             int r = __builtin_ctz(hits);
             hits &= hits - 1;
             int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             int pos = atomicAdd(&misc[0], 1);
-            if (pos < RES_CAND) cand[pos] = ((unsigned)slot_l << 20) | (unsigned)code;
+            if (pos < RES_CAND) cand[pos] = ((unsigned)c << 20) | (unsigned)code;
         }
     }
     __syncthreads();
@@ -647,8 +649,6 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     if (partials != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
-        __syncthreads();
-        double *red = (double *)lds;
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -703,7 +703,13 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
 }
 
 // partials layout: [pass 1: ceil(N/256)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
-int dvq_filter_nparts(long N) { return (int)((N + 255) / 256) + (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
+int dvq_filter_nparts(long N) { return 2 * (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
+
+static int tune_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
 template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
@@ -712,19 +718,30 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
                          char *records, int cap, hipStream_t st)
 {
     static bool attr_set = false;
-    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 8 * 64 * sizeof(float) + 2 * 8 * 32 * sizeof(float);
-    const size_t shmem2 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + RES_CAND * 4 + RES_SLOTS * 8 + 16 + RES_SLOTS * 4;
+    static int nw = 8, stagger = 0;
+    const size_t shmem8 = 4 * (size_t)(D / 16) * 1024 + 4 * 8 * 64 * sizeof(float) + 2 * 8 * 32 * sizeof(float);
+    const size_t shmem4 = 2 * (size_t)(D / 16) * 1024 + 2 * 4 * 64 * sizeof(float) + 2 * 4 * 32 * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem1);
-        (void)hipFuncSetAttribute((const void *)vq_resolve_kernel<D>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2);
+        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D, 8>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem8);
+        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D, 4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem4);
+        nw = tune_int("DVQ_TUNE_NW", 8);
+        stagger = tune_int("DVQ_TUNE_STAGGER", 0);
         attr_set = true;
     }
-    const int nb1 = (int)((N + 255) / 256);
-    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(512), shmem1, st, z, img, meta,
-                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
-    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), shmem2, st, img, meta,
+    int nb1;
+    if (nw == 4) {
+        nb1 = (int)((N + 127) / 128);
+        hipLaunchKernelGGL((vq_assign_filter_kernel<D, 4>), dim3(nb1), dim3(256), shmem4, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger);
+    } else {
+        nb1 = (int)((N + 255) / 256);
+        hipLaunchKernelGGL((vq_assign_filter_kernel<D, 8>), dim3(nb1), dim3(512), shmem8, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger);
+    }
+    nb1 = (int)((N + 127) / 128);                            // partials slots reserved for pass 1
+    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), 0, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
                        exact_list, records, cap);
     return (int)hipGetLastError();
@@ -753,7 +770,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     default:  return -1000;
     }
     if (rc) return rc;
-    double *partials3 = partials ? partials + (N + 255) / 256 + cap / RES_SLOTS : nullptr;
+    double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
                                  exact_list, counters + 1, st);
 }
