@@ -46,6 +46,7 @@ static constexpr float GAMMA_P = 1.2207031e-4f;   // 2^-13
 static constexpr float PACK_E = 1.93e-6f;         // 2^-19 (1 + margin)
 static constexpr float REF_XN = 1.2e-7f;          // 2u
 static constexpr float REF_RE = 1.6e-5f;          // u + gamma_256 (D <= 256)
+static constexpr float DVQ_SEED_PAD = -3.0e38f;
 static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per workgroup
 static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup
 
@@ -116,7 +117,10 @@ __global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__r
                                                                 const float *__restrict__ en_all,
                                                                 char *__restrict__ img)
 {
-    // tile t = [fp16 image: D/16 x 1 KiB][tail 256 B: en[32] (raw norms; +inf for codes >= K), pad[32]]
+    // tile t = [fp16 image: D/16 x 1 KiB][tail 256 B: seed[32] = -2^(b-1) en_j, the MFMA accumulator
+    // start value that turns the dot product into the score; codes >= K get a huge negative FINITE
+    // seed (they never win, and packing the register index into the low mantissa bits cannot turn
+    // them into NaNs as it would for -inf); pad[32]]
     const float sb = meta->scale_b;
     const int S16 = D / 16;
     const size_t img_halves = (size_t)S16 * 512;
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__r
         } else if (((r - (int)img_halves) & 1) == 0) {
             int q = (r - (int)img_halves) >> 1;            // float index in the tail, 0..63
             int code = t * 32 + q;
-            float v = (q < 32) ? ((code < K) ? en_all[code] : __builtin_inff()) : 0.0f;
+            float v = 0.0f;
+            if (q < 32) v = (code < K) ? fmaxf(-0.5f * sb * en_all[code], DVQ_SEED_PAD) : DVQ_SEED_PAD;
             ((float *)(tile + img_halves * 2))[q] = v;
         }
     }
@@ -201,9 +206,8 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
     constexpr int NBUF = (NW == 8) ? 4 : 2;                  // tile ring (LDS budget: 160 KiB / CU)
     constexpr int SB = (S16 < 4) ? S16 : 4;                  // k-steps per load batch (8*SB values/lane)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [NBUF][IMG_BYTES] fp16 tiles | [NBUF][NW][64] raw norms (per-wave copy) | [2][NW][32] seeds
+    // [NBUF][IMG_BYTES] fp16 tiles | [NBUF][NW][64] accumulator seeds (per-wave DMA copy)
     float *enraw = (float *)(lds + NBUF * IMG_BYTES);
-    float *seedbuf = enraw + NBUF * NW * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,11 +334,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
         if (bad) thr2W = __builtin_nanf("");             // NaN threshold = "not decidable here"
     }
 
-    // accumulator seeds -2^(b-1) en_j, wave-private in LDS, prepared from the raw norms that travel
-    // with the tile.  Padded codes (>= K, raw norm +inf) get a huge negative FINITE seed: they never
-    // win, and packing the register index into the low mantissa bits cannot turn them into NaNs.
     const float seed_scale = -0.5f * sB;
-    constexpr float SEED_PAD = -3.0e38f;
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
     int t1 = 0;
@@ -353,12 +353,8 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
             asm volatile("" ::: "memory");
             if (t + 1 < T) issue(t + 1);
         }
-        if (lane < 32) {                                     // this wave's seeds for tile t
-            float raw = enraw[((t & (NBUF - 1)) * NW + wave) * 64 + c];
-            seedbuf[((t & 1) * NW + wave) * 32 + c] = fmaxf(raw * seed_scale, SEED_PAD);
-        }
         const char *tile = lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16;
-        const float *seeds = seedbuf + ((t & 1) * NW + wave) * 32 + 4 * h;
+        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -488,6 +484,590 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// pass 1, register-resident form: 4-wave workgroups, TWO per CU (<= 256 VGPRs).  A wave keeps its
+// 32 tokens twice in registers -- fp32 (D/2 VGPRs, read once, reused for z_q and the resolver
+// record: z is never re-read, HBM traffic = the algorithmic bytes) and fp16 MFMA fragments (D/4).
+// Only two waves share a SIMD, so the code loop is written for per-wave matrix-core duty: seeds
+// read before the barrier, A fragments rotated through four register sets one k-step group ahead.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, int stagger_sleeps, unsigned long long *__restrict__ stamps)
+{
+    constexpr int NW = 4;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int S16 = D / 16;
+    constexpr int IMG_BYTES = S16 * 1024;
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;
+    constexpr int CPW = (S16 + NW - 1) / NW;
+    constexpr int PER_TILE = CPW + 1;
+    constexpr int NBUF = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int T = dvq_num_tiles(K);
+    const float sB = meta->scale_b;
+
+    if (stagger_sleeps > 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < 512) {
+        for (int i = 0; i < stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);   // see the NW-wave form
+    }
+    auto issue = [&](int t) {
+        const int tt = (t < T) ? t : T - 1;                  // past the end: harmless repeat (constant counts)
+        const char *src = img + (size_t)tt * TILE_STRIDE;
+        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            int chunk = wave * CPW + q;
+            if (chunk >= S16) chunk = S16 - 1;
+            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
+        }
+        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int n_raw = (tile_id * NW + wave) * 32 + c;
+    const int n = (n_raw < N) ? n_raw : -1;
+    auto token_base = [&]() -> size_t {
+        const long nn = (n >= 0) ? n : N - 1;
+        const long bimg = nn / HW;
+        const int hw = (int)(nn - bimg * HW);
+        return ((size_t)bimg * D + 8 * h) * HW + hw;
+    };
+    float zf[S16][8];
+    {
+        const float *zp = z + token_base();
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zf[s][j] = zp[(size_t)(16 * s + j) * HW];
+    }
+    f16x8 zh[S16];
+    float xn, thr2W;
+    {
+        float pa[2][8];
+        float amax = 0.0f, zeta2 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            u32x4 packed;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float v0 = zf[s][2 * j2], v1 = zf[s][2 * j2 + 1];
+                const float q0 = sq_rn(v0), q1 = sq_rn(v1);
+                pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
+                pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
+                amax = vmax_raw(amax, fabsf(v0));
+                amax = vmax_raw(amax, fabsf(v1));
+                f32x2 vv = {v0, v1};
+                f16x2 hh = __builtin_convertvector(vv, f16x2);
+                packed[j2] = __builtin_bit_cast(unsigned, hh);
+                const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
+                zeta2 = __builtin_fmaf(r0, r0, zeta2);
+                zeta2 = __builtin_fmaf(r1, r1, zeta2);
+            }
+            zh[s] = __builtin_bit_cast(f16x8, packed);
+        }
+        float t8[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
+            float a0 = h == 0 ? pa[0][l] : o0;
+            float a1 = h == 0 ? o0 : pa[0][l];
+            float a2 = h == 0 ? pa[1][l] : o1;
+            float a3 = h == 0 ? o1 : pa[1][l];
+            t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+        }
+        xn = t8[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        zeta2 += __shfl_xor(zeta2, 32);
+        const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
+        const bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok
+                         || !((0.5f * sB * enmax) < 1.0e37f);
+        const float zeta = sqrtf(zeta2) * 1.001f;
+        const float Rh = sqrtf(xn) * 1.00001f;
+        const float zn_ = Rh + zeta;
+        const float ehn = sB * emax + etamax;
+        float Wv = zeta * ehn + zn_ * etamax
+                   + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
+                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
+                   + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
+        thr2W = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+    }
+    const float seed_scale = -0.5f * sB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
+    if (stamps) st1 = __builtin_amdgcn_s_memrealtime();
+
+    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+    int t1 = 0;
+    unsigned long long segA = 0, segB = 0, segC = 0, segD = 0, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    for (int t = 0; t < T; ++t) {
+        if (stamps) tk0 = __builtin_amdgcn_s_memtime();
+        // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
+        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
+        }
+        if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
+        asm volatile("" ::: "memory");
+        if (stamps) tk1 = __builtin_amdgcn_s_memtime();
+        issue(t + 3);
+        // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
+        // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
+        const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                    lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+        f16x8 a0, a1, a2, a3;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // seeds / norms traffic of this step is done
+        if (stamps) tk2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+#define DVQ_MM(src, S, WAIT, NEXT)                                                      \
+        asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[S], acc, 0, 0, 0);         \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
+        NEXT
+        DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+        if (S16 == 16) {
+            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+            DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, )
+            DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, ) DVQ_MM(a3, 11, 3, )
+            DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, ) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
+        } else if (S16 == 8) {
+            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+            DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
+        } else {
+            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
+        }
+#undef DVQ_MM
+#undef DVQ_RD
+        if (stamps) tk3 = __builtin_amdgcn_s_memtime();
+        const float om = m1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
+            m1 = vmax_raw(m1, g);
+        }
+        t1 = (m1 != om) ? t : t1;
+        if (stamps) {
+            asm volatile("" :: "v"(m1), "v"(m2));
+            unsigned long long tk4 = __builtin_amdgcn_s_memtime();
+            segA += tk1 - tk0; segB += tk2 - tk1; segC += tk3 - tk2; segD += tk4 - tk3;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+    if (stamps) st2 = __builtin_amdgcn_s_memrealtime();
+
+    int code;
+    float thr;
+    bool final_ok;
+    {
+        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+        const int ot = __shfl_xor(t1, 32);
+        const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);
+        const float best = other_wins ? o1 : m1;
+        const float second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
+        const int wt = other_wins ? ot : t1;
+        const int wh = other_wins ? (h ^ 1) : h;
+        const int r = (int)(__float_as_uint(best) & 15u);
+        code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
+        thr = best - thr2W;
+        final_ok = (best - second) > thr2W;
+    }
+    const bool valid = n >= 0;
+    bool hopeless = !(code < K) || !(thr == thr);
+    int slot = -1;
+    if (valid && !hopeless && !final_ok) {
+        if (h == 0) slot = atomicAdd(&counters[0], 1);
+        slot = __shfl(slot, c);
+        if (slot >= rec_cap) { hopeless = true; slot = -1; }
+    }
+    if (valid && hopeless && h == 0) {
+        int pos = atomicAdd(&counters[1], 1);
+        exact_list[pos] = n;
+    }
+    if (slot >= 0) {
+        char *rec = records + (size_t)slot * rec_bytes(D);
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
+            f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
+            f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
+            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
+            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
+        }
+        if (h == 0) {
+            RecMeta rm;
+            rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
+            rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
+            *(RecMeta *)(rec + (size_t)D * 6) = rm;
+        }
+    }
+    float lsum = 0.0f;
+    if (valid && !hopeless) {
+        if (h == 0) codes[n] = (long long)code;
+        if (zq != nullptr || partials != nullptr) {
+            const float *ep = E + (size_t)code * D + 8 * h;
+            float *zqp = zq ? zq + token_base() : nullptr;
+            const float m = (mask != nullptr) ? mask[n] : 1.0f;
+            constexpr int SB = (S16 < 4) ? S16 : 4;
+#pragma unroll
+            for (int s0 = 0; s0 < S16; s0 += SB) {
+                f32x4 eg[SB][2];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
+                    eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const int s = s0 + q;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float e = eg[q][j >> 2][j & 3];
+                        float diff = __fsub_rn(e, zf[s][j]);
+                        if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[s][j], diff);
+                        lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                    }
+                }
+            }
+        }
+    }
+    if (partials != nullptr) {
+        double dsum = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        __syncthreads();
+        double *red = (double *)lds;
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    if (stamps) {                                            // diagnostic build only (DVQ_DEBUG_STAMPS)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long *o = stamps + 8 * blockIdx.x;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = segA; o[5] = segB; o[6] = segC; o[7] = segD;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 1, persistent form (D = 256, the production shape): one 4-wave workgroup per CU, ONE wave per
+// SIMD with the whole 512-register file, looping over 128-token tiles.
+//   * z is read from HBM exactly once: while a wave runs the code loop of its current 32 tokens it
+//     prefetches the next tile's fp32 z into a second register set (16 loads per code tile during
+//     the first 8 code tiles), so the HBM stream, the matrix cores and the z_q stores of the
+//     previous tile overlap inside every wave instead of relying on other waves;
+//   * the fp32 values stay in registers for z_q and for the resolver record (no re-read);
+//   * the fp16 codebook ring (4 x 16 KiB, global->LDS DMA, counted vmcnt, one barrier per code
+//     tile) runs continuously across token tiles.
+// Wait accounting (vmcnt counts DMA, loads and stores in issue order).  Per code-tile step t the
+// wave issues, in this order: [wait] [barrier] [DMA of tile g+3: PER_TILE ops] [prefetch loads:
+// 16 if t < 8].  Tile g+1 must have landed at step t; it was issued at step t-2, so everything
+// issued after it may stay in flight: PF(t-2) + PER_TILE + PF(t-1).  Step 0 drains everything
+// (the z_q stores of the previous tile were issued long before: the fp16 conversion sits between).
+// The DMA and prefetch ops are issued unconditionally (wrapped / clamped addresses at the end of
+// the sequence) so that the counts are compile-time constants.
+// ---------------------------------------------------------------------------------------------
+template <int PFI> struct PfTag { static constexpr int value = PFI; };
+
+__global__ __launch_bounds__(256, 1) void vq_assign_filter_persist_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int nparts_reserved, int *__restrict__ counters,
+    int *__restrict__ exact_list, char *__restrict__ records, int rec_cap, int ntiles)
+{
+    constexpr int D = 256;
+    constexpr int NW = 4;
+    constexpr int S16 = D / 16;
+    constexpr int IMG_BYTES = S16 * 1024;
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;
+    constexpr int CPW = S16 / NW;                            // 4 DMA pieces per wave per tile
+    constexpr int PER_TILE = CPW + 1;
+    constexpr int NBUF = 4;
+    constexpr int PF_STEPS = 8, PF_PER = 16;                 // prefetch: 8 steps x 16 loads = 128 values
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int T = dvq_num_tiles(K);
+    const float sB = meta->scale_b;
+    const float seed_scale = -0.5f * sB;
+    const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
+    const bool codebook_bad = !meta->ok || !((0.5f * sB * enmax) < 1.0e37f);
+
+    int ring_g = 0;      // code tiles issued so far (ring slot = g & 3)
+    int ring_t = 0;      // codebook tile index of the next issue (wraps at T)
+    auto issue_next = [&]() {
+        const char *src = img + (size_t)ring_t * TILE_STRIDE;
+        char *dst = lds + (ring_g & (NBUF - 1)) * IMG_BYTES;
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            int chunk = wave * CPW + q;
+            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
+        }
+        glds4(src + IMG_BYTES + lane * 4, enraw + ((ring_g & (NBUF - 1)) * NW + wave) * 64);
+        ++ring_g;
+        ring_t = (ring_t + 1 == T) ? 0 : ring_t + 1;
+    };
+    issue_next();
+    issue_next();
+    issue_next();
+
+    auto token_of = [&](int tl) -> int {                      // token of this lane in tile tl, or -1
+        const long n = ((long)tl * NW + wave) * 32 + c;
+        return (tl < ntiles && n < N) ? (int)n : -1;
+    };
+    auto base_of = [&](int n) -> size_t {
+        const long nn = (n >= 0) ? n : N - 1;
+        const long bimg = nn / HW;
+        const int hw = (int)(nn - bimg * HW);
+        return ((size_t)bimg * D + 8 * h) * HW + hw;           // channel 16s + 8h + j at + (16s+j)*HW
+    };
+
+    float zn[S16][8];                                          // next tile (prefetch target)
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);             // first tile: consecutive tiles on one XCD
+    {
+        const float *zp = z + base_of(token_of(tile));
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zn[s][j] = zp[(size_t)(16 * s + j) * HW];
+    }
+    double dsum = 0.0;
+    int cur_g = 0;                                             // ring position of code tile 0 of this token tile
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n = token_of(tile);
+        const int next_tile = tile + gridDim.x;
+        const float *znp = z + base_of(token_of(next_tile));  // clamped when there is no next tile
+        float zf[S16][8];
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zf[s][j] = zn[s][j];
+
+        // ---- exact xn, fp16 fragments, residual norm, decision threshold
+        f16x8 zh[S16];
+        float xn, thr2W;
+        {
+            float pa[2][8];
+            float amax = 0.0f, zeta2 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                u32x4 packed;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const float v0 = zf[s][2 * j2], v1 = zf[s][2 * j2 + 1];
+                    const float q0 = sq_rn(v0), q1 = sq_rn(v1);
+                    pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
+                    pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
+                    amax = vmax_raw(amax, fabsf(v0));
+                    amax = vmax_raw(amax, fabsf(v1));
+                    f32x2 vv = {v0, v1};
+                    f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    packed[j2] = __builtin_bit_cast(unsigned, hh);
+                    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
+                    zeta2 = __builtin_fmaf(r0, r0, zeta2);
+                    zeta2 = __builtin_fmaf(r1, r1, zeta2);
+                }
+                zh[s] = __builtin_bit_cast(f16x8, packed);
+                __builtin_amdgcn_sched_barrier(0);             // bound the live temporaries per k-step
+            }
+            float t8[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
+                float a0 = h == 0 ? pa[0][l] : o0;
+                float a1 = h == 0 ? o0 : pa[0][l];
+                float a2 = h == 0 ? pa[1][l] : o1;
+                float a3 = h == 0 ? o1 : pa[1][l];
+                t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+            }
+            xn = t8[0];
+#pragma unroll
+            for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            zeta2 += __shfl_xor(zeta2, 32);
+            const bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || codebook_bad;
+            const float zeta = sqrtf(zeta2) * 1.001f;
+            const float Rh = sqrtf(xn) * 1.00001f;
+            const float zn_ = Rh + zeta;
+            const float ehn = sB * emax + etamax;
+            float Wv = zeta * ehn + zn_ * etamax
+                       + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
+                       + PACK_E * sB * (Rh * emax + 0.5f * enmax)
+                       + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
+            thr2W = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+        }
+
+        // ---- code loop
+        float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+        int t1 = 0;
+        auto step = [&](auto pf_tag, int t) {
+            constexpr int PFI = decltype(pf_tag)::value;       // 0..9 peeled steps, -1 = steady state
+            __builtin_amdgcn_sched_barrier(0);                 // nothing moves across code-tile steps
+            if (PFI == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (PFI == 1 || PFI == 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE + PF_PER) : "memory");
+            else if (PFI > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE + 2 * PF_PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_next();                                      // ring slot of the tile consumed last step
+            if (PFI >= 0 && PFI < PF_STEPS) {                  // next token tile: 2 k-steps = 16 values
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        zn[2 * PFI + q][j] = znp[(size_t)(16 * (2 * PFI + q) + j) * HW];
+            }
+            const int slot = (cur_g + t) & (NBUF - 1);
+            const char *tile_p = lds + slot * IMG_BYTES + lane * 16;
+            const float *seeds = enraw + (slot * NW + wave) * 64 + 4 * h;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
+            }
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                f16x8 a = *(const f16x8 *)(tile_p + s * 1024);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
+            }
+            const float om = m1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
+                m1 = vmax_raw(m1, g);
+            }
+            t1 = (m1 != om) ? t : t1;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(PfTag<0>{}, 0); step(PfTag<1>{}, 1); step(PfTag<2>{}, 2); step(PfTag<3>{}, 3);
+        step(PfTag<4>{}, 4); step(PfTag<5>{}, 5); step(PfTag<6>{}, 6); step(PfTag<7>{}, 7);
+        step(PfTag<8>{}, 8); step(PfTag<9>{}, 9);
+        for (int t = 10; t < T; ++t) step(PfTag<-1>{}, t);
+        cur_g += T;
+
+        // ---- merge the two lane halves; provisional winner; final / queued / exact-list
+        int code;
+        float thr;
+        bool final_ok;
+        {
+            const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+            const int ot = __shfl_xor(t1, 32);
+            const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);
+            const float best = other_wins ? o1 : m1;
+            const float second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
+            const int wt = other_wins ? ot : t1;
+            const int wh = other_wins ? (h ^ 1) : h;
+            const int r = (int)(__float_as_uint(best) & 15u);
+            code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
+            thr = best - thr2W;
+            final_ok = (best - second) > thr2W;
+        }
+        const bool valid = n >= 0;
+        bool hopeless = !(code < K) || !(thr == thr);
+        int slot = -1;
+        if (valid && !hopeless && !final_ok) {
+            if (h == 0) slot = atomicAdd(&counters[0], 1);
+            slot = __shfl(slot, c);
+            if (slot >= rec_cap) { hopeless = true; slot = -1; }
+        }
+        if (valid && hopeless && h == 0) {
+            int pos = atomicAdd(&counters[1], 1);
+            exact_list[pos] = n;
+        }
+        if (slot >= 0) {
+            char *rec = records + (size_t)slot * rec_bytes(D);
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
+                f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
+                f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
+                *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
+                *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
+            }
+            if (h == 0) {
+                RecMeta rm;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
+                rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
+                *(RecMeta *)(rec + (size_t)D * 6) = rm;
+            }
+        }
+        // ---- provisional (usually final) outputs from the registers: code, z_q, loss term
+        float lsum = 0.0f;
+        if (valid && !hopeless) {
+            if (h == 0) codes[n] = (long long)code;
+            if (zq != nullptr || partials != nullptr) {
+                const float *ep = E + (size_t)code * D + 8 * h;
+                float *zqp = zq ? zq + base_of(n) : nullptr;
+                const float m = (mask != nullptr) ? mask[n] : 1.0f;
+#pragma unroll
+                for (int s0 = 0; s0 < S16; s0 += 4) {
+                    f32x4 eg[4][2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
+                        eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int s = s0 + q;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float e = eg[q][j >> 2][j & 3];
+                            float diff = __fsub_rn(e, zf[s][j]);
+                            if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[s][j], diff);
+                            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                        }
+                    }
+                }
+            }
+        }
+        dsum += (double)lsum;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the surplus ring DMA before LDS reuse
+    if (partials != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        __syncthreads();
+        double *red = (double *)lds;
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        for (int i = (int)gridDim.x + (int)blockIdx.x * 256 + tid; i < nparts_reserved; i += (int)gridDim.x * 256)
+            partials[i] = 0.0;                                // unused reserved slots
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // resolver: queued tokens, RES_SLOTS (= 32, one MFMA column set) per workgroup.  The queue is short
 // (a few % of the tokens), so the work is spread for LATENCY: the four waves of a workgroup share
 // the same 32 tokens and each takes every fourth code tile, reading its A fragments straight from
@@ -538,13 +1118,12 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     for (int s = 0; s < S16; ++s) zh[s] = *(const f16x8 *)(rec + (s * 2 + h) * 16);
     const RecMeta rm = *(const RecMeta *)(rec + (size_t)D * 6);
     const float thr = live ? rm.thr : __builtin_inff();
-    const float nss = rm.seed_scale;                  // -2^(b-1)
     __syncthreads();
 
     // ---- enumerate: every code whose approximate score reaches best - 2W
     for (int t = wave; t < T; t += 4) {
         const char *tile = img + (size_t)t * TILE_STRIDE;
-        const float *enr = (const float *)(tile + IMG_BYTES) + 4 * h;
+        const float *enr = (const float *)(tile + IMG_BYTES) + 4 * h;      // accumulator seeds of the tile      // accumulator seeds of the tile
         f16x8 a[S16];
 #pragma unroll
         for (int s = 0; s < S16; ++s) a[s] = *(const f16x8 *)(tile + s * 1024 + lane * 16);
@@ -561,7 +1140,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float g = __builtin_fmaf(en4[g4][q], nss, acc[4 * g4 + q]);       // +inf norm = padding
+                float g = acc[4 * g4 + q] + en4[g4][q];                            // padding: -3e38
                 hits |= (g >= thr) ? (1u << (4 * g4 + q)) : 0u;
             }
         while (hits) {
@@ -705,6 +1284,27 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
 // partials layout: [pass 1: ceil(N/256)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
 int dvq_filter_nparts(long N) { return 2 * (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
 
+// diagnostic: per-workgroup phase time stamps (s_memrealtime, 100 MHz), enabled by DVQ_DEBUG_STAMPS=1
+static unsigned long long *g_stamps = nullptr;
+static int g_stamps_n = 0;
+static unsigned long long *dvq_debug_stamps(int nblocks)
+{
+    static int on = -1;
+    if (on < 0) on = getenv("DVQ_DEBUG_STAMPS") ? 1 : 0;
+    if (!on) return nullptr;
+    if (g_stamps_n < nblocks) {
+        if (g_stamps) (void)hipFree(g_stamps);
+        (void)hipMalloc((void **)&g_stamps, (size_t)nblocks * 64);
+        g_stamps_n = nblocks;
+    }
+    return g_stamps;
+}
+extern "C" int dvq_debug_read_stamps(unsigned long long *host, int nblocks)
+{
+    if (!g_stamps || nblocks > g_stamps_n) return -1;
+    return (int)hipMemcpy(host, g_stamps, (size_t)nblocks * 64, hipMemcpyDeviceToHost);
+}
+
 static int tune_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -731,7 +1331,31 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
         attr_set = true;
     }
     int nb1;
-    if (nw == 4) {
+    const int ntiles = (int)((N + 127) / 128);
+    static int persist = -1, persist_grid = 256;
+    if (persist < 0) {
+        persist = tune_int("DVQ_TUNE_PERSIST", 1);
+        persist_grid = tune_int("DVQ_TUNE_GRID", 256);
+        (void)hipFuncSetAttribute((const void *)vq_assign_filter_persist_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4);
+    }
+    static int variant = -1;
+    if (variant < 0) {
+        variant = tune_int("DVQ_TUNE_VARIANT", 1);            // 0: NW-wave re-read form, 1: register-resident, 2: persistent
+        (void)hipFuncSetAttribute((const void *)vq_assign_filter_regs_kernel<D>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4));
+    }
+    if (variant == 2 && D == 256 && dvq_num_tiles(K) >= 12 && ntiles >= 2 * persist_grid) {
+        const size_t shm = 4 * 16 * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4;
+        hipLaunchKernelGGL(vq_assign_filter_persist_kernel, dim3(persist_grid), dim3(256), shm, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, ntiles, counters, exact_list, records, cap, ntiles);
+    } else if (variant == 1) {
+        const size_t shm = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4;
+        hipLaunchKernelGGL(vq_assign_filter_regs_kernel<D>, dim3(ntiles), dim3(256), shm, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger,
+                           dvq_debug_stamps(ntiles));
+    } else if (nw == 4) {
         nb1 = (int)((N + 127) / 128);
         hipLaunchKernelGGL((vq_assign_filter_kernel<D, 4>), dim3(nb1), dim3(256), shmem4, st, z, img, meta,
                            E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger);

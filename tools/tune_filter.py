@@ -10,17 +10,22 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     E = synth.codebook_trained(1024, 256)
     z = torch.from_numpy(synth.z_tokens(E, B, 32, 32, 2003)).to(dev)
     Et = torch.from_numpy(E).to(dev)
-    p = _CodebookPrep()
+    p, pe = _CodebookPrep(), _CodebookPrep()
+    zq0, c0, l0 = vq_assign(z, Et, pe, None, mode=0)
+    zq1, c1, l1 = vq_assign(z, Et, p, None, mode=1)
+    ok = bool(torch.equal(c0, c1) and torch.equal(zq0, zq1))
     for _ in range(5): vq_assign(z, Et, p, None, mode=1)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(20): vq_assign(z, Et, p, None, mode=1)
     e.record(); torch.cuda.synchronize()
-    print("RESULT %.1f us" % (s.elapsed_time(e) / 20 * 1000))
+    print("RESULT %.1f us exact-match %s loss %s %s" % (s.elapsed_time(e) / 20 * 1000, ok, l0.tolist(), l1.tolist()))
 else:
-    for nw in (8, 4):
-        for st in (0, 2, 4, 8, 12):
-            env = dict(os.environ, DVQ_TUNE_NW=str(nw), DVQ_TUNE_STAGGER=str(st))
-            out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True).stdout
-            print("nw", nw, "stagger", st, [l for l in out.splitlines() if l.startswith("RESULT")])
+    for cfg in sys.argv[1:]:
+        env = dict(os.environ)
+        for kv in cfg.split(","):
+            k, v = kv.split("=")
+            env["DVQ_TUNE_" + k] = v
+        out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+        print(cfg, [l for l in out.stdout.splitlines() if l.startswith("RESULT")] or out.stderr[-300:])
