@@ -28,8 +28,6 @@
 //   reference side, d = fl(fl(xn+en) - 2 dotc), dotc the D-term fp32 chain:
 //                                 <= 2^(a+b) [u(1+u)(xn+en) + (u + gamma_D)(1+gamma_D) ||z|| ||e_j||]
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
-#include <stdlib.h>
-
 #include "dvq_common.h"
 
 struct DvqF16Meta {
@@ -178,329 +176,21 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 1
-//   workgroup = 4 waves x 32 tokens (consecutive hw positions); FOUR workgroups per CU (<= 128
-//   VGPRs): latency of LDS reads, DMA and HBM is hidden by the other three waves of each SIMD.
-//   A wave converts its 32 tokens once to fp16 MFMA B fragments (D/4 VGPRs, no scaling of z: fp16
-//   holds |z| up to 65504, smaller magnitudes are covered by the computed residual norm) while it
-//   accumulates the exact xn; the fp32 values are NOT kept: the epilogue re-reads the wave's z
-//   tile (last-level-cache resident) for z_q.
-//   The fp16 codebook streams through LDS tile by tile (global->LDS DMA, double buffer); the
-//   accumulator of every tile is seeded from LDS with -2^(b-1) en_j so the MFMA output is the score.
-// ---------------------------------------------------------------------------------------------
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, 16 / NW) void vq_assign_filter_kernel(
-    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
-    const float *__restrict__ E, const float *__restrict__ mask,
-    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
-    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, int stagger_sleeps)
-{
-    // NW waves per workgroup (32 tokens each); 16/NW workgroups per CU
-    constexpr int S16 = D / 16;
-    constexpr int IMG_BYTES = S16 * 1024;                    // fp16 image of one 32-code tile
-    constexpr int TILE_STRIDE = IMG_BYTES + 256;             // + raw-norm tail, in the prep buffer
-    constexpr int CHUNKS = S16;                              // 1-KiB DMA pieces per tile
-    constexpr int CPW = (CHUNKS + NW - 1) / NW;              // pieces per wave (some waves idle if < NW)
-    constexpr int PER_TILE = CPW + 1;                        // DMA ops one wave issues per tile
-    constexpr int NBUF = (NW == 8) ? 4 : 2;                  // tile ring (LDS budget: 160 KiB / CU)
-    constexpr int SB = (S16 < 4) ? S16 : 4;                  // k-steps per load batch (8*SB values/lane)
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [NBUF][IMG_BYTES] fp16 tiles | [NBUF][NW][64] accumulator seeds (per-wave DMA copy)
-    float *enraw = (float *)(lds + NBUF * IMG_BYTES);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int T = dvq_num_tiles(K);
-    const float sB = meta->scale_b;
-
-    auto issue = [&](int t) {                                // PER_TILE DMA ops in every wave
-        const char *src = img + (size_t)t * TILE_STRIDE;
-        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
-#pragma unroll
-        for (int q = 0; q < CPW; ++q) {
-            int chunk = wave * CPW + q;
-            if (chunk >= CHUNKS) chunk = CHUNKS - 1;         // D < 128: surplus waves repeat a piece
-            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
-        }
-        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
-    };
-    // phase stagger (speed only): the workgroups that share a CU start at different times so that
-    // the HBM-bound prologue/epilogue of one overlaps the matrix-core-bound code loop of another
-    if (stagger_sleeps > 0) {
-        const int slots = 256 * (16 / NW);
-        if ((int)blockIdx.x < slots) {
-            const int k = ((int)blockIdx.x >> 8) * stagger_sleeps;
-            for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-    issue(0);
-    if (NBUF > 2) {
-        if (T > 1) issue(1);
-        if (T > 2) issue(2);
-    }
-
-    // token of this lane; -1 = past the end (loads are clamped to the last token)
-    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int n_raw = (tile_id * NW + wave) * 32 + c;
-    const int n = (n_raw < N) ? n_raw : -1;
-    auto token_base = [&]() -> size_t {
-        const long nn = (n >= 0) ? n : N - 1;
-        const long bimg = nn / HW;
-        const int hw = (int)(nn - bimg * HW);
-        return ((size_t)bimg * D + 8 * h) * HW + hw;           // channel 16s + 8h + j at + (16s+j)*HW
-    };
-
-    // ---- prologue: one pass over the token's channels, SB k-steps at a time:
-    //      exact ATen-order xn partials a[m] (m = i mod 32 = 16(s&1) + 8h + j), |z| max,
-    //      fp16 fragments and the squared norm of their rounding residual
-    f16x8 zh[S16];
-    float xn, thr2W;
-    {
-        const float *zp = z + token_base();
-        float pa[2][8];
-        float amax = 0.0f, zeta2 = 0.0f;
-#pragma unroll
-        for (int s0 = 0; s0 < S16; s0 += SB) {
-            if (s0 > 0) {
-                // the next batch's addresses are made to depend on this batch's results, otherwise
-                // the scheduler issues every load first and spills the raw values
-                unsigned dep;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(dep)
-                             : "v"(zeta2), "v"(amax), "v"(pa[0][0]), "v"(pa[0][1]), "v"(pa[0][2]), "v"(pa[0][3]),
-                               "v"(pa[0][4]), "v"(pa[0][5]), "v"(pa[0][6]), "v"(pa[0][7]), "v"(pa[1][0]),
-                               "v"(pa[1][1]), "v"(pa[1][2]), "v"(pa[1][3]), "v"(pa[1][4]), "v"(pa[1][5]),
-                               "v"(pa[1][6]), "v"(pa[1][7]));
-                zp += dep;
-            }
-            float zf[SB][8];
-#pragma unroll
-            for (int q = 0; q < SB; ++q)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) zf[q][j] = zp[(size_t)(16 * (s0 + q) + j) * HW];
-#pragma unroll
-            for (int q = 0; q < SB; ++q) {
-                const int s = s0 + q;
-                u32x4 packed;
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {             // two channels -> one v_cvt_pk_f16_f32 (RNE)
-                    const float v0 = zf[q][2 * j2], v1 = zf[q][2 * j2 + 1];
-                    const float q0 = sq_rn(v0), q1 = sq_rn(v1);
-                    pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
-                    pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
-                    amax = vmax_raw(amax, fabsf(v0));
-                    amax = vmax_raw(amax, fabsf(v1));
-                    f32x2 vv = {v0, v1};
-                    f16x2 hh = __builtin_convertvector(vv, f16x2);
-                    packed[j2] = __builtin_bit_cast(unsigned, hh);
-                    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
-                    zeta2 = __builtin_fmaf(r0, r0, zeta2);
-                    zeta2 = __builtin_fmaf(r1, r1, zeta2);
-                }
-                zh[s] = __builtin_bit_cast(f16x8, packed);
-            }
-            asm volatile("" ::: "memory");                   // keep the batches apart (register budget)
-        }
-        float t8[8];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
-            float a0 = h == 0 ? pa[0][l] : o0;      // a[l]      (h=0, p=0)
-            float a1 = h == 0 ? o0 : pa[0][l];      // a[l+8]    (h=1, p=0)
-            float a2 = h == 0 ? pa[1][l] : o1;      // a[l+16]   (h=0, p=1)
-            float a3 = h == 0 ? o1 : pa[1][l];      // a[l+24]   (h=1, p=1)
-            t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
-        }
-        xn = t8[0];
-#pragma unroll
-        for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
-        zeta2 += __shfl_xor(zeta2, 32);
-        // NaN / Inf / squares overflowing fp32 / beyond fp16 range -> not decidable here
-        bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok;
-        const float zeta = sqrtf(zeta2) * 1.001f;
-        const float Rh = sqrtf(xn) * 1.00001f;
-        const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
-        const float zn = Rh + zeta;                      // >= ||zh||
-        const float ehn = sB * emax + etamax;            // >= ||eh_j||
-        float Wv = zeta * ehn + zn * etamax
-                   + GAMMA_P * (zn * ehn + 0.5f * sB * enmax)
-                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
-                   + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
-        thr2W = 2.0f * Wv * 1.001f;
-        // seeds must stay far from the padding value and from overflow: 2^(b-1) max en < 1e37
-        bad = bad || !((0.5f * sB * enmax) < 1.0e37f);
-        if (bad) thr2W = __builtin_nanf("");             // NaN threshold = "not decidable here"
-    }
-
-    const float seed_scale = -0.5f * sB;
-
-    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
-    int t1 = 0;
-
-    for (int t = 0; t < T; ++t) {
-        if (NBUF > 2) {
-            // this wave's DMA of tiles <= t+1 has landed (only tile t+2 may still be in flight) ...
-            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // ... and everybody else's; tile t-1 consumed
-            asm volatile("" ::: "memory");
-            if (t + 3 < T) issue(t + 3);                     // into the ring slot of tile t-1
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + 1 < T) issue(t + 1);
-        }
-        const char *tile = lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16;
-        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
-        }
-#pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            f16x8 a = *(const f16x8 *)(tile + s * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
-        }
-        const float om = m1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-            m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
-            m1 = vmax_raw(m1, g);
-        }
-        t1 = (m1 != om) ? t : t1;
-    }
-
-    // ---- merge the two lane halves; provisional winner; final / queued / exact-list
-    int code;
-    float thr;
-    bool final_ok;
-    {
-        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-        const int ot = __shfl_xor(t1, 32);
-        const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);   // both lanes of a token agree
-        const float best = other_wins ? o1 : m1;
-        const float second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
-        const int wt = other_wins ? ot : t1;
-        const int wh = other_wins ? (h ^ 1) : h;
-        const int r = (int)(__float_as_uint(best) & 15u);
-        code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-        thr = best - thr2W;
-        final_ok = (best - second) > thr2W;
-    }
-    const bool valid = n >= 0;
-    const size_t zbase = token_base();
-    bool hopeless = !(code < K) || !(thr == thr);                 // NaN threshold -> exact list
-    int slot = -1;
-    if (valid && !hopeless && !final_ok) {                        // queue for the resolver
-        if (h == 0) slot = atomicAdd(&counters[0], 1);
-        slot = __shfl(slot, c);                                   // lane c (h = 0) of the same token
-        if (slot >= rec_cap) { hopeless = true; slot = -1; }
-    }
-    if (valid && hopeless && h == 0) {
-        int pos = atomicAdd(&counters[1], 1);
-        exact_list[pos] = n;
-    }
-    char *rec = (slot >= 0) ? records + (size_t)slot * rec_bytes(D) : nullptr;
-    if (rec != nullptr) {
-#pragma unroll
-        for (int s = 0; s < S16; ++s) *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
-        if (h == 0) {
-            RecMeta rm;
-            rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
-            rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
-            *(RecMeta *)(rec + (size_t)D * 6) = rm;
-        }
-    }
-    // ---- provisional (usually final) outputs: code, z_q = z + (e - z), loss term; z is re-read
-    float lsum = 0.0f;
-    if (valid && !hopeless) {
-        if (h == 0) codes[n] = (long long)code;
-        if (zq != nullptr || partials != nullptr || rec != nullptr) {
-            const float *ep = E + (size_t)code * D + 8 * h;
-            const float *zp = z + zbase;
-            float *zqp = zq ? zq + zbase : nullptr;
-            const float m = (mask != nullptr) ? mask[n] : 1.0f;
-#pragma unroll
-            for (int s0 = 0; s0 < S16; s0 += SB) {
-                if (s0 > 0) {                                // same trick: one batch at a time
-                    unsigned dep;
-                    asm volatile("v_mov_b32 %0, 0" : "=v"(dep) : "v"(lsum));
-                    zp += dep;
-                    ep += dep;
-                }
-                float zf[SB][8];
-                f32x4 eg[SB][2];
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) zf[q][j] = zp[(size_t)(16 * (s0 + q) + j) * HW];
-                    eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
-                    eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
-                }
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    const int s = s0 + q;
-                    if (rec != nullptr) {
-                        f32x4 lo = {zf[q][0], zf[q][1], zf[q][2], zf[q][3]};
-                        f32x4 hi = {zf[q][4], zf[q][5], zf[q][6], zf[q][7]};
-                        *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
-                        *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float e = eg[q][j >> 2][j & 3];
-                        float diff = __fsub_rn(e, zf[q][j]);
-                        if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[q][j], diff);
-                        lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-    }
-    if (partials != nullptr) {
-        double dsum = (double)lsum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
-        __syncthreads();
-        double *red = (double *)lds;
-        if (lane == 0) red[wave] = dsum;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += red[w];
-            partials[blockIdx.x * (NW / 4)] = tot;          // one slot per 128 tokens is reserved
-            if (NW == 8) partials[2 * blockIdx.x + 1] = 0.0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass 1, register-resident form: 4-wave workgroups, TWO per CU (<= 256 VGPRs).  A wave keeps its
+// pass 1: 4-wave workgroups of 128 consecutive tokens, TWO per CU (<= 256 VGPRs).  A wave keeps its
 // 32 tokens twice in registers -- fp32 (D/2 VGPRs, read once, reused for z_q and the resolver
 // record: z is never re-read, HBM traffic = the algorithmic bytes) and fp16 MFMA fragments (D/4).
 // Only two waves share a SIMD, so the code loop is written for per-wave matrix-core duty: seeds
 // read before the barrier, A fragments rotated through four register sets one k-step group ahead.
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, int stagger_sleeps, unsigned long long *__restrict__ stamps)
+    char *__restrict__ records, int rec_cap)
 {
     constexpr int NW = 4;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if (stamps) st0 = __builtin_amdgcn_s_memrealtime();
     constexpr int S16 = D / 16;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
@@ -516,9 +206,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
 
-    if (stagger_sleeps > 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < 512) {
-        for (int i = 0; i < stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);   // see the NW-wave form
-    }
     auto issue = [&](int t) {
         const int tt = (t < T) ? t : T - 1;                  // past the end: harmless repeat (constant counts)
         const char *src = img + (size_t)tt * TILE_STRIDE;
@@ -607,13 +294,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
     }
     const float seed_scale = -0.5f * sB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
-    if (stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
     int t1 = 0;
-    unsigned long long segA = 0, segB = 0, segC = 0, segD = 0, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
     for (int t = 0; t < T; ++t) {
-        if (stamps) tk0 = __builtin_amdgcn_s_memtime();
         // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
         const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
         f32x16 acc;
@@ -626,7 +310,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
         if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
         __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
         asm volatile("" ::: "memory");
-        if (stamps) tk1 = __builtin_amdgcn_s_memtime();
         issue(t + 3);
         // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
         // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
@@ -634,7 +317,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
                                     lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
         f16x8 a0, a1, a2, a3;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // seeds / norms traffic of this step is done
-        if (stamps) tk2 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
 #define DVQ_MM(src, S, WAIT, NEXT)                                                      \
@@ -658,7 +340,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
         }
 #undef DVQ_MM
 #undef DVQ_RD
-        if (stamps) tk3 = __builtin_amdgcn_s_memtime();
         const float om = m1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -667,14 +348,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
             m1 = vmax_raw(m1, g);
         }
         t1 = (m1 != om) ? t : t1;
-        if (stamps) {
-            asm volatile("" :: "v"(m1), "v"(m2));
-            unsigned long long tk4 = __builtin_amdgcn_s_memtime();
-            segA += tk1 - tk0; segB += tk2 - tk1; segC += tk3 - tk2; segD += tk4 - tk3;
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-    if (stamps) st2 = __builtin_amdgcn_s_memrealtime();
 
     int code;
     float thr;
@@ -760,310 +435,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_regs_kernel(
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
-    if (stamps) {                                            // diagnostic build only (DVQ_DEBUG_STAMPS)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            unsigned long long *o = stamps + 8 * blockIdx.x;
-            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = segA; o[5] = segB; o[6] = segC; o[7] = segD;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass 1, persistent form (D = 256, the production shape): one 4-wave workgroup per CU, ONE wave per
-// SIMD with the whole 512-register file, looping over 128-token tiles.
-//   * z is read from HBM exactly once: while a wave runs the code loop of its current 32 tokens it
-//     prefetches the next tile's fp32 z into a second register set (16 loads per code tile during
-//     the first 8 code tiles), so the HBM stream, the matrix cores and the z_q stores of the
-//     previous tile overlap inside every wave instead of relying on other waves;
-//   * the fp32 values stay in registers for z_q and for the resolver record (no re-read);
-//   * the fp16 codebook ring (4 x 16 KiB, global->LDS DMA, counted vmcnt, one barrier per code
-//     tile) runs continuously across token tiles.
-// Wait accounting (vmcnt counts DMA, loads and stores in issue order).  Per code-tile step t the
-// wave issues, in this order: [wait] [barrier] [DMA of tile g+3: PER_TILE ops] [prefetch loads:
-// 16 if t < 8].  Tile g+1 must have landed at step t; it was issued at step t-2, so everything
-// issued after it may stay in flight: PF(t-2) + PER_TILE + PF(t-1).  Step 0 drains everything
-// (the z_q stores of the previous tile were issued long before: the fp16 conversion sits between).
-// The DMA and prefetch ops are issued unconditionally (wrapped / clamped addresses at the end of
-// the sequence) so that the counts are compile-time constants.
-// ---------------------------------------------------------------------------------------------
-template <int PFI> struct PfTag { static constexpr int value = PFI; };
-
-__global__ __launch_bounds__(256, 1) void vq_assign_filter_persist_kernel(
-    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
-    const float *__restrict__ E, const float *__restrict__ mask,
-    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
-    double *__restrict__ partials, int nparts_reserved, int *__restrict__ counters,
-    int *__restrict__ exact_list, char *__restrict__ records, int rec_cap, int ntiles)
-{
-    constexpr int D = 256;
-    constexpr int NW = 4;
-    constexpr int S16 = D / 16;
-    constexpr int IMG_BYTES = S16 * 1024;
-    constexpr int TILE_STRIDE = IMG_BYTES + 256;
-    constexpr int CPW = S16 / NW;                            // 4 DMA pieces per wave per tile
-    constexpr int PER_TILE = CPW + 1;
-    constexpr int NBUF = 4;
-    constexpr int PF_STEPS = 8, PF_PER = 16;                 // prefetch: 8 steps x 16 loads = 128 values
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int T = dvq_num_tiles(K);
-    const float sB = meta->scale_b;
-    const float seed_scale = -0.5f * sB;
-    const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
-    const bool codebook_bad = !meta->ok || !((0.5f * sB * enmax) < 1.0e37f);
-
-    int ring_g = 0;      // code tiles issued so far (ring slot = g & 3)
-    int ring_t = 0;      // codebook tile index of the next issue (wraps at T)
-    auto issue_next = [&]() {
-        const char *src = img + (size_t)ring_t * TILE_STRIDE;
-        char *dst = lds + (ring_g & (NBUF - 1)) * IMG_BYTES;
-#pragma unroll
-        for (int q = 0; q < CPW; ++q) {
-            int chunk = wave * CPW + q;
-            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
-        }
-        glds4(src + IMG_BYTES + lane * 4, enraw + ((ring_g & (NBUF - 1)) * NW + wave) * 64);
-        ++ring_g;
-        ring_t = (ring_t + 1 == T) ? 0 : ring_t + 1;
-    };
-    issue_next();
-    issue_next();
-    issue_next();
-
-    auto token_of = [&](int tl) -> int {                      // token of this lane in tile tl, or -1
-        const long n = ((long)tl * NW + wave) * 32 + c;
-        return (tl < ntiles && n < N) ? (int)n : -1;
-    };
-    auto base_of = [&](int n) -> size_t {
-        const long nn = (n >= 0) ? n : N - 1;
-        const long bimg = nn / HW;
-        const int hw = (int)(nn - bimg * HW);
-        return ((size_t)bimg * D + 8 * h) * HW + hw;           // channel 16s + 8h + j at + (16s+j)*HW
-    };
-
-    float zn[S16][8];                                          // next tile (prefetch target)
-    int tile = xcd_swizzle(blockIdx.x, gridDim.x);             // first tile: consecutive tiles on one XCD
-    {
-        const float *zp = z + base_of(token_of(tile));
-#pragma unroll
-        for (int s = 0; s < S16; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zn[s][j] = zp[(size_t)(16 * s + j) * HW];
-    }
-    double dsum = 0.0;
-    int cur_g = 0;                                             // ring position of code tile 0 of this token tile
-
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int n = token_of(tile);
-        const int next_tile = tile + gridDim.x;
-        const float *znp = z + base_of(token_of(next_tile));  // clamped when there is no next tile
-        float zf[S16][8];
-#pragma unroll
-        for (int s = 0; s < S16; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = zn[s][j];
-
-        // ---- exact xn, fp16 fragments, residual norm, decision threshold
-        f16x8 zh[S16];
-        float xn, thr2W;
-        {
-            float pa[2][8];
-            float amax = 0.0f, zeta2 = 0.0f;
-#pragma unroll
-            for (int s = 0; s < S16; ++s) {
-                u32x4 packed;
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    const float v0 = zf[s][2 * j2], v1 = zf[s][2 * j2 + 1];
-                    const float q0 = sq_rn(v0), q1 = sq_rn(v1);
-                    pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
-                    pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
-                    amax = vmax_raw(amax, fabsf(v0));
-                    amax = vmax_raw(amax, fabsf(v1));
-                    f32x2 vv = {v0, v1};
-                    f16x2 hh = __builtin_convertvector(vv, f16x2);
-                    packed[j2] = __builtin_bit_cast(unsigned, hh);
-                    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
-                    zeta2 = __builtin_fmaf(r0, r0, zeta2);
-                    zeta2 = __builtin_fmaf(r1, r1, zeta2);
-                }
-                zh[s] = __builtin_bit_cast(f16x8, packed);
-                __builtin_amdgcn_sched_barrier(0);             // bound the live temporaries per k-step
-            }
-            float t8[8];
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
-                float a0 = h == 0 ? pa[0][l] : o0;
-                float a1 = h == 0 ? o0 : pa[0][l];
-                float a2 = h == 0 ? pa[1][l] : o1;
-                float a3 = h == 0 ? o1 : pa[1][l];
-                t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
-            }
-            xn = t8[0];
-#pragma unroll
-            for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
-            amax = fmaxf(amax, __shfl_xor(amax, 32));
-            zeta2 += __shfl_xor(zeta2, 32);
-            const bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || codebook_bad;
-            const float zeta = sqrtf(zeta2) * 1.001f;
-            const float Rh = sqrtf(xn) * 1.00001f;
-            const float zn_ = Rh + zeta;
-            const float ehn = sB * emax + etamax;
-            float Wv = zeta * ehn + zn_ * etamax
-                       + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
-                       + PACK_E * sB * (Rh * emax + 0.5f * enmax)
-                       + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
-            thr2W = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
-        }
-
-        // ---- code loop
-        float m1 = -__builtin_inff(), m2 = -__builtin_inff();
-        int t1 = 0;
-        auto step = [&](auto pf_tag, int t) {
-            constexpr int PFI = decltype(pf_tag)::value;       // 0..9 peeled steps, -1 = steady state
-            __builtin_amdgcn_sched_barrier(0);                 // nothing moves across code-tile steps
-            if (PFI == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (PFI == 1 || PFI == 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE + PF_PER) : "memory");
-            else if (PFI > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE + 2 * PF_PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue_next();                                      // ring slot of the tile consumed last step
-            if (PFI >= 0 && PFI < PF_STEPS) {                  // next token tile: 2 k-steps = 16 values
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        zn[2 * PFI + q][j] = znp[(size_t)(16 * (2 * PFI + q) + j) * HW];
-            }
-            const int slot = (cur_g + t) & (NBUF - 1);
-            const char *tile_p = lds + slot * IMG_BYTES + lane * 16;
-            const float *seeds = enraw + (slot * NW + wave) * 64 + 4 * h;
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
-            }
-#pragma unroll
-            for (int s = 0; s < S16; ++s) {
-                f16x8 a = *(const f16x8 *)(tile_p + s * 1024);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
-            }
-            const float om = m1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
-                m1 = vmax_raw(m1, g);
-            }
-            t1 = (m1 != om) ? t : t1;
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        step(PfTag<0>{}, 0); step(PfTag<1>{}, 1); step(PfTag<2>{}, 2); step(PfTag<3>{}, 3);
-        step(PfTag<4>{}, 4); step(PfTag<5>{}, 5); step(PfTag<6>{}, 6); step(PfTag<7>{}, 7);
-        step(PfTag<8>{}, 8); step(PfTag<9>{}, 9);
-        for (int t = 10; t < T; ++t) step(PfTag<-1>{}, t);
-        cur_g += T;
-
-        // ---- merge the two lane halves; provisional winner; final / queued / exact-list
-        int code;
-        float thr;
-        bool final_ok;
-        {
-            const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-            const int ot = __shfl_xor(t1, 32);
-            const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);
-            const float best = other_wins ? o1 : m1;
-            const float second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
-            const int wt = other_wins ? ot : t1;
-            const int wh = other_wins ? (h ^ 1) : h;
-            const int r = (int)(__float_as_uint(best) & 15u);
-            code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-            thr = best - thr2W;
-            final_ok = (best - second) > thr2W;
-        }
-        const bool valid = n >= 0;
-        bool hopeless = !(code < K) || !(thr == thr);
-        int slot = -1;
-        if (valid && !hopeless && !final_ok) {
-            if (h == 0) slot = atomicAdd(&counters[0], 1);
-            slot = __shfl(slot, c);
-            if (slot >= rec_cap) { hopeless = true; slot = -1; }
-        }
-        if (valid && hopeless && h == 0) {
-            int pos = atomicAdd(&counters[1], 1);
-            exact_list[pos] = n;
-        }
-        if (slot >= 0) {
-            char *rec = records + (size_t)slot * rec_bytes(D);
-#pragma unroll
-            for (int s = 0; s < S16; ++s) {
-                *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
-                f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
-                f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
-                *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
-                *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
-            }
-            if (h == 0) {
-                RecMeta rm;
-                rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
-                rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
-                *(RecMeta *)(rec + (size_t)D * 6) = rm;
-            }
-        }
-        // ---- provisional (usually final) outputs from the registers: code, z_q, loss term
-        float lsum = 0.0f;
-        if (valid && !hopeless) {
-            if (h == 0) codes[n] = (long long)code;
-            if (zq != nullptr || partials != nullptr) {
-                const float *ep = E + (size_t)code * D + 8 * h;
-                float *zqp = zq ? zq + base_of(n) : nullptr;
-                const float m = (mask != nullptr) ? mask[n] : 1.0f;
-#pragma unroll
-                for (int s0 = 0; s0 < S16; s0 += 4) {
-                    f32x4 eg[4][2];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
-                        eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int s = s0 + q;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float e = eg[q][j >> 2][j & 3];
-                            float diff = __fsub_rn(e, zf[s][j]);
-                            if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[s][j], diff);
-                            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-                        }
-                    }
-                }
-            }
-        }
-        dsum += (double)lsum;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the surplus ring DMA before LDS reuse
-    if (partials != nullptr) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
-        __syncthreads();
-        double *red = (double *)lds;
-        if (lane == 0) red[wave] = dsum;
-        __syncthreads();
-        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        for (int i = (int)gridDim.x + (int)blockIdx.x * 256 + tid; i < nparts_reserved; i += (int)gridDim.x * 256)
-            partials[i] = 0.0;                                // unused reserved slots
     }
 }
 
@@ -1284,33 +655,6 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
 // partials layout: [pass 1: ceil(N/256)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
 int dvq_filter_nparts(long N) { return 2 * (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
 
-// diagnostic: per-workgroup phase time stamps (s_memrealtime, 100 MHz), enabled by DVQ_DEBUG_STAMPS=1
-static unsigned long long *g_stamps = nullptr;
-static int g_stamps_n = 0;
-static unsigned long long *dvq_debug_stamps(int nblocks)
-{
-    static int on = -1;
-    if (on < 0) on = getenv("DVQ_DEBUG_STAMPS") ? 1 : 0;
-    if (!on) return nullptr;
-    if (g_stamps_n < nblocks) {
-        if (g_stamps) (void)hipFree(g_stamps);
-        (void)hipMalloc((void **)&g_stamps, (size_t)nblocks * 64);
-        g_stamps_n = nblocks;
-    }
-    return g_stamps;
-}
-extern "C" int dvq_debug_read_stamps(unsigned long long *host, int nblocks)
-{
-    if (!g_stamps || nblocks > g_stamps_n) return -1;
-    return (int)hipMemcpy(host, g_stamps, (size_t)nblocks * 64, hipMemcpyDeviceToHost);
-}
-
-static int tune_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
                          const float *E, const float *mask, int HW, int K, long N, float *zq,
@@ -1318,53 +662,15 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
                          char *records, int cap, hipStream_t st)
 {
     static bool attr_set = false;
-    static int nw = 8, stagger = 0;
-    const size_t shmem8 = 4 * (size_t)(D / 16) * 1024 + 4 * 8 * 64 * sizeof(float) + 2 * 8 * 32 * sizeof(float);
-    const size_t shmem4 = 2 * (size_t)(D / 16) * 1024 + 2 * 4 * 64 * sizeof(float) + 2 * 4 * 32 * sizeof(float);
+    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D, 8>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem8);
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D, 4>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem4);
-        nw = tune_int("DVQ_TUNE_NW", 8);
-        stagger = tune_int("DVQ_TUNE_STAGGER", 0);
+        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem1);
         attr_set = true;
     }
-    int nb1;
-    const int ntiles = (int)((N + 127) / 128);
-    static int persist = -1, persist_grid = 256;
-    if (persist < 0) {
-        persist = tune_int("DVQ_TUNE_PERSIST", 1);
-        persist_grid = tune_int("DVQ_TUNE_GRID", 256);
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_persist_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4);
-    }
-    static int variant = -1;
-    if (variant < 0) {
-        variant = tune_int("DVQ_TUNE_VARIANT", 1);            // 0: NW-wave re-read form, 1: register-resident, 2: persistent
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_regs_kernel<D>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4));
-    }
-    if (variant == 2 && D == 256 && dvq_num_tiles(K) >= 12 && ntiles >= 2 * persist_grid) {
-        const size_t shm = 4 * 16 * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4;
-        hipLaunchKernelGGL(vq_assign_filter_persist_kernel, dim3(persist_grid), dim3(256), shm, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, ntiles, counters, exact_list, records, cap, ntiles);
-    } else if (variant == 1) {
-        const size_t shm = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * 4 + 2 * 4 * 32 * 4;
-        hipLaunchKernelGGL(vq_assign_filter_regs_kernel<D>, dim3(ntiles), dim3(256), shm, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger,
-                           dvq_debug_stamps(ntiles));
-    } else if (nw == 4) {
-        nb1 = (int)((N + 127) / 128);
-        hipLaunchKernelGGL((vq_assign_filter_kernel<D, 4>), dim3(nb1), dim3(256), shmem4, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger);
-    } else {
-        nb1 = (int)((N + 255) / 256);
-        hipLaunchKernelGGL((vq_assign_filter_kernel<D, 8>), dim3(nb1), dim3(512), shmem8, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, stagger);
-    }
-    nb1 = (int)((N + 127) / 128);                            // partials slots reserved for pass 1
+    const int nb1 = (int)((N + 127) / 128);
+    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), 0, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
                        exact_list, records, cap);
