@@ -48,25 +48,27 @@ def cpu_baseline(E, B_gpu, target_s):
     from oracle import oracle
     oracle.build()
     cores = os.cpu_count() or 1
-    probe_b = 2
-    hf = synth.z_tokens(E, probe_b, 32, 32, 2903)
-    mask = np.ones((probe_b, 1, 32, 32), np.float32)
-    oracle.vq_assign_nchw(hf[:1], E, mask[:1])                       # warm
-    t0 = time.perf_counter()
-    oracle.vq_assign_nchw(hf, E, mask)
-    per_img = (time.perf_counter() - t0) / probe_b
-    nb = int(max(4, min(B_gpu, target_s / max(per_img, 1e-6))))
+    nb = min(B_gpu, 64)
     hf = synth.z_tokens(E, nb, 32, 32, 2903)
     hc = synth.z_tokens(E, nb, 16, 16, 2913)
     ent = synth.entropy_map(5903, nb, 16, 16)
-    t0 = time.perf_counter()
-    gate = oracle.entropy_gate(ent, 1.6777750253677368)
-    sel = oracle.route_select_dual(gate, hc, hf)
-    oracle.vq_assign_nchw(sel["h_dual"], E, sel["codebook_mask"])
-    dt = time.perf_counter() - t0
-    return {"value": nb / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images of the same workload (gate + select + VQ assign), oracle C port with "
-                      "OpenMP over tokens + AVX2 FMA chains, %.1f s" % (nb, dt)}
+
+    def one_pass():
+        gate = oracle.entropy_gate(ent, 1.6777750253677368)
+        sel = oracle.route_select_dual(gate, hc, hf)
+        oracle.vq_assign_nchw(sel["h_dual"], E, sel["codebook_mask"])
+
+    one_pass()                                                   # warm (page-in, OpenMP team)
+    reps, t0 = 0, time.perf_counter()
+    while True:                                                  # repeat the sample for ~target_s
+        one_pass()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_s or reps >= 10000:
+            break
+    return {"value": nb * reps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over %d images of the same workload (gate + select + VQ assign), oracle C "
+                      "port: OpenMP over tokens (%d threads) + AVX2 FMA chains, %.1f s" % (reps, nb, cores, dt)}
 
 
 def main():

@@ -6,8 +6,8 @@
 //   modules/dynamic_modules/RouterDual.py:53-57      (entropy threshold gate)
 // One pass: every output float4 reads exactly one source (the branch that won its cell), so HBM
 // traffic is the algorithmic 1 read + 1 write per element; the reference materialises two
-// upsampled copies and reads all branches.  Pure data movement -> HBM-bound, no LDS needed:
-// each thread moves 16 B, consecutive lanes consecutive addresses.
+// upsampled copies and reads all branches.  Pure data movement -> HBM-bound: each thread moves
+// 16 B, consecutive lanes consecutive addresses; LDS only holds the image's grain map (1 B / cell).
 #include "dvq_common.h"
 
 template <int G, bool I64>
@@ -38,8 +38,13 @@ __device__ __forceinline__ int gate_argmax(const void *gate, size_t cell)
 }
 
 // G = 2: dual (fine grid = 2x coarse); G = 3: triple (fine grid = 4x coarse, median 2x).
-// Work item = one float4 of one row of plane p of image b, p in [0, C]: planes 0..C-1 are the
-// feature channels, plane C is the codebook_mask plane (whose items also emit `indices`).
+// One workgroup = one image b and a run of PLANES_PER_BLOCK planes p in [0, C]: planes 0..C-1 are
+// the feature channels, plane C is the codebook_mask plane (which also emits `indices`).  The
+// image's grain map (argmax per coarse cell) is evaluated once per workgroup into LDS; after that
+// every thread streams float4s: one 16-B load from the branch that won the cell, one 16-B store.
+constexpr int PLANES_PER_BLOCK = 8;
+constexpr int MAX_CELLS = 4096;                 // grain map bytes kept in LDS (64 x 64 coarse cells)
+
 template <int G, bool I64>
 __global__ __launch_bounds__(256) void route_select_kernel(
     const void *__restrict__ gate, const float *__restrict__ h_coarse,
@@ -48,60 +53,71 @@ __global__ __launch_bounds__(256) void route_select_kernel(
     float *__restrict__ h_out, long long *__restrict__ indices, float *__restrict__ cmask)
 {
     constexpr int SC = (G == 2) ? 2 : 4;          // fine pixels per coarse cell edge
+    __shared__ unsigned char grain[MAX_CELLS];
     const int H = SC * hc, W = SC * wc, W4 = W / 4;
-    const size_t per_plane = (size_t)H * W4;
-    const size_t total = (size_t)B * (C + 1) * per_plane;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const size_t bp = i / per_plane;
-        const int rem = (int)(i - bp * per_plane);
-        const int b = (int)(bp / (C + 1)), p = (int)(bp - (size_t)b * (C + 1));
-        const int y = rem / W4, x = (rem - y * W4) * 4;
-        const int cy = y / SC;
-        // grain of the (up to two) coarse cells this float4 touches
-        const int cx0 = x / SC, cx1 = (x + 3) / SC;
-        const size_t cell0 = ((size_t)b * hc + cy) * wc + cx0;
-        const int g0 = gate_argmax<G, I64>(gate, cell0);
-        const int g1 = (cx1 != cx0) ? gate_argmax<G, I64>(gate, cell0 + 1) : g0;
-        if (p == C) {
-            f32x4 m;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int g = ((x + j) / SC == cx0) ? g0 : g1;
-                m[j] = (G == 2) ? (g == 0 ? 0.25f : 1.0f)
-                                : (g == 0 ? 0.0625f : (g == 1 ? 0.25f : 1.0f));
-            }
-            *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
-            if (y % SC == 0) {
-                if (x % SC == 0) indices[cell0] = g0;
-                if (cx1 != cx0) indices[cell0 + 1] = g1;
-            }
-            continue;
-        }
+    const int per_plane = H * W4;
+    const int ncell = hc * wc;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const int p0 = blockIdx.x * PLANES_PER_BLOCK;
+    const int p1 = (p0 + PLANES_PER_BLOCK < C + 1) ? p0 + PLANES_PER_BLOCK : C + 1;
+    const bool in_lds = ncell <= MAX_CELLS;
+    if (in_lds) {
+        for (int cell = threadIdx.x; cell < ncell; cell += 256)
+            grain[cell] = (unsigned char)gate_argmax<G, I64>(gate, (size_t)b * ncell + cell);
+        __syncthreads();
+    }
+    auto grain_of = [&](int cell) -> int {
+        return in_lds ? (int)grain[cell] : gate_argmax<G, I64>(gate, (size_t)b * ncell + cell);
+    };
+    for (int p = p0; p < p1; ++p) {
         const size_t plane = (size_t)b * C + p;
-        const size_t o = (plane * H + y) * W + x;
-        f32x4 v;
-        const bool all_fine = (g0 == G - 1) && (g1 == G - 1);
-        if (all_fine) {
-            v = *(const f32x4 *)(h_fine + o);
-        } else {
-            f32x4 f = {0.f, 0.f, 0.f, 0.f};
-            if (g0 == G - 1 || g1 == G - 1) f = *(const f32x4 *)(h_fine + o);
+        for (int i = threadIdx.x; i < per_plane; i += 256) {
+            const int y = i / W4, x = (i - y * W4) * 4;
+            const int cy = y / SC;
+            const int cx0 = x / SC, cx1 = (x + 3) / SC;       // the (up to two) coarse cells of this float4
+            const int cell0 = cy * wc + cx0;
+            const int g0 = grain_of(cell0);
+            const int g1 = (cx1 != cx0) ? grain_of(cell0 + 1) : g0;
+            if (p == C) {
+                f32x4 m;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int xx = x + j;
-                const int g = (xx / SC == cx0) ? g0 : g1;
-                float s;
-                if (g == 0)
-                    s = h_coarse[(plane * hc + cy) * wc + xx / SC];
-                else if (G == 3 && g == 1)
-                    s = h_median[(plane * (2 * hc) + y / 2) * (2 * wc) + xx / 2];
-                else
-                    s = f[j];
-                v[j] = s;
+                for (int j = 0; j < 4; ++j) {
+                    int g = ((x + j) / SC == cx0) ? g0 : g1;
+                    m[j] = (G == 2) ? (g == 0 ? 0.25f : 1.0f)
+                                    : (g == 0 ? 0.0625f : (g == 1 ? 0.25f : 1.0f));
+                }
+                *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
+                if (y % SC == 0) {
+                    if (x % SC == 0) indices[(size_t)b * ncell + cell0] = g0;
+                    if (cx1 != cx0) indices[(size_t)b * ncell + cell0 + 1] = g1;
+                }
+                continue;
             }
+            const size_t o = (plane * H + y) * W + x;
+            f32x4 v;
+            if (g0 == G - 1 && g1 == G - 1) {
+                v = *(const f32x4 *)(h_fine + o);
+            } else {
+                f32x4 f = {0.f, 0.f, 0.f, 0.f};
+                if (g0 == G - 1 || g1 == G - 1) f = *(const f32x4 *)(h_fine + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = x + j;
+                    const int g = (xx / SC == cx0) ? g0 : g1;
+                    float sv;
+                    if (g == 0)
+                        sv = h_coarse[(plane * hc + cy) * wc + xx / SC];
+                    else if (G == 3 && g == 1)
+                        sv = h_median[(plane * (2 * hc) + y / 2) * (2 * wc) + xx / 2];
+                    else
+                        sv = f[j];
+                    v[j] = sv;
+                }
+            }
+            *(f32x4 *)(h_out + o) = v;
         }
-        *(f32x4 *)(h_out + o) = v;
+    }
+    if (in_lds) __syncthreads();                  // the next image overwrites the grain map
     }
 }
 
@@ -153,9 +169,7 @@ int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *
                             const float *h_median, const float *h_fine, int B, int C, int hc, int wc,
                             float *h_out, long long *indices, float *cmask, hipStream_t st)
 {
-    const int SC = (G == 2) ? 2 : 4;
-    size_t items = (size_t)B * (C + 1) * (SC * hc) * (SC * wc / 4);
-    dim3 grid(grid_for(items)), block(256);
+    dim3 grid((C + 1 + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK, B < 65535 ? B : 65535), block(256);
     if (G == 2 && gate_i64)
         hipLaunchKernelGGL((route_select_kernel<2, true>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
     else if (G == 2)

@@ -1,0 +1,36 @@
+"""Turn the two PMC passes (FETCH_SIZE, WRITE_SIZE; units: KiB... 1024-byte units per the guide)
+into profiles/pmc_traffic.json: HBM bytes per launch of the filter kernel, with the gfx950 FETCH_SIZE
+correction calibrated on the exact kernel's known z read (same 4-B-per-lane access pattern)."""
+import csv, glob, json, sys, collections
+def load(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return per
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+N, D = 256 * 1024, 256
+known_read = N * D * 4 + 32 * (D * 4 + D * 4 + 8)            # z + the 32-code f32 tile image
+cal = [v for v in fetch["vq_assign_exact_kernel<256>"][:4]]
+cal_kib = sum(cal[1:]) / len(cal[1:])
+factor = known_read / (cal_kib * 1024.0)
+out = {"calibration": {"kernel": "vq_assign_exact_kernel<256> K=32 codes-only", "known_read_bytes": known_read,
+                       "FETCH_SIZE_raw_bytes": cal_kib * 1024.0, "fetch_correction_factor": factor}}
+def avg(per, name):
+    v = per[name]
+    return sum(v[1:]) / max(1, len(v[1:]))
+kernels = {}
+for name in ("vq_assign_filter_kernel<256>", "vq_resolve_kernel<256>"):
+    f_raw, w = avg(fetch, name) * 1024.0, avg(write, name) * 1024.0
+    kernels[name] = {"FETCH_SIZE_raw_bytes": f_raw, "fetch_bytes_corrected": f_raw * factor, "write_bytes": w,
+                     "hbm_bytes_per_launch": f_raw * factor + w}
+out["kernels"] = kernels
+alg = N * (D * 4 * 2 + 8 + 4) + 1024 * D * 4
+tot = sum(k["hbm_bytes_per_launch"] for k in kernels.values())
+out["filter"] = {"hbm_bytes_per_launch": kernels["vq_assign_filter_kernel<256>"]["hbm_bytes_per_launch"],
+                 "hbm_bytes_filter_plus_resolver": tot, "algorithmic_bytes": alg,
+                 "ratio_dominant_kernel_to_algorithmic": kernels["vq_assign_filter_kernel<256>"]["hbm_bytes_per_launch"] / alg}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["filter"]), "factor", factor)
