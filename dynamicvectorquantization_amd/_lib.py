@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(CSRC, "libdvq.so")
 DVQ_OK = 0
 MODE_EXACT = 0
 MODE_FILTER = 1
+MODE_FILTER_PASS1 = 2   # profiling aid: only the dominant filter kernel
 GATE_F32 = 0
 GATE_I64 = 1
 

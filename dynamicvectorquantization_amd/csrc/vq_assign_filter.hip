@@ -659,7 +659,7 @@ template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
                          const float *E, const float *mask, int HW, int K, long N, float *zq,
                          long long *codes, double *partials, int *counters, int *exact_list,
-                         char *records, int cap, hipStream_t st)
+                         char *records, int cap, bool pass1_only, hipStream_t st)
 {
     static bool attr_set = false;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
@@ -671,6 +671,7 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
     const int nb1 = (int)((N + 127) / 128);
     hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
                        E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
+    if (pass1_only) return (int)hipGetLastError();
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), 0, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
                        exact_list, records, cap);
@@ -679,7 +680,7 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
 
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, hipStream_t st)
+                      void *ws_extra, bool pass1_only, hipStream_t st)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
@@ -694,12 +695,12 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     if (e != hipSuccess) return (int)e;
     int rc;
     switch (D) {
-    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, st); break;
-    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, st); break;
-    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, st); break;
+    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
+    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
+    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
     default:  return -1000;
     }
-    if (rc) return rc;
+    if (rc || pass1_only) return rc;
     double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
                                  exact_list, counters + 1, st);

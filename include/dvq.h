@@ -39,6 +39,10 @@ extern "C" {
                             /* is not provably decided is re-evaluated by the exact chain.     */
                             /* Output is identical to DVQ_MODE_EXACT.                          */
 
+#define DVQ_MODE_FILTER_PASS1 2  /* profiling aid: ONLY the fp16 filter kernel of DVQ_MODE_FILTER (the      */
+                                /* dominant kernel); queued tokens keep their provisional code, the loss   */
+                                /* is not finalised.  Not a production mode.                               */
+
 /* gate dtypes for the router select */
 #define DVQ_GATE_F32 0
 #define DVQ_GATE_I64 1
