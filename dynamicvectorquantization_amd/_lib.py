@@ -27,6 +27,7 @@ EXPORTS = (
     "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_fallback_count_offset",
     "dvq_embed_gather_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_triple_f32",
+    "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
 
 
@@ -73,6 +74,13 @@ def _load():
     lib.dvq_route_select_dual_f32.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.dvq_route_select_triple_f32.restype = i32
     lib.dvq_route_select_triple_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.dvq_permute_dual_count_i64.restype = i32
+    lib.dvq_permute_dual_count_i64.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.dvq_permute_dual_forward_i64.restype = i32
+    lib.dvq_permute_dual_forward_i64.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i64),
+                                                 vp, vp, vp, vp, vp, vp, vp]
+    lib.dvq_permute_dual_backward_i64.restype = i32
+    lib.dvq_permute_dual_backward_i64.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp]
     return lib
 
 

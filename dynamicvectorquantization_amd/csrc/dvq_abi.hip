@@ -39,6 +39,16 @@ int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate
 int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
                             hipStream_t st);
 
+int dvq_launch_permute_count(const long long *grain, int B, int ncell, int *counts, int *maxes, hipStream_t st);
+int dvq_launch_permute_forward(const long long *codes, const long long *grain, int B, int hc, int wc,
+                               int row_first, int Lc, int Lf, const long long *special,
+                               long long *cc, long long *cp, long long *cs, long long *fc, long long *fp,
+                               long long *fs, hipStream_t st);
+int dvq_launch_permute_backward(const long long *cc, const long long *fc, const long long *cp,
+                                const long long *fp, int B, int Lc, int Lf, int hc, int wc,
+                                long long cpos_eos, long long fpos_eos, long long *target, hipStream_t st);
+int dvq_permute_max_cells(void);
+
 static int hip_rc(int rc, const char *what)
 {
     if (rc == 0) return DVQ_OK;
@@ -191,6 +201,57 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h
     if (!h_median) { dvq_set_error("dvq_route_select_triple_f32: null h_median"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_route_select(3, gate_dtype == DVQ_GATE_I64, gate, h_coarse, h_median, h_fine, B, C, hc, wc,
                                           h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_triple");
+}
+
+static int perm_dims_ok(const char *fn, int B, int hc, int wc)
+{
+    if (B <= 0 || hc <= 0 || wc <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    if ((long)hc * wc > dvq_permute_max_cells()) { dvq_set_error("%s: hc*wc=%ld exceeds %d coarse cells", fn, (long)hc * wc, dvq_permute_max_cells()); return DVQ_EUNSUPPORTED; }
+    return DVQ_OK;
+}
+
+int dvq_permute_dual_count_i64(const int64_t *grain, int B, int hc, int wc, int32_t *counts, int32_t *maxes,
+                               void *stream)
+{
+    if (!grain || !counts || !maxes) { dvq_set_error("dvq_permute_dual_count_i64: null pointer"); return DVQ_EINVAL; }
+    int rc = perm_dims_ok("dvq_permute_dual_count_i64", B, hc, wc);
+    if (rc) return rc;
+    return hip_rc(dvq_launch_permute_count((const long long *)grain, B, hc * wc, counts, maxes, (hipStream_t)stream), "permute_count");
+}
+
+int dvq_permute_dual_forward_i64(const int64_t *codes, const int64_t *grain, int B, int hc, int wc,
+                                 int order, int Lc, int Lf, const int64_t *special,
+                                 int64_t *coarse_content, int64_t *coarse_position, int64_t *coarse_segment,
+                                 int64_t *fine_content, int64_t *fine_position, int64_t *fine_segment,
+                                 void *stream)
+{
+    if (!codes || !grain || !special || !coarse_content || !coarse_position || !coarse_segment || !fine_content ||
+        !fine_position || !fine_segment) { dvq_set_error("dvq_permute_dual_forward_i64: null pointer"); return DVQ_EINVAL; }
+    int rc = perm_dims_ok("dvq_permute_dual_forward_i64", B, hc, wc);
+    if (rc) return rc;
+    if (order != 0 && order != 1) { dvq_set_error("dvq_permute_dual_forward_i64: order %d (0 region-first, 1 row-first)", order); return DVQ_EINVAL; }
+    if (Lc <= 0 || Lf <= 0) { dvq_set_error("dvq_permute_dual_forward_i64: Lc, Lf must be positive"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_permute_forward((const long long *)codes, (const long long *)grain, B, hc, wc, order, Lc, Lf,
+                                             (const long long *)special, (long long *)coarse_content,
+                                             (long long *)coarse_position, (long long *)coarse_segment,
+                                             (long long *)fine_content, (long long *)fine_position,
+                                             (long long *)fine_segment, (hipStream_t)stream), "permute_forward");
+}
+
+int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *fine_content,
+                                  const int64_t *coarse_position, const int64_t *fine_position,
+                                  int B, int Lc, int Lf, int hc, int wc,
+                                  int64_t coarse_position_eos, int64_t fine_position_eos,
+                                  int64_t *target, void *stream)
+{
+    if (!coarse_content || !fine_content || !coarse_position || !fine_position || !target) { dvq_set_error("dvq_permute_dual_backward_i64: null pointer"); return DVQ_EINVAL; }
+    int rc = perm_dims_ok("dvq_permute_dual_backward_i64", B, hc, wc);
+    if (rc) return rc;
+    if (Lc <= 0 || Lf <= 0) { dvq_set_error("dvq_permute_dual_backward_i64: Lc, Lf must be positive"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_permute_backward((const long long *)coarse_content, (const long long *)fine_content,
+                                              (const long long *)coarse_position, (const long long *)fine_position,
+                                              B, Lc, Lf, hc, wc, coarse_position_eos, fine_position_eos,
+                                              (long long *)target, (hipStream_t)stream), "permute_backward");
 }
 
 }  // extern "C"

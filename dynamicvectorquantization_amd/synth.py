@@ -135,3 +135,16 @@ def seeded_param(seed, i, key, shape):
     else:
         a = 0.1 * normal(seed + i, shape)
     return a.astype(np.float32)
+
+
+def images_flat_noise(seed, B, size=256, patch=16, p_noise=0.5, image_offset=0):
+    """images [B, 3, size, size] in [-1, 1] (section 8d): every patch x patch block is either one
+    flat colour (patch entropy ~0..0.7 -> coarse) or U(-1, 1) noise (entropy ~3 -> fine)."""
+    g = size // patch
+    off = image_offset
+    noisy = bernoulli(seed, (B, g, g), p_noise, offset=off * g * g)
+    flat = uniform(seed + 1, (B, 3, g, g), -1.0, 1.0, offset=off * 3 * g * g)
+    noise = uniform(seed + 2, (B, 3, size, size), -1.0, 1.0, offset=off * 3 * size * size)
+    flat_up = flat.repeat(patch, axis=-1).repeat(patch, axis=-2)
+    mask = noisy.repeat(patch, axis=-1).repeat(patch, axis=-2)[:, None]
+    return np.where(mask, noise, flat_up).astype(np.float32), noisy

@@ -121,6 +121,34 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 const float *h_fine, int B, int C, int hc, int wc,
                                 float *h_out, int64_t *indices, float *cmask, void *stream);
 
+/*
+ * DualGrainSeperatePermuter (modules/dynamic_modules/permuter.py): dense codes + grain map <->
+ * variable-length coarse / fine streams.  All tensors int64 like the reference.
+ *   count    counts[B,2] = (#coarse, #fine cells) per image, maxes[2] = their batch maxima; the
+ *            caller reads maxes (one device->host copy, as pad_sequence implies) and allocates
+ *            Lc = maxes[0] + 1, Lf = 4*maxes[1] + 1.
+ *   forward  permuter.py:50-109.  codes [B, 2hc, 2wc], grain [B, hc, wc] (0 coarse / 1 fine),
+ *            order 0 = "region-first", 1 = "row-first"; special[6] (HOST array) = content_pad,
+ *            content_eos, coarse_position_pad, coarse_position_eos, fine_position_pad,
+ *            fine_position_eos; outputs [B, Lc] x3 (content, position, segment = 0) and [B, Lf] x3
+ *            (content, position, segment = 1).  Entries that do not fit Lc / Lf are dropped.
+ *   backward permuter.py:111-135 (sequential semantics: later entries win, entries after EOS
+ *            ignored, no coarse upsample if the coarse stream has no EOS) -> target [B, 2hc, 2wc].
+ * hc*wc <= 1024.
+ */
+int dvq_permute_dual_count_i64(const int64_t *grain, int B, int hc, int wc,
+                               int32_t *counts, int32_t *maxes, void *stream);
+int dvq_permute_dual_forward_i64(const int64_t *codes, const int64_t *grain, int B, int hc, int wc,
+                                 int order, int Lc, int Lf, const int64_t *special,
+                                 int64_t *coarse_content, int64_t *coarse_position, int64_t *coarse_segment,
+                                 int64_t *fine_content, int64_t *fine_position, int64_t *fine_segment,
+                                 void *stream);
+int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *fine_content,
+                                  const int64_t *coarse_position, const int64_t *fine_position,
+                                  int B, int Lc, int Lf, int hc, int wc,
+                                  int64_t coarse_position_eos, int64_t fine_position_eos,
+                                  int64_t *target, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,39 @@
+"""Patch-entropy map (row a12): fp32 transcendental math -> 1e-5 tolerance; the grain map the
+fixed-entropy router derives from it must equal the reference's (values sit far from the threshold)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import _cases as C
+
+
+def _check(dev_name):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.entropy import Entropy
+    g = C.load("entropy_map_B2")
+    img, noisy = synth.images_flat_noise(int(g["seed"]), 2)
+    assert C.crc(img) == g["img_crc"] and np.array_equal(noisy, g["noisy"].astype(bool))
+    m = Entropy(16, 256, 256, chunk=1).eval()
+    with torch.no_grad():
+        ent = m(torch.from_numpy(img).to(dev_name)).cpu().numpy()
+    assert ent.shape == (2, 16, 16) and ent.dtype == np.float32
+    ref = g["entropy"]
+    assert np.all(np.abs(ent - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))), np.abs(ent - ref).max()
+    assert np.array_equal(ent > float(g["thr"]), noisy)                # identical grain map
+    assert ent[~noisy].min() > 0                                         # 1e-40 epsilon survived (no flush to zero)
+    return ent
+
+
+def test_entropy_cpu_matches_reference():
+    _check("cpu")
+
+
+@pytest.mark.gpu
+def test_entropy_gpu_matches_reference(dev, golden_dir):
+    import os
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    ent = _check(dev)
+    r = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    gate = r(entropy=torch.from_numpy(ent).to(dev))
+    g = C.load("entropy_map_B2")
+    assert np.array_equal(gate[..., 1].cpu().numpy().astype(bool), g["noisy"].astype(bool))
