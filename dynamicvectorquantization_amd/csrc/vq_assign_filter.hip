@@ -206,17 +206,22 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
 
-    auto issue = [&](int t) {
-        const int tt = (t < T) ? t : T - 1;                  // past the end: harmless repeat (constant counts)
+    // DMA of code tile t into its ring slot, in PER_TILE pieces (q < CPW: 1 KiB of the image, q == CPW:
+    // this wave's copy of the seeds).  Past the end: harmless repeat, so the counts stay constant.
+    auto issue_piece = [&](int t, int q) {
+        const int tt = (t < T) ? t : T - 1;
         const char *src = img + (size_t)tt * TILE_STRIDE;
-        char *dst = lds + (t & (NBUF - 1)) * IMG_BYTES;
-#pragma unroll
-        for (int q = 0; q < CPW; ++q) {
+        if (q < CPW) {
             int chunk = wave * CPW + q;
             if (chunk >= S16) chunk = S16 - 1;
-            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024);
+            glds16(src + chunk * 1024 + lane * 16, lds + (t & (NBUF - 1)) * IMG_BYTES + chunk * 1024);
+        } else {
+            glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
         }
-        glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
     issue(0);
     issue(1);
@@ -310,13 +315,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
         __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
         asm volatile("" ::: "memory");
-        issue(t + 3);
+        if (S16 != 16) issue(t + 3);                         // D = 256: pieces ride between the MFMAs below
         // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
         // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
         const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
                                     lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
         f16x8 a0, a1, a2, a3;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // seeds / norms traffic of this step is done
+        // make the compiler wait for the seed reads HERE (an opaque use of acc); otherwise its own
+        // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
+        asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);
 #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
 #define DVQ_MM(src, S, WAIT, NEXT)                                                      \
@@ -328,10 +335,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         NEXT
         DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
         if (S16 == 16) {
-            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-            DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, )
-            DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, ) DVQ_MM(a3, 11, 3, )
-            DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, ) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
+            // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
+            // then overlaps the MFMA already in the pipe instead of preceding the whole chain
+            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+            DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
+            DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
+            DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
         } else if (S16 == 8) {
             DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
             DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
