@@ -48,6 +48,7 @@ int dvq_launch_permute_backward(const long long *cc, const long long *fc, const 
                                 const long long *fp, int B, int Lc, int Lf, int hc, int wc,
                                 long long cpos_eos, long long fpos_eos, long long *target, hipStream_t st);
 int dvq_permute_max_cells(void);
+int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
 
 static int hip_rc(int rc, const char *what)
 {
@@ -201,6 +202,14 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h
     if (!h_median) { dvq_set_error("dvq_route_select_triple_f32: null h_median"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_route_select(3, gate_dtype == DVQ_GATE_I64, gate, h_coarse, h_median, h_fine, B, C, hc, wc,
                                           h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_triple");
+}
+
+int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream)
+{
+    if (!images || !out) { dvq_set_error("dvq_entropy_map_f32: null pointer"); return DVQ_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0) { dvq_set_error("dvq_entropy_map_f32: sizes must be positive"); return DVQ_EINVAL; }
+    if (patch != 16 || H % 16 != 0 || W % 16 != 0) { dvq_set_error("dvq_entropy_map_f32: patch=%d H=%d W=%d (patch 16, H and W multiples of 16)", patch, H, W); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_entropy_map(images, B, H, W, out, (hipStream_t)stream), "entropy_map");
 }
 
 static int perm_dims_ok(const char *fn, int B, int hc, int wc)

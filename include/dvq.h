@@ -122,6 +122,13 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 float *h_out, int64_t *indices, float *cmask, void *stream);
 
 /*
+ * Patch-entropy map, Entropy.forward (models/stage1_dynamic/dqvae_dual_entropy.py:13-63) with
+ * patch_size 16: images [B, 3, H, W] f32 (H, W multiples of 16) -> out [B, H/16, W/16] f32.
+ * Transcendental fp32 math: equal to the reference within 1e-5, not bit for bit.
+ */
+int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream);
+
+/*
  * DualGrainSeperatePermuter (modules/dynamic_modules/permuter.py): dense codes + grain map <->
  * variable-length coarse / fine streams.  All tensors int64 like the reference.
  *   count    counts[B,2] = (#coarse, #fine cells) per image, maxes[2] = their batch maxima; the

@@ -7,13 +7,13 @@ import torch
 from tests import _cases as C
 
 
-def _check(dev_name):
+def _check(dev_name, fused=False):
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.entropy import Entropy
     g = C.load("entropy_map_B2")
     img, noisy = synth.images_flat_noise(int(g["seed"]), 2)
     assert C.crc(img) == g["img_crc"] and np.array_equal(noisy, g["noisy"].astype(bool))
-    m = Entropy(16, 256, 256, chunk=1).eval()
+    m = Entropy(16, 256, 256, chunk=1, fused=fused).eval()
     with torch.no_grad():
         ent = m(torch.from_numpy(img).to(dev_name)).cpu().numpy()
     assert ent.shape == (2, 16, 16) and ent.dtype == np.float32
@@ -32,8 +32,30 @@ def test_entropy_cpu_matches_reference():
 def test_entropy_gpu_matches_reference(dev, golden_dir):
     import os
     from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
-    ent = _check(dev)
+    _check(dev, fused=False)                                       # the reference op sequence on PyTorch-ROCm
+    ent = _check(dev, fused=True)                                  # the fused HIP kernel
     r = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
     gate = r(entropy=torch.from_numpy(ent).to(dev))
     g = C.load("entropy_map_B2")
     assert np.array_equal(gate[..., 1].cpu().numpy().astype(bool), g["noisy"].astype(bool))
+
+
+def test_fused_entropy_refuses_cpu_tensors():
+    from dynamicvectorquantization_amd import _lib
+    from dynamicvectorquantization_amd.entropy import Entropy
+    with pytest.raises(_lib.DvqError):
+        Entropy(16, 256, 256)(torch.zeros(1, 3, 256, 256))
+
+
+@pytest.mark.gpu
+def test_fused_entropy_full_batch(dev):
+    """B = 64: fused kernel vs the reference op sequence on the same device"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.entropy import Entropy
+    img, noisy = synth.images_flat_noise(5001, 64)
+    x = torch.from_numpy(img).to(dev)
+    with torch.no_grad():
+        a = Entropy(16, 256, 256, fused=True)(x)
+        b = Entropy(16, 256, 256, chunk=8, fused=False)(x)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert np.array_equal((a > 1.6777750253677368).cpu().numpy(), noisy)
