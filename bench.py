@@ -78,11 +78,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()      # (a 1-GPU box can still exercise the N > 1 code path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DVQ_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dynamicvectorquantization_amd import _lib, synth
     from dynamicvectorquantization_amd.encode import all_gather_codes
