@@ -48,6 +48,8 @@ int dvq_launch_permute_backward(const long long *cc, const long long *fc, const 
                                 const long long *fp, int B, int Lc, int Lf, int hc, int wc,
                                 long long cpos_eos, long long fpos_eos, long long *target, hipStream_t st);
 int dvq_permute_max_cells(void);
+int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
+                              float *cluster_size, float *vectors_sum, hipStream_t st);
 int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
 
 static int hip_rc(int rc, const char *what)
@@ -202,6 +204,15 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h
     if (!h_median) { dvq_set_error("dvq_route_select_triple_f32: null h_median"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_route_select(3, gate_dtype == DVQ_GATE_I64, gate, h_coarse, h_median, h_fine, B, C, hc, wc,
                                           h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_triple");
+}
+
+int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int D, int HW, int K,
+                                float *cluster_size, float *vectors_sum, void *stream)
+{
+    if (!z || !codes || !cluster_size || !vectors_sum) { dvq_set_error("dvq_ema_accumulate_nchw_f32: null pointer"); return DVQ_EINVAL; }
+    if (B <= 0 || D <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_ema_accumulate_nchw_f32: sizes must be positive"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_ema_accumulate(z, (const long long *)codes, D, HW, (long)B * HW, K, cluster_size, vectors_sum,
+                                            (hipStream_t)stream), "ema_accumulate");
 }
 
 int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream)

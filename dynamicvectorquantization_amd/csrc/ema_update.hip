@@ -1,0 +1,64 @@
+// ema_update.hip -- training-mode codebook statistics for gfx950.
+//
+// Replaces the dense part of VQEmbedding._update_buffers (reference modules/vector_quantization/
+// quantize2_mask.py:66-84): the reference builds a one-hot [K, N] fp32 matrix (1 GiB at K = 1024,
+// N = 262144), scatters ones into it, row-sums it and multiplies it with the [N, D] token matrix.
+// Here: cluster_size[j] = #tokens with code j and vectors_sum[j, :] = sum of their vectors, straight
+// from the NCHW latents.  A workgroup transposes a [64 channel x 64 token] tile through LDS so that a
+// wave adds 64 CONSECUTIVE channels of one token to its code's row per instruction: 256 contiguous
+// bytes per float-atomic wave-instruction, the shape that runs at the chip's full atomic rate
+// (64 lanes hitting 64 different rows would be ~17x slower).  Bound: float-atomic throughput.
+// Float atomics add in arrival order: sums agree with the reference to rounding (1e-5), not bit for bit.
+#include "dvq_common.h"
+
+__global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__restrict__ z,
+                                                             const long long *__restrict__ codes, int D, int HW,
+                                                             long N, int K, float *__restrict__ cluster_size,
+                                                             float *__restrict__ vectors_sum)
+{
+    __shared__ float tile[64][65];                 // [channel][token], +1 pad: conflict-free transpose
+    __shared__ int code_s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long tok0 = (long)blockIdx.x * 64;
+    {
+        const long n = tok0 + threadIdx.x;
+        if (threadIdx.x < 64) {
+            long long cj = (n < N) ? codes[n] : -1;
+            code_s[threadIdx.x] = (cj >= 0 && cj < K) ? (int)cj : -1;
+            if (cj >= 0 && cj < K) atomicAdd(&cluster_size[cj], 1.0f);
+        }
+    }
+    const long n = tok0 + lane;                    // token of this lane while loading
+    const long nn = (n < N) ? n : N - 1;
+    const long b = nn / HW;
+    const int hw = (int)(nn - b * HW);
+    const float *zp = z + (size_t)b * D * HW + hw;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {             // wave w loads channels c0 + 16w + i: 64 tokens, coalesced
+            const int ch = 16 * wave + i;
+            tile[ch][lane] = (c0 + ch < D) ? zp[(size_t)(c0 + ch) * HW] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {             // wave w adds tokens 16w + i: lane = channel
+            const int tk = 16 * wave + i;
+            const int cj = code_s[tk];
+            if (cj >= 0 && c0 + lane < D)
+                atomicAdd(&vectors_sum[(size_t)cj * D + c0 + lane], tile[lane][tk]);
+        }
+    }
+}
+
+int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
+                              float *cluster_size, float *vectors_sum, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(cluster_size, 0, (size_t)K * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(vectors_sum, 0, (size_t)K * D * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ema_accumulate_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, z, codes, D, HW, N, K,
+                       cluster_size, vectors_sum);
+    return (int)hipGetLastError();
+}

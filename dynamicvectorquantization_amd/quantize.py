@@ -207,16 +207,36 @@ class VQEmbedding(nn.Embedding):
         return x + torch.rand_like(x) * std
 
     @torch.no_grad()
-    def _update_buffers(self, vectors, idxs):
-        """Training-mode EMA statistics (quantize2_mask.py:66-105).  The reference builds a dense
-        one-hot [K, N] matrix and multiplies; here the same sums are a bincount and an index_add
-        (summation order differs: tolerance-level parity), followed by the same collectives."""
+    def _cluster_sums(self, vectors, idxs, nchw=None):
+        """cluster_size [K] and vectors_sum_per_cluster [K, D] (quantize2_mask.py:74-84).  The
+        reference builds a dense one-hot [K, N] matrix and multiplies.  With the NCHW latents at
+        hand (`nchw` = z [B, D, *spatial], the layout the quantizer receives) one HIP kernel
+        (`dvq_ema_accumulate_nchw_f32`) produces both; otherwise a bincount and an index_add.
+        Either way the summation order differs from the reference: tolerance-level parity."""
+        n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
+        if nchw is not None and nchw.is_cuda and nchw.dtype == torch.float32:
+            z = nchw.contiguous()
+            B, HW = z.shape[0], z[0, 0].numel()
+            codes = idxs.reshape(B, HW).contiguous()
+            cluster_size = torch.empty(n_embed, dtype=torch.float32, device=z.device)
+            vsum = torch.empty(n_embed, embed_dim, dtype=torch.float32, device=z.device)
+            with torch.cuda.device(z.device):
+                _lib.check(_lib_handle.dvq_ema_accumulate_nchw_f32(
+                    z.data_ptr(), codes.data_ptr(), B, embed_dim, HW, n_embed, cluster_size.data_ptr(),
+                    vsum.data_ptr(), _lib.stream_ptr(z.device)), "dvq_ema_accumulate_nchw_f32")
+            return cluster_size, vsum
+        cluster_size = torch.bincount(idxs, minlength=n_embed).to(vectors.dtype)
+        return cluster_size, vectors.new_zeros(n_embed, embed_dim).index_add_(0, idxs, vectors)
+
+    @torch.no_grad()
+    def _update_buffers(self, vectors, idxs, nchw=None):
+        """Training-mode EMA statistics + dead-code restart (quantize2_mask.py:66-105); same
+        collectives as the reference when torch.distributed is initialised."""
         n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
         vectors = vectors.reshape(-1, embed_dim)
         idxs = idxs.reshape(-1)
         n_vectors = vectors.shape[0]
-        cluster_size = torch.bincount(idxs, minlength=n_embed).to(vectors.dtype)
-        vectors_sum_per_cluster = vectors.new_zeros(n_embed, embed_dim).index_add_(0, idxs, vectors)
+        cluster_size, vectors_sum_per_cluster = self._cluster_sums(vectors, idxs, nchw)
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(vectors_sum_per_cluster, op=dist.ReduceOp.SUM)
             dist.all_reduce(cluster_size, op=dist.ReduceOp.SUM)
@@ -292,11 +312,11 @@ class VectorQuantize2(nn.Module):
                                                    float(self.beta), 1.0, self.assign_mode)
         if self.training and self.codebook.ema:
             with torch.no_grad():
-                if self.accept_image_fmap or need_transpose:     # channel-major -> token rows
+                if self.accept_image_fmap or need_transpose:     # channel-major -> token rows (a view)
                     ztok = z.reshape(z.shape[0], z.shape[1], -1).permute(0, 2, 1)
+                    self.codebook._update_buffers(ztok, codes.reshape(-1), nchw=z.detach())
                 else:
-                    ztok = z
-                self.codebook._update_buffers(ztok, codes.reshape(-1))
+                    self.codebook._update_buffers(z, codes.reshape(-1))
                 self.codebook._update_embedding()
         if self.accept_image_fmap or need_transpose:
             x_q = zq

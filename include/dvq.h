@@ -122,6 +122,16 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 float *h_out, int64_t *indices, float *cmask, void *stream);
 
 /*
+ * Training-mode codebook statistics, the dense part of VQEmbedding._update_buffers
+ * (quantize2_mask.py:66-84: one-hot [K, N] matrix, row sum, matmul):
+ *   cluster_size[j] = #tokens with code j, vectors_sum[j, :] = sum of those tokens' vectors.
+ * z [B, D, HW] f32 (NCHW), codes [B, HW] int64; both outputs are overwritten.  Codes outside
+ * [0, K) are ignored.  Float atomics: equal to the reference within rounding (1e-5).
+ */
+int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int D, int HW, int K,
+                                float *cluster_size, float *vectors_sum, void *stream);
+
+/*
  * Patch-entropy map, Entropy.forward (models/stage1_dynamic/dqvae_dual_entropy.py:13-63) with
  * patch_size 16: images [B, 3, H, W] f32 (H, W multiples of 16) -> out [B, H/16, W/16] f32.
  * Transcendental fp32 math: equal to the reference within 1e-5, not bit for bit.

@@ -1,0 +1,59 @@
+"""Timing of the BASELINE.json configs other than the headline one (which bench.py owns): parity
+for these is covered by tests/; this prints one JSON object with per-config times on 1 GPU."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicvectorquantization_amd import synth, _lib
+from dynamicvectorquantization_amd.quantize import VectorQuantize2, VectorQuantizer2, _CodebookPrep, vq_assign
+from dynamicvectorquantization_amd.router import (DualGrainFeatureRouter, TripleGrainFeatureRouter,
+                                                  route_select_dual, route_select_triple)
+from dynamicvectorquantization_amd.encode import encode_dual, encode_triple
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(a).to(dev)
+
+def timeit(fn, n=20, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+out = {}
+E = synth.codebook_trained(1024, 256)
+# configs[0]: fixed-granularity VQ-VAE, 16x16x256, K=1024, B=4
+vqg = VectorQuantizer2(1024, 256, beta=0.25, legacy=False).to(dev).eval()
+z = t(synth.z_tokens(E, 4, 16, 16, 2001))
+with torch.no_grad():
+    out["cfg1_vqgan_B4_16x16_ms"] = timeit(lambda: vqg(z))
+# configs[1]: dual feature router r=0.5, B=64
+vq = VectorQuantize2(1024, 256).to(dev).eval(); vq.codebook.weight.data[:-1].copy_(t(E))
+r = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
+hf, hc = t(synth.z_tokens(E, 64, 32, 32, 2102)), t(synth.z_tokens(E, 64, 16, 16, 2112))
+with torch.no_grad():
+    out["cfg2_dual_feature_B64_ms"] = timeit(lambda: encode_dual(r, vq, hf, hc))
+    out["cfg2_router_mlp_only_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc))
+# configs[3] per-rank share: triple F32/16/8, B=128 per GPU
+r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
+hf, hm, hc = (t(synth.z_tokens(E, 128, 32, 32, 2104)), t(synth.z_tokens(E, 128, 16, 16, 2114)),
+              t(synth.z_tokens(E, 128, 8, 8, 2124)))
+with torch.no_grad():
+    out["cfg4_triple_B128_per_gpu_ms"] = timeit(lambda: encode_triple(r3, vq, hf, hm, hc))
+# configs[4]: large-codebook stress K=16384, B=512 (exact fp32-MFMA path vs fp16 filter path)
+E16 = synth.codebook_trained(16384, 256)
+Et = t(E16)
+zb = t(synth.z_tokens(E16, 64, 32, 32, 2005))
+pe, pf = _CodebookPrep(), _CodebookPrep()
+te = timeit(lambda: vq_assign(zb, Et, pe, None, mode=_lib.MODE_EXACT), n=5, warm=2)
+tf = timeit(lambda: vq_assign(zb, Et, pf, None, mode=_lib.MODE_FILTER), n=5, warm=2)
+out["cfg5_K16384_B64_exact_ms"], out["cfg5_K16384_B64_filter_ms"] = te, tf
+out["cfg5_K16384_B512_exact_ms_extrapolated"], out["cfg5_K16384_B512_filter_ms_extrapolated"] = te * 8, tf * 8
+out["cfg5_filter_queue"] = pf.fallback_count()
+zq0, c0, _ = vq_assign(zb, Et, pe, None, mode=_lib.MODE_EXACT)
+zq1, c1, _ = vq_assign(zb, Et, pf, None, mode=_lib.MODE_FILTER)
+out["cfg5_modes_bit_identical"] = bool(torch.equal(c0, c1) and torch.equal(zq0, zq1))
+flops = 2.0 * 16384 * 256 * 64 * 1024
+out["cfg5_exact_tflops"] = flops / (te * 1e-3) / 1e12
+out["cfg5_filter_tflops_equiv"] = flops / (tf * 1e-3) / 1e12
+print(json.dumps(out, indent=1))
