@@ -26,10 +26,9 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      hipStream_t st);
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, hipStream_t st);
+                      void *ws_extra, bool pass1_only, float *loss, float beta, hipStream_t st);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
-int dvq_filter_nparts(long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
                              float *loss, hipStream_t st);
 int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
@@ -140,10 +139,8 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                               (char *)ws + partials_bytes, pass1_only, st);
-        if (rc == 0 && pass1_only) return DVQ_OK;
-        if (rc) return hip_rc(rc, "vq_assign_filter");
-        nparts = dvq_filter_nparts(N);
+                               (char *)ws + partials_bytes, pass1_only, loss, beta, st);
+        return hip_rc(rc, "vq_assign_filter");     // the loss finalize is fused into its last kernel
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
                               (long long *)codes, partials, st);

@@ -83,5 +83,17 @@ __device__ __forceinline__ void argmin_merge(float &d, int &i, float d2, int i2)
     if (other) { d = d2; i = i2; }
 }
 
+// Loss finalize fused into the last kernel of the filter path (vq_assign_exact_kernel in list
+// mode): the block that draws the last ticket sums partials[0 .. nparts) and writes loss[0..1].
+struct DvqLossTail {
+    float *loss;              // nullptr = no fused finalize
+    const double *partials;
+    int *ticket;              // zeroed by the op's counter memset
+    int nparts;
+    double inv_numel;
+    float beta;
+};
+#define DVQ_EXACT_LIST_BLOCKS 256   // grid of the list-mode exact kernel (it walks the list in chunks)
+
 // per-launch host-side error plumbing (dvq_abi.hip)
 void dvq_set_error(const char *fmt, ...);

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
     const float *__restrict__ mask, int HW, int K, long N,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
-    const int *__restrict__ list, const int *__restrict__ list_count)
+    const int *__restrict__ list, const int *__restrict__ list_count,
+    DvqLossTail tail)
 {
     constexpr int S = D / 2;                         // MFMA steps (2 k each)
     constexpr int TILE_FLOATS = 32 * D + 64;
@@ -36,16 +37,16 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    // tokens: the dense range [0, N), or (pass 2 of the filter path) the entries of a work list
-    long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
+    // tokens: the dense range [0, N) (one 128-token chunk per block), or (pass 2 of the filter path)
+    // the entries of a work list, which a small grid walks in 128-entry chunks
+    const int cnt = (list != nullptr) ? *list_count : 0;
+    double block_sum = 0.0;
+    for (long chunk = blockIdx.x; list == nullptr ? chunk == (long)blockIdx.x : chunk * 128 < cnt;
+         chunk += gridDim.x) {
+    long n = (chunk * 4 + wave) * 32 + c;
     bool valid = n < N;
     long nn = valid ? n : N - 1;
     if (list != nullptr) {
-        const int cnt = *list_count;
-        if ((long)blockIdx.x * 128 >= cnt) {             // block-uniform: nothing queued for this block
-            if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
-            return;
-        }
         valid = n < cnt;
         n = list[valid ? n : 0];
         nn = n;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     };
 
     const int T = dvq_num_tiles(K);
+    __syncthreads();                          // (list mode, next chunk) everyone is done with the buffers
     stage(0, lds);
 
     // ---- xn: ATen-order sum of squares of this token (both lanes of a token get the same value)
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         }
         if (!valid) lsum = 0.0f;
     }
+    block_sum += (double)lsum;
+    }   // chunk loop
     if (partials != nullptr) {
-        double ds = (double)lsum;
+        double ds = block_sum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off);
         __syncthreads();                       // all waves are done with the tile buffers
@@ -173,6 +177,45 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         if (lane == 0) red[wave] = ds;
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    if (tail.loss != nullptr) {
+        // fused loss finalize: the block that takes the last ticket sums every partial of the op
+        // (fixed order -> the result does not depend on which block that is)
+        int *flag = (int *)lds + 16;
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            int old = atomicAdd(tail.ticket, 1);
+            *flag = (old == (int)gridDim.x - 1);
+        }
+        __syncthreads();
+        if (*flag) {
+            __threadfence();
+            // partials of the earlier kernels are plain memory by now; this kernel's own need
+            // device-coherent loads (they were written by blocks on other XCDs)
+            const int nprev = tail.nparts - (int)gridDim.x;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int i = tid;
+            for (; i + 768 < nprev; i += 1024) {
+                s0 += tail.partials[i]; s1 += tail.partials[i + 256];
+                s2 += tail.partials[i + 512]; s3 += tail.partials[i + 768];
+            }
+            for (; i < nprev; i += 256) s0 += tail.partials[i];
+            for (i = nprev + tid; i < tail.nparts; i += 256)
+                s1 += __hip_atomic_load(tail.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            double *red = (double *)lds + 16;
+            __syncthreads();
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            if (tid == 0) {
+                float mean = (float)(((red[0] + red[1]) + (red[2] + red[3])) * tail.inv_numel);
+                tail.loss[0] = mean;
+                tail.loss[1] = __fadd_rn(__fmul_rn(tail.beta, mean), mean);
+            }
+        }
     }
 }
 
@@ -254,7 +297,7 @@ int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st
 template <int D>
 static int launch_exact(const float *z, const float *tiles, const float *E, const float *mask,
                         int HW, int K, long N, float *zq, long long *codes, double *partials,
-                        const int *list, const int *list_count, hipStream_t st)
+                        const int *list, const int *list_count, DvqLossTail tail, hipStream_t st)
 {
     static bool attr_set = false;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
@@ -264,20 +307,21 @@ static int launch_exact(const float *z, const float *tiles, const float *E, cons
         attr_set = true;
     }
     int blocks = (int)((N + 127) / 128);
+    if (list != nullptr && blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
     hipLaunchKernelGGL(vq_assign_exact_kernel<D>, dim3(blocks), dim3(256), shmem, st,
-                       z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count);
+                       z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
     return (int)hipGetLastError();
 }
 
 // pass 2 of the filter path: the tokens listed in list[0 .. *list_count)
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                          const int *list, const int *list_count, hipStream_t st)
+                          const int *list, const int *list_count, DvqLossTail tail, hipStream_t st)
 {
     switch (D) {
-    case 64:  return launch_exact<64>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
-    case 128: return launch_exact<128>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
-    case 256: return launch_exact<256>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, st);
+    case 64:  return launch_exact<64>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
+    case 128: return launch_exact<128>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
+    case 256: return launch_exact<256>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
     default:  return -1000;
     }
 }
@@ -287,10 +331,11 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      hipStream_t st)
 {
     const float *tiles = prep;
+    const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f};
     switch (D) {
-    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
-    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
-    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, st);
+    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
+    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
+    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
     default:  return -1000;
     }
 }

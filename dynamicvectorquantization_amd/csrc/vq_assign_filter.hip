@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
 // ---------------------------------------------------------------------------------------------
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                          const int *list, const int *list_count, hipStream_t st);
+                          const int *list, const int *list_count, DvqLossTail tail, hipStream_t st);
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -661,8 +661,13 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// partials layout: [pass 1: ceil(N/256)][resolver: cap/RES_SLOTS][exact list: ceil(N/128)]
-int dvq_filter_nparts(long N) { return 2 * (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS; }
+// partials layout: [pass 1: ceil(N/128)][resolver: cap/RES_SLOTS][exact list: min(ceil(N/128), DVQ_EXACT_LIST_BLOCKS)]
+static int list_blocks(long N)
+{
+    long nb = (N + 127) / 128;
+    return (int)(nb < DVQ_EXACT_LIST_BLOCKS ? nb : DVQ_EXACT_LIST_BLOCKS);
+}
+int dvq_filter_nparts(long N) { return (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS + list_blocks(N); }
 
 template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
@@ -689,7 +694,7 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
 
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, hipStream_t st)
+                      void *ws_extra, bool pass1_only, float *loss, float beta, hipStream_t st)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
@@ -700,7 +705,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     int *exact_list = (int *)((char *)ws_extra + 256);
     char *records = (char *)ws_extra + 256 + align256((size_t)N * sizeof(int));
     const int cap = rec_capacity(N);
-    hipError_t e = hipMemsetAsync(counters, 0, 16, st);
+    hipError_t e = hipMemsetAsync(counters, 0, 32, st);     // [0] queue, [1] exact list, [4] finalize ticket
     if (e != hipSuccess) return (int)e;
     int rc;
     switch (D) {
@@ -711,6 +716,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     }
     if (rc || pass1_only) return rc;
     double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
+    // the list kernel is the last of the op: it also sums all partials into loss[0..1]
+    const DvqLossTail tail = {partials ? loss : nullptr, partials, counters + 4, dvq_filter_nparts(N),
+                              1.0 / ((double)N * D), beta};
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
-                                 exact_list, counters + 1, st);
+                                 exact_list, counters + 1, tail, st);
 }

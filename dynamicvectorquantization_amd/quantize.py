@@ -208,38 +208,41 @@ class VQEmbedding(nn.Embedding):
 
     @torch.no_grad()
     def _cluster_sums(self, vectors, idxs, nchw=None):
-        """cluster_size [K] and vectors_sum_per_cluster [K, D] (quantize2_mask.py:74-84).  The
-        reference builds a dense one-hot [K, N] matrix and multiplies.  With the NCHW latents at
+        """cluster_size [K] and vectors_sum_per_cluster [K, D] (quantize2_mask.py:74-84), returned as
+        views of ONE flat [K*D + K] buffer so the data-parallel reduction is a single collective.
+        The reference builds a dense one-hot [K, N] matrix and multiplies.  With the NCHW latents at
         hand (`nchw` = z [B, D, *spatial], the layout the quantizer receives) one HIP kernel
         (`dvq_ema_accumulate_nchw_f32`) produces both; otherwise a bincount and an index_add.
         Either way the summation order differs from the reference: tolerance-level parity."""
         n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
+        flat = torch.empty(n_embed * embed_dim + n_embed, dtype=torch.float32, device=vectors.device)
+        vsum = flat[:n_embed * embed_dim].view(n_embed, embed_dim)
+        cluster_size = flat[n_embed * embed_dim:]
         if nchw is not None and nchw.is_cuda and nchw.dtype == torch.float32:
             z = nchw.contiguous()
             B, HW = z.shape[0], z[0, 0].numel()
             codes = idxs.reshape(B, HW).contiguous()
-            cluster_size = torch.empty(n_embed, dtype=torch.float32, device=z.device)
-            vsum = torch.empty(n_embed, embed_dim, dtype=torch.float32, device=z.device)
             with torch.cuda.device(z.device):
                 _lib.check(_lib_handle.dvq_ema_accumulate_nchw_f32(
                     z.data_ptr(), codes.data_ptr(), B, embed_dim, HW, n_embed, cluster_size.data_ptr(),
                     vsum.data_ptr(), _lib.stream_ptr(z.device)), "dvq_ema_accumulate_nchw_f32")
-            return cluster_size, vsum
-        cluster_size = torch.bincount(idxs, minlength=n_embed).to(vectors.dtype)
-        return cluster_size, vectors.new_zeros(n_embed, embed_dim).index_add_(0, idxs, vectors)
+        else:
+            cluster_size.copy_(torch.bincount(idxs, minlength=n_embed))
+            vsum.zero_().index_add_(0, idxs, vectors.to(torch.float32))
+        return cluster_size, vsum, flat
 
     @torch.no_grad()
     def _update_buffers(self, vectors, idxs, nchw=None):
-        """Training-mode EMA statistics + dead-code restart (quantize2_mask.py:66-105); same
-        collectives as the reference when torch.distributed is initialised."""
+        """Training-mode EMA statistics + dead-code restart (quantize2_mask.py:66-105).  Data-parallel:
+        the reference's two all_reduce calls (:87-88) are one all_reduce over the flat [K*D + K]
+        statistics buffer; the restart vectors are broadcast from rank 0 as in :100."""
         n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
         vectors = vectors.reshape(-1, embed_dim)
         idxs = idxs.reshape(-1)
         n_vectors = vectors.shape[0]
-        cluster_size, vectors_sum_per_cluster = self._cluster_sums(vectors, idxs, nchw)
+        cluster_size, vectors_sum_per_cluster, flat = self._cluster_sums(vectors, idxs, nchw)
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(vectors_sum_per_cluster, op=dist.ReduceOp.SUM)
-            dist.all_reduce(cluster_size, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         self.cluster_size_ema.mul_(self.decay).add_(cluster_size, alpha=1 - self.decay)
         self.embed_ema.mul_(self.decay).add_(vectors_sum_per_cluster, alpha=1 - self.decay)
         if self.restart_unused_codes:

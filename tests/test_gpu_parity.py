@@ -366,3 +366,16 @@ def test_autograd_straight_through(dev):
     e = vq.get_codebook_entry(codes).permute(0, 3, 1, 2)
     expect = 1.0 + 3.0 * 0.25 * 2.0 * (z.detach() - e) * mask / z.numel()
     assert torch.allclose(z.grad, expect, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_filter_mode_matches_exact_mode_on_random_sweep():
+    """The exact mode is pinned to the oracle above; the filter mode must agree with it bit for bit on
+    random shapes, scales (fp16-range overflow / underflow), duplicated codes, NaN / Inf latents."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_modes", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_modes.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, n = fuzz.run(80, seed=777, verbose=False)
+    assert n == 80 and bad == 0

@@ -66,3 +66,50 @@ def test_all_gather_codes_world2(B):
         assert np.array_equal(codes, o["codes"].reshape(B, 8, 8))
         assert np.array_equal(grain, gate.argmax(-1))
         assert abs(mean - o["sqerr"] / o["numel"]) <= 1e-6 * abs(mean)
+
+
+def _ema_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dynamicvectorquantization_amd.quantize import VQEmbedding
+        torch.manual_seed(5)                                   # same initial codebook on both ranks
+        emb = VQEmbedding(16, 8, decay=0.0, restart_unused_codes=True)   # decay 0: EMA = this step's statistics
+        g = torch.Generator().manual_seed(100 + rank)          # different tokens / assignments per rank
+        vec = torch.randn(40, 8, generator=g)
+        idx = torch.randint(0, 12, (40,), generator=g)         # codes 12..15 stay unused -> restarted
+        emb._update_buffers(vec, idx)
+        emb._update_embedding()
+        q.put((rank, vec.numpy(), idx.numpy(), emb.cluster_size_ema.numpy().copy(),
+               emb.embed_ema.numpy().copy(), emb.weight.detach().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ema_update_world2_single_collective():
+    """training-mode EMA statistics under data parallelism (reference quantize2_mask.py:86-100): the
+    fused all_reduce over [K*D + K] leaves every rank with the statistics of the union of the shards,
+    and the dead-code restart vectors are rank 0's on every rank"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ema_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, v0, i0, cs0, ee0, w0), (_, v1, i1, cs1, ee1, w1) = res
+    np.testing.assert_array_equal(cs0, cs1)
+    np.testing.assert_array_equal(ee0, ee1)
+    np.testing.assert_array_equal(w0[:-1], w1[:-1])
+    idx = np.concatenate([i0, i1]); vec = np.concatenate([v0, v1])
+    counts = np.bincount(idx, minlength=16).astype(np.float64)
+    used = counts > 0
+    sums = np.zeros((16, 8)); np.add.at(sums, idx, vec.astype(np.float64))
+    np.testing.assert_array_equal(cs0[used], counts[used])                 # all-reduced counts of BOTH shards
+    np.testing.assert_allclose(ee0[used], sums[used], rtol=1e-5, atol=1e-6)
+    assert used.sum() == 12 and np.all(cs0[~used] == 1.0)                   # dead codes restarted ...
+    rows0 = {tuple(np.round(r, 5)) for r in v0}
+    assert all(tuple(np.round(r, 5)) in rows0 for r in ee0[~used])          # ... with rank 0's vectors everywhere

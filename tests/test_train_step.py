@@ -43,7 +43,7 @@ def test_ema_accumulate_vs_float64(dev):
     m.codebook.weight.data[:-1].copy_(torch.from_numpy(E).to(dev))
     with torch.no_grad():
         _, _, (_, _, codes) = m(z)
-        cs, vs = m.codebook._cluster_sums(None, codes.reshape(-1), nchw=z)
+        cs, vs, _ = m.codebook._cluster_sums(z, codes.reshape(-1), nchw=z)
     tok = z.reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D).double()
     ref_cs = torch.bincount(codes.reshape(-1), minlength=K).double()
     ref_vs = torch.zeros(K, D, dtype=torch.float64, device=dev).index_add_(0, codes.reshape(-1), tok)

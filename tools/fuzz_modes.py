@@ -1,0 +1,67 @@
+"""Randomised parity sweep: DVQ_MODE_FILTER must reproduce DVQ_MODE_EXACT bit for bit (codes, z_q, and
+the loss to 1e-6) across scales, codebook shapes, near-duplicate codes and odd sizes.  The exact mode is
+itself pinned to the oracle / reference goldens by tests/; this sweep hunts for inputs on which the
+filter's error bound would be too optimistic."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicvectorquantization_amd import synth, _lib
+from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+
+
+def run(ncases=150, seed=12345, verbose=True):
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(seed)
+  bad = 0
+  stats = []
+  for case in range(ncases):
+      D = int(rng.choice([64, 128, 256, 256, 256]))
+      K = int(rng.choice([1, 7, 31, 32, 33, 100, 256, 1000, 1024, 2048, 4096]))
+      B = int(rng.choice([1, 2, 3, 8])); H = int(rng.choice([1, 3, 8, 16, 32])); W = int(rng.choice([1, 5, 8, 16, 32]))
+      kind = rng.choice(["trained", "default", "mixed", "dups", "tiny", "huge"])
+      E = synth.codebook_trained(K, D, seed=int(rng.integers(1 << 30)))
+      if kind == "default":
+          E = synth.codebook_default_init(K, D, seed=int(rng.integers(1 << 30)))
+      elif kind == "mixed":
+          E = E * np.exp2(rng.integers(-6, 6, size=(K, 1))).astype(np.float32)
+      elif kind == "dups":
+          idx = rng.integers(0, K, size=K // 2 + 1); E[idx] = E[(idx + 1) % K] * np.float32(1 + 2.0 ** -rng.integers(10, 24))
+      elif kind == "tiny":
+          E = E * np.float32(1e-12)
+      elif kind == "huge":
+          E = E * np.float32(3e9)
+      zscale = np.float32(np.exp2(rng.integers(-12, 12))) if rng.random() < 0.4 else np.float32(1.0)
+      z = synth.z_tokens(E, B, H, W, int(rng.integers(1 << 30))) * zscale
+      if rng.random() < 0.2:
+          zt = z.reshape(B, D, -1); j = rng.integers(0, K, size=zt.shape[2]); zt[0] = E[j].T   # exactly on codes
+      if rng.random() < 0.1:
+          z.reshape(-1)[rng.integers(0, z.size, size=3)] = [np.nan, np.inf, -np.inf]
+      mask = None if rng.random() < 0.5 else np.where(rng.random((B, 1, H, W)) < 0.5, 1.0, 0.25).astype(np.float32)
+      zt_, Et_ = torch.from_numpy(z).to(dev), torch.from_numpy(np.ascontiguousarray(E)).to(dev)
+      mt_ = None if mask is None else torch.from_numpy(mask).to(dev)
+      pe, pf = _CodebookPrep(), _CodebookPrep()
+      zq0, c0, l0 = vq_assign(zt_, Et_, pe, mt_, mode=_lib.MODE_EXACT)
+      zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=_lib.MODE_FILTER)
+      torch.cuda.synchronize()
+      okc = torch.equal(c0, c1)
+      okz = bool(((zq0 == zq1) | (torch.isnan(zq0) & torch.isnan(zq1))).all())
+      a, b = float(l0[1]), float(l1[1])
+      # the loss sums per-token fp32 terms; a rewritten token's provisional term is taken back in a different
+      # fp32 order, so the two modes agree to ~1e-7 of the typical squared error, not of the final sum
+      with np.errstate(all="ignore"):
+          scale = abs(a) + 1.25 * float(np.nanmean(np.square(np.where(np.isfinite(z), z, 0), dtype=np.float64))
+                                        + np.mean(np.square(E, dtype=np.float64)))
+      okl = (np.isnan(a) and np.isnan(b)) or a == b or abs(a - b) <= 1e-6 * scale
+      q = pf.fallback_count()
+      stats.append((q[0] + q[1]) / max(1, B * H * W))
+      if not (okc and okz and okl):
+          bad += 1
+          print("MISMATCH case", case, dict(D=D, K=K, B=B, H=H, W=W, kind=kind, zscale=float(zscale)), okc, okz, okl, a, b, q)
+  if verbose:
+    print("cases", len(stats), "mismatches", bad, "mean queued fraction %.3f max %.3f" % (np.mean(stats), np.max(stats)))
+  return bad, len(stats)
+
+
+if __name__ == "__main__":
+    bad, n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 150)
+    sys.exit(1 if bad else 0)
