@@ -50,6 +50,11 @@ int dvq_permute_max_cells(void);
 int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
                               float *cluster_size, float *vectors_sum, hipStream_t st);
 int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
+size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int groups, int Hid);
+int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
+                           int B, int C, int hc, int wc, int groups, float eps,
+                           const float *W1, const float *b1, const float *W2, const float *b2,
+                           int Hid, int act, float *gate, void *ws, hipStream_t st);
 
 static int hip_rc(int rc, const char *what)
 {
@@ -210,6 +215,53 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
     if (B <= 0 || D <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_ema_accumulate_nchw_f32: sizes must be positive"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_ema_accumulate(z, (const long long *)codes, D, HW, (long)B * HW, K, cluster_size, vectors_sum,
                                             (hipStream_t)stream), "ema_accumulate");
+}
+
+size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int num_groups, int hidden)
+{
+    if (num_branches < 2 || num_branches > 3 || B <= 0 || C <= 0 || num_groups < 0 || hidden < 0) return 0;
+    return dvq_router_gate_ws_bytes(num_branches, B, C, num_groups, hidden > 0 ? hidden : 32);
+}
+
+int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, const float *h_fine,
+                        int B, int C, int hc, int wc, int num_groups, float eps,
+                        const float *gn_w_coarse, const float *gn_b_coarse,
+                        const float *gn_w_median, const float *gn_b_median,
+                        const float *gn_w_fine, const float *gn_b_fine,
+                        const float *w1, const float *b1, const float *w2, const float *b2,
+                        int hidden, int activation, float *gate, void *ws, size_t ws_bytes, void *stream)
+{
+    const char *fn = "dvq_router_gate_f32";
+    if (nb != 2 && nb != 3) { dvq_set_error("%s: num_branches=%d (2 or 3)", fn, nb); return DVQ_EINVAL; }
+    if (!h_coarse || !h_fine || !w2 || !b2 || !gate) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if ((nb == 3) != (h_median != nullptr)) { dvq_set_error("%s: h_median must be given exactly when num_branches == 3", fn); return DVQ_EINVAL; }
+    if (B <= 0 || C <= 0 || hc <= 0 || wc <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    if (activation != DVQ_ACT_NONE && activation != DVQ_ACT_SILU && activation != DVQ_ACT_RELU) { dvq_set_error("%s: unknown activation %d", fn, activation); return DVQ_EINVAL; }
+    if (activation != DVQ_ACT_NONE && (!w1 || !b1 || hidden <= 0)) { dvq_set_error("%s: hidden layer requested without w1 / b1 / hidden", fn); return DVQ_EINVAL; }
+    if (num_groups < 0 || (num_groups > 0 && C % num_groups != 0)) { dvq_set_error("%s: C=%d is not divisible by num_groups=%d", fn, C, num_groups); return DVQ_EINVAL; }
+    if (num_groups > 0 && (!gn_w_coarse || !gn_b_coarse || !gn_w_fine || !gn_b_fine || (nb == 3 && (!gn_w_median || !gn_b_median)))) {
+        dvq_set_error("%s: GroupNorm affine parameters missing", fn); return DVQ_EINVAL;
+    }
+    if (C % 8 != 0 || nb * C > 1280) { dvq_set_error("%s: C=%d unsupported (C %% 8 == 0, num_branches*C <= 1280)", fn, C); return DVQ_EUNSUPPORTED; }
+    if (num_groups > 0 && ((size_t)(C / num_groups) * hc * wc) % 4 != 0) { dvq_set_error("%s: group size not a multiple of 4 floats", fn); return DVQ_EUNSUPPORTED; }
+    if (!ws || ws_bytes < dvq_router_gate_workspace_bytes(nb, B, C, num_groups, hidden)) {
+        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_router_gate_workspace_bytes(nb, B, C, num_groups, hidden));
+        return DVQ_EWORKSPACE;
+    }
+    if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    const float *h[3], *gw[3], *gb[3];
+    if (nb == 2) {
+        h[0] = h_coarse; h[1] = h_fine; h[2] = nullptr;
+        gw[0] = gn_w_coarse; gw[1] = gn_w_fine; gw[2] = nullptr;
+        gb[0] = gn_b_coarse; gb[1] = gn_b_fine; gb[2] = nullptr;
+    } else {
+        h[0] = h_coarse; h[1] = h_median; h[2] = h_fine;
+        gw[0] = gn_w_coarse; gw[1] = gn_w_median; gw[2] = gn_w_fine;
+        gb[0] = gn_b_coarse; gb[1] = gn_b_median; gb[2] = gn_b_fine;
+    }
+    return hip_rc(dvq_launch_router_gate(nb, h, gw, gb, B, C, hc, wc, num_groups, eps, w1, b1, w2, b2,
+                                         activation == DVQ_ACT_NONE ? 32 : hidden, activation, gate, ws,
+                                         (hipStream_t)stream), "router_gate");
 }
 
 int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream)

@@ -1,0 +1,312 @@
+// router_gate.hip -- fused feature-router gate for gfx950.
+//
+// Replaces the forward of the reference feature routers (inference; training keeps the autograd path):
+//   modules/dynamic_modules/RouterDual.py:35-43     GroupNorm x2, AvgPool2d(2) of the fine branch,
+//                                                   channel concat, NHWC, Linear [-> SiLU -> Linear]
+//   modules/dynamic_modules/RouterTriple.py:46-56   GroupNorm x3, AvgPool2d(4) fine / (2) median, concat,
+//                                                   Linear [-> SiLU | ReLU -> Linear]
+// which is 8-10 launches and ~5 passes over the branch features in the reference.  Here:
+//   1. gn_stats_kernel   one pass over every branch: (mean, rstd) per (image, group).
+//   2. w1_tile_kernel    hidden-layer weight -> 32-row MFMA tile images (same layout as the codebook
+//                        tiles of vq_assign_exact.hip).
+//   3. router_gate_kernel  one workgroup per 32 coarse cells: pools the raw features (the average of
+//                        normalised pixels is the normalised average), applies the GroupNorm affine,
+//                        keeps the [32 x F] feature tile in LDS, multiplies it with the hidden layer on
+//                        the fp32 matrix cores (v_mfma_f32_32x32x2_f32; fp32 because the logits decide
+//                        an argmax downstream), applies the activation and contracts with the output
+//                        layer in the MFMA epilogue.  The [cells x F] concat, its NHWC copy and the
+//                        hidden activations never reach HBM.
+// fp32 with a different summation order than ATen/MKL: tolerance parity (logits 1e-4), by design.
+#include "dvq_common.h"
+
+struct DvqGateArgs {
+    const float *h[3];        // branches, coarse -> fine
+    const float *gn_w[3];     // GroupNorm affine per branch (nullptr with groups == 0)
+    const float *gn_b[3];
+    int scale[3];             // fine pixels per coarse cell edge of the branch (1, 2[, 4])
+    int nb;                   // branches (2 dual, 3 triple)
+    int B, C, hc, wc;
+    int groups;               // 0 = no normalisation
+    float eps;
+};
+
+// ---- 1. GroupNorm statistics: stats[(br * B + b) * groups + g] = (mean, rstd)
+__global__ __launch_bounds__(256) void gn_stats_kernel(DvqGateArgs a, float2 *__restrict__ stats)
+{
+    const int br = blockIdx.y;
+    const int bg = blockIdx.x;                              // b * groups + g
+    const int sc = a.scale[br];
+    const size_t n = (size_t)(a.C / a.groups) * (a.hc * sc) * (a.wc * sc);   // contiguous in NCHW
+    const float *p = a.h[br] + (size_t)bg * n;
+    double s = 0.0, ss = 0.0;
+    const size_t n4 = n / 4;
+    for (size_t i = threadIdx.x; i < n4; i += 256) {
+        f32x4 v = *(const f32x4 *)(p + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s += v[j]; ss += (double)v[j] * v[j]; }
+    }
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) { s += p[i]; ss += (double)p[i] * p[i]; }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double mean = red[0][0] / (double)n;
+        double var = red[1][0] / (double)n - mean * mean;    // biased, as GroupNorm
+        if (var < 0.0) var = 0.0;
+        stats[(size_t)br * gridDim.x + bg] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.eps)));
+    }
+}
+
+// ---- 2. hidden-layer weight W1 [Hid, F] -> tile images: img[t][kg][c][p] = W1[32t + c][8kg + 2(p&3) + (p>>2)]
+__global__ __launch_bounds__(256) void w1_tile_kernel(const float *__restrict__ W1, int Hid, int F,
+                                                      float *__restrict__ tiles)
+{
+    const size_t per_tile = (size_t)32 * F;
+    const size_t total = (size_t)((Hid + 31) / 32) * per_tile;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i / per_tile);
+        const int r = (int)(i - (size_t)t * per_tile);
+        const int kg = r >> 8, c = (r >> 3) & 31, p = r & 7;
+        const int k = kg * 8 + 2 * (p & 3) + (p >> 2);
+        const int row = t * 32 + c;
+        tiles[i] = (row < Hid) ? W1[(size_t)row * F + k] : 0.0f;
+    }
+}
+
+// ---- 3. the gate
+// ACT: 0 = single Linear (no hidden layer), 1 = SiLU, 2 = ReLU.  G = logits per cell (2 / 3).
+template <int G>
+__global__ __launch_bounds__(256) void router_gate_kernel(
+    DvqGateArgs a, const float2 *__restrict__ stats, const float *__restrict__ w1_tiles,
+    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+    int Hid, int act, float *__restrict__ gate)
+{
+    extern __shared__ __attribute__((aligned(16))) float X[];      // [F/8][32 cells][8] (+ reduction scratch)
+    const int F = a.nb * a.C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const long ncell = (long)a.B * a.hc * a.wc;
+    const long cell0 = (long)blockIdx.x * 32;
+
+    // ---- feature tile: pooled + normalised, in MFMA B-operand order.  A thread keeps one cell
+    // (tid & 31) and walks channels (tid >> 5) + 8i, eight independent loads in flight.
+    {
+        const int cell = tid & 31;
+        const long cg = cell0 + cell;
+        const bool live = cg < ncell;
+        const long cgl = live ? cg : ncell - 1;
+        const int b = (int)(cgl / (a.hc * a.wc));
+        const int rem = (int)(cgl - (long)b * a.hc * a.wc);
+        const int y = rem / a.wc, x = rem - y * a.wc;
+        const int cpg = a.groups > 0 ? a.C / a.groups : 1;
+        for (int br = 0; br < a.nb; ++br) {
+            const int sc = a.scale[br];
+            const int Wb = a.wc * sc;
+            const size_t plane = (size_t)(a.hc * sc) * Wb;
+            const float *p0 = a.h[br] + (size_t)b * a.C * plane + (size_t)sc * y * Wb + sc * x;
+            const float2 *st = stats + ((size_t)br * a.B + b) * (a.groups > 0 ? a.groups : 1);
+            const float *gw = a.gn_w[br], *gb = a.gn_b[br];
+            auto pooled = [&](int ch) -> float {
+                const float *p = p0 + (size_t)ch * plane;
+                if (sc == 1) return p[0];
+                if (sc == 2) {
+                    f32x2 r0 = *(const f32x2 *)p, r1 = *(const f32x2 *)(p + Wb);
+                    return ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
+                }
+                float s4 = 0.0f;                        // sc == 4
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 r = *(const f32x4 *)(p + (size_t)i * Wb);
+                    s4 += (r[0] + r[1]) + (r[2] + r[3]);
+                }
+                return s4 * 0.0625f;
+            };
+            auto put = [&](int ch, float v) {
+                if (a.groups > 0) {
+                    const float2 ms = st[ch / cpg];
+                    v = (v - ms.x) * ms.y * gw[ch] + gb[ch];
+                }
+                const int k = br * a.C + ch;
+                const int pp = ((k & 7) >> 1) | ((k & 1) << 2);
+                X[((k >> 3) * 32 + cell) * 8 + pp] = live ? v : 0.0f;
+            };
+            int ch = tid >> 5;
+            for (; ch + 56 < a.C; ch += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = pooled(ch + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) put(ch + 8 * u, v[u]);
+            }
+            for (; ch < a.C; ch += 8) put(ch, pooled(ch));
+        }
+    }
+    __syncthreads();
+
+    float part[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) part[g] = 0.0f;
+    float *PB = X + 32 * F;                            // hidden bias + output-layer rows: [1 + G][Hid]
+    if (act != 0) {
+        for (int i = tid; i < Hid; i += 256) {
+            PB[i] = b1[i];
+#pragma unroll
+            for (int g = 0; g < G; ++g) PB[(1 + g) * Hid + i] = W2[(size_t)g * Hid + i];
+        }
+    }
+
+    if (act == 0) {
+        // single Linear: gate[cell][g] = W2[g][:] . x + b2[g]; 8 threads per cell split k
+        const int cell = tid >> 3, sub = tid & 7;
+        for (int k = sub; k < F; k += 8) {
+            const int pp = ((k & 7) >> 1) | ((k & 1) << 2);
+            const float xv = X[((k >> 3) * 32 + cell) * 8 + pp];
+#pragma unroll
+            for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(W2[(size_t)g * F + k], xv, part[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            part[g] += __shfl_xor(part[g], 1);
+            part[g] += __shfl_xor(part[g], 2);
+            part[g] += __shfl_xor(part[g], 4);
+        }
+        const long cg = cell0 + cell;
+        if (sub == 0 && cg < ncell) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) gate[cg * G + g] = part[g] + b2[g];
+        }
+        return;
+    }
+
+    __syncthreads();
+    // ---- hidden layer on the fp32 matrix cores: wave w takes hidden-row tiles w, w + 4, ...
+    const int T = (Hid + 31) / 32;
+    const float *xp = X + c * 8 + 4 * h;
+    for (int t = wave; t < T; t += 4) {
+        const float *ap = w1_tiles + (size_t)t * 32 * F + c * 8 + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int KG = F / 8;
+        int kg0 = 0;
+        f32x4 av[8];                                   // A fragments of the current 8-step group (from L2)
+        if (KG >= 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = *(const f32x4 *)(ap + u * 256);
+        }
+        for (; kg0 + 8 <= KG; kg0 += 8) {
+            f32x4 an[8], xv[8];
+            const bool more = kg0 + 16 <= KG;          // prefetch the next group under this one's MFMAs
+#pragma unroll
+            for (int u = 0; u < 8; ++u) an[u] = more ? *(const f32x4 *)(ap + (kg0 + 8 + u) * 256) : av[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *(const f32x4 *)(xp + (kg0 + u) * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], xv[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], xv[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][2], xv[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][3], xv[u][3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = an[u];
+        }
+        for (; kg0 < KG; ++kg0) {
+            const f32x4 a1 = *(const f32x4 *)(ap + kg0 * 256);
+            const f32x4 x1 = *(const f32x4 *)(xp + kg0 * 256);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], x1[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], x1[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], x1[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], x1[3], acc, 0, 0, 0);
+        }
+        // epilogue: bias, activation, contraction with the output layer (rows of this lane)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (j < Hid) {
+                const float yv = acc[r] + PB[j];
+                const float hv = (act == 1) ? yv / (1.0f + expf(-yv)) : (yv > 0.0f ? yv : 0.0f);
+#pragma unroll
+                for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(PB[(1 + g) * Hid + j], hv, part[g]);
+            }
+        }
+    }
+    __syncthreads();                                   // everyone is done reading X
+    float *red = X;                                    // [4 waves][G][32 cells]
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float v = part[g] + __shfl_xor(part[g], 32);
+        if (h == 0) red[(wave * G + g) * 32 + c] = v;
+    }
+    __syncthreads();
+    if (tid < 32 * G) {
+        const int cell = tid / G, g = tid - cell * G;
+        const long cg = cell0 + cell;
+        if (cg < ncell) {
+            float v = (red[(0 * G + g) * 32 + cell] + red[(1 * G + g) * 32 + cell]) +
+                      (red[(2 * G + g) * 32 + cell] + red[(3 * G + g) * 32 + cell]);
+            gate[cg * G + g] = v + b2[g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static size_t align256r(size_t x) { return (x + 255) / 256 * 256; }
+
+// ws: [stats nb*B*groups float2][W1 tile images ceil(Hid/32)*32*F floats]
+size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int groups, int Hid)
+{
+    const size_t F = (size_t)nb * C;
+    return align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)) +
+           align256r((size_t)((Hid + 31) / 32) * 32 * F * sizeof(float)) + 256;
+}
+
+int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
+                           int B, int C, int hc, int wc, int groups, float eps,
+                           const float *W1, const float *b1, const float *W2, const float *b2,
+                           int Hid, int act, float *gate, void *ws, hipStream_t st)
+{
+    DvqGateArgs a;
+    for (int i = 0; i < 3; ++i) {
+        a.h[i] = i < nb ? h[i] : nullptr;
+        a.gn_w[i] = (i < nb && groups > 0) ? gn_w[i] : nullptr;
+        a.gn_b[i] = (i < nb && groups > 0) ? gn_b[i] : nullptr;
+        a.scale[i] = 1 << i;
+    }
+    a.nb = nb; a.B = B; a.C = C; a.hc = hc; a.wc = wc; a.groups = groups; a.eps = eps;
+    const int F = nb * C;
+    float2 *stats = (float2 *)ws;
+    float *tiles = (float *)((char *)ws + align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)));
+    if (groups > 0)
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups, nb), dim3(256), 0, st, a, stats);
+    if (act != 0) {
+        size_t total = (size_t)((Hid + 31) / 32) * 32 * F;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(w1_tile_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, tiles);
+    }
+    const long ncell = (long)B * hc * wc;
+    const unsigned grid = (unsigned)((ncell + 31) / 32);
+    const size_t shmem = ((size_t)32 * F + (size_t)(1 + nb) * Hid) * sizeof(float);
+    if (nb == 2) {
+        static bool set2 = false;
+        if (!set2) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set2 = true; }
+        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(256), shmem, st, a, stats, tiles, b1, W2, b2, Hid, act, gate);
+    } else {
+        static bool set3 = false;
+        if (!set3) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set3 = true; }
+        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(256), shmem, st, a, stats, tiles, b1, W2, b2, Hid, act, gate);
+    }
+    return (int)hipGetLastError();
+}

@@ -9,8 +9,9 @@ Same constructor kwargs (including the reference's misspelt `fine_grain_ratito`)
 signatures, return structures and state_dict keys (`gate.*`, `feature_norm_{fine,median,coarse}.*`).
 
 The entropy gate and both selects are HIP kernels (one launch each).  The feature routers' gate
-MLP (GroupNorm -> AvgPool -> concat -> Linear/SiLU/Linear) is a small dense GEMM and stays on
-PyTorch-ROCm (MIOpen / hipBLASLt) -- SURVEY.md section 8 row a8/a9, fused version is row f4.
+(GroupNorm -> AvgPool -> concat -> Linear[/act/Linear]) runs as the fused `dvq_router_gate_f32`
+kernel whenever no gradient is needed; with autograd recording (router
+training) the same math runs as differentiable torch ops on the GPU.
 """
 import json
 
@@ -112,6 +113,53 @@ class DualGrainFixedEntropyRouter(nn.Module):
         return entropy_gate(entropy, self.fine_grain_threshold)
 
 
+_ACT_OF_GATE = {"1layer-fc": _lib.ACT_NONE, "2layer-fc-SiLu": _lib.ACT_SILU, "2layer-fc-ReLu": _lib.ACT_RELU}
+
+
+def _needs_autograd(module, *tensors):
+    if not torch.is_grad_enabled():
+        return False
+    return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
+
+
+def fused_router_gate(gate, gate_type, norms, branches):
+    """gate: the router's nn.Linear / nn.Sequential; norms / branches: coarse -> fine lists of the
+    GroupNorm (or Identity) modules and of the [B, C, rows, cols] feature maps.
+    -> logits [B, hc, wc, len(branches)] f32 from one fused kernel (RouterDual.py:35-43, RouterTriple.py:46-56)."""
+    nb = len(branches)
+    hs = [_lib.require_cuda_f32(h, "router input") for h in branches]
+    B, C, hc, wc = hs[0].shape
+    for i, h in enumerate(hs):
+        if tuple(h.shape) != (B, C, hc << i, wc << i):
+            raise ValueError("router branch %d has shape %s, expected %s" % (i, tuple(h.shape), (B, C, hc << i, wc << i)))
+    groups, eps, gw, gb = 0, 0.0, [None] * nb, [None] * nb
+    if isinstance(norms[0], nn.GroupNorm):
+        groups, eps = norms[0].num_groups, norms[0].eps
+        gw = [n.weight.detach().float().contiguous() for n in norms]
+        gb = [n.bias.detach().float().contiguous() for n in norms]
+    act = _ACT_OF_GATE[gate_type]
+    if act == _lib.ACT_NONE:
+        w1 = b1 = None
+        w2, b2, hidden = gate.weight, gate.bias, 0
+    else:
+        w1, b1, w2, b2 = gate[0].weight, gate[0].bias, gate[2].weight, gate[2].bias
+        hidden = w1.shape[0]
+    w1, b1, w2, b2 = [None if t is None else t.detach().float().contiguous() for t in (w1, b1, w2, b2)]
+    dev = hs[0].device
+    out = torch.empty((B, hc, wc, nb), dtype=torch.float32, device=dev)
+    ws_bytes = _lib_handle.dvq_router_gate_workspace_bytes(nb, B, C, groups, hidden)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    med = hs[1] if nb == 3 else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib_handle.dvq_router_gate_f32(
+            nb, hs[0].data_ptr(), ptr(med), hs[-1].data_ptr(), B, C, hc, wc, groups, float(eps),
+            ptr(gw[0]), ptr(gb[0]), ptr(gw[1]) if nb == 3 else None, ptr(gb[1]) if nb == 3 else None,
+            ptr(gw[-1]), ptr(gb[-1]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), hidden, act,
+            out.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "dvq_router_gate_f32")
+    return out
+
+
 def _make_gate(gate_type, width, splits, allow_relu):
     if gate_type == "1layer-fc":
         return nn.Linear(width, splits)
@@ -146,6 +194,9 @@ class DualGrainFeatureRouter(nn.Module):
         self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
 
     def forward(self, h_fine, h_coarse, entropy=None):
+        if h_fine.is_cuda and not _needs_autograd(self, h_fine, h_coarse):
+            return fused_router_gate(self.gate, self.gate_type, [self.feature_norm_coarse, self.feature_norm_fine],
+                                     [h_coarse, h_fine])
         h_fine = self.feature_norm_fine(h_fine)
         h_coarse = self.feature_norm_coarse(h_coarse)
         avg_h_fine = self.gate_pool(h_fine)
@@ -169,6 +220,10 @@ class TripleGrainFeatureRouter(nn.Module):
         self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
 
     def forward(self, h_fine, h_median, h_coarse, entropy=None):
+        if h_fine.is_cuda and not _needs_autograd(self, h_fine, h_median, h_coarse):
+            return fused_router_gate(self.gate, self.gate_type,
+                                     [self.feature_norm_coarse, self.feature_norm_median, self.feature_norm_fine],
+                                     [h_coarse, h_median, h_fine])
         h_fine = self.feature_norm_fine(h_fine)
         h_median = self.feature_norm_median(h_median)
         h_coarse = self.feature_norm_coarse(h_coarse)

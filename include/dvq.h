@@ -132,6 +132,33 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
                                 float *cluster_size, float *vectors_sum, void *stream);
 
 /*
+ * Fused feature-router gate (inference), the forward of DualGrainFeatureRouter
+ * (modules/dynamic_modules/RouterDual.py:35-43) and TripleGrainFeatureRouter
+ * (modules/dynamic_modules/RouterTriple.py:46-56): GroupNorm per branch, average pooling of the
+ * finer branches onto the coarse grid, channel concat (coarse, [median,] fine), then
+ *   activation == DVQ_ACT_NONE : gate = w2 x + b2                (gate_type "1layer-fc"; w1/b1 ignored,
+ *                                                                 w2 is [nb, nb*C], hidden ignored)
+ *   DVQ_ACT_SILU / DVQ_ACT_RELU: gate = w2 act(w1 x + b1) + b2   ("2layer-fc-SiLu" / "2layer-fc-ReLu";
+ *                                                                 w1 [hidden, nb*C], w2 [nb, hidden])
+ * num_branches nb = 2 (h_median must be NULL; h_fine is 2x the coarse grid) or 3 (median 2x, fine 4x).
+ * h_* are [B, C, rows, cols] f32 NCHW; num_groups == 0 means normalization_type "none" (gn_* ignored),
+ * otherwise gn_w_* / gn_b_* are the [C] affine parameters of each branch's GroupNorm(num_groups, C, eps).
+ * gate [B, hc, wc, nb] f32 logits.  C % 8 == 0, nb*C <= 1280.  fp32 throughout (fp32 matrix cores);
+ * summation order differs from ATen/MKL: logits equal the reference within 1e-4, not bit for bit.
+ */
+#define DVQ_ACT_NONE 0
+#define DVQ_ACT_SILU 1
+#define DVQ_ACT_RELU 2
+size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int num_groups, int hidden);
+int dvq_router_gate_f32(int num_branches, const float *h_coarse, const float *h_median, const float *h_fine,
+                        int B, int C, int hc, int wc, int num_groups, float eps,
+                        const float *gn_w_coarse, const float *gn_b_coarse,
+                        const float *gn_w_median, const float *gn_b_median,
+                        const float *gn_w_fine, const float *gn_b_fine,
+                        const float *w1, const float *b1, const float *w2, const float *b2,
+                        int hidden, int activation, float *gate, void *ws, size_t ws_bytes, void *stream);
+
+/*
  * Patch-entropy map, Entropy.forward (models/stage1_dynamic/dqvae_dual_entropy.py:13-63) with
  * patch_size 16: images [B, 3, H, W] f32 (H, W multiples of 16) -> out [B, H/16, W/16] f32.
  * Transcendental fp32 math: equal to the reference within 1e-5, not bit for bit.

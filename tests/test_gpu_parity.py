@@ -248,8 +248,9 @@ def test_route_select_shapes_vs_oracle(dev, oracle_mod, shape):
 
 @pytest.mark.parametrize("which", ["dual", "triple"])
 def test_feature_router_logits(dev, which):
-    """feature routers run on PyTorch-ROCm (GroupNorm, exp, k=512/768 GEMM: not bit-reproducible):
-    logits within 1e-4, grain indices equal wherever the reference margin exceeds 1e-3"""
+    """feature routers (fused dvq_router_gate_f32 kernel under no_grad; GroupNorm, exp, k=512/768 GEMM are
+    not bit-reproducible): logits within 1e-4 of the reference capture, grain indices equal wherever the
+    reference margin exceeds 1e-3"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
     g = C.load("feature_router_" + which)
@@ -273,6 +274,41 @@ def test_feature_router_logits(dev, which):
     srt = np.sort(ref, axis=-1)
     clear = (srt[..., -1] - srt[..., -2]) > 1e-3
     assert np.array_equal(got.argmax(-1)[clear], ref.argmax(-1)[clear])
+
+
+@pytest.mark.parametrize("which,norm,gate_type,B,hc,wc", [
+    ("dual", "group-32", "2layer-fc-SiLu", 3, 5, 6),       # ragged: 90 cells, last workgroup partly empty
+    ("dual", "none", "1layer-fc", 2, 16, 16),
+    ("dual", "group-8", "1layer-fc", 1, 4, 4),
+    ("triple", "group-32", "2layer-fc-ReLu", 2, 8, 8),
+    ("triple", "none", "2layer-fc-SiLu", 1, 3, 2),
+    ("triple", "group-16", "1layer-fc", 5, 8, 8),
+])
+def test_fused_router_gate_matches_torch_ops(dev, which, norm, gate_type, B, hc, wc):
+    """the fused kernel (no_grad) against the same module evaluated with differentiable torch ops
+    (grad enabled), every gate / normalisation type the reference accepts"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    Cc = 64
+    torch.manual_seed(11)
+    r = (DualGrainFeatureRouter if which == "dual" else TripleGrainFeatureRouter)(Cc, norm, gate_type).to(dev)
+    with torch.no_grad():
+        for n_, p_ in r.named_parameters():                # non-trivial GroupNorm affine
+            if "feature_norm" in n_:
+                p_.copy_(torch.randn_like(p_) * 0.5 + (1.0 if n_.endswith("weight") else 0.0))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    nbr = 2 if which == "dual" else 3
+    feats = [t(synth.features(700 + i, B, Cc, hc << i, wc << i) * np.float32(1.5) + np.float32(0.3)) for i in range(nbr)]
+    kw = dict(h_coarse=feats[0], h_fine=feats[-1])
+    if nbr == 3:
+        kw["h_median"] = feats[1]
+    with torch.no_grad():
+        fused = r(**kw)
+    ref = r(**kw)                                          # parameters require grad -> torch-op path
+    assert ref.requires_grad and not fused.requires_grad
+    assert fused.shape == ref.shape == (B, hc, wc, nbr)
+    err = float((fused - ref.detach()).abs().max())
+    assert err < 1e-4 * max(1.0, float(ref.detach().abs().max())), err
 
 
 def test_encode_dual_end_to_end(dev, oracle_mod, golden_dir):

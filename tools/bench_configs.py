@@ -33,13 +33,16 @@ r = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
 hf, hc = t(synth.z_tokens(E, 64, 32, 32, 2102)), t(synth.z_tokens(E, 64, 16, 16, 2112))
 with torch.no_grad():
     out["cfg2_dual_feature_B64_ms"] = timeit(lambda: encode_dual(r, vq, hf, hc))
-    out["cfg2_router_mlp_only_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc))
+    out["cfg2_router_gate_fused_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc))
+out["cfg2_router_gate_torch_ops_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc).detach())   # grad enabled -> torch ops
 # configs[3] per-rank share: triple F32/16/8, B=128 per GPU
 r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
 hf, hm, hc = (t(synth.z_tokens(E, 128, 32, 32, 2104)), t(synth.z_tokens(E, 128, 16, 16, 2114)),
               t(synth.z_tokens(E, 128, 8, 8, 2124)))
 with torch.no_grad():
     out["cfg4_triple_B128_per_gpu_ms"] = timeit(lambda: encode_triple(r3, vq, hf, hm, hc))
+    out["cfg4_router_gate_fused_ms"] = timeit(lambda: r3(h_fine=hf, h_median=hm, h_coarse=hc))
+out["cfg4_router_gate_torch_ops_ms"] = timeit(lambda: r3(h_fine=hf, h_median=hm, h_coarse=hc).detach())
 # configs[4]: large-codebook stress K=16384, B=512 (exact fp32-MFMA path vs fp16 filter path)
 E16 = synth.codebook_trained(16384, 256)
 Et = t(E16)
