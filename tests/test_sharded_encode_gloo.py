@@ -36,6 +36,13 @@ def _worker(rank, world, port, B, q):
         codes = torch.from_numpy(o["codes"].reshape(e - s, 8, 8))
         grain = torch.from_numpy(gate.argmax(-1))
         g_codes, g_grain, mean = all_gather_codes(codes, grain, torch.tensor(o["sqerr"]), o["numel"], K, B)
+        # two exchanges in flight (the pipelined form bench.py uses), waited in order
+        h1 = all_gather_codes(codes, grain, torch.tensor(o["sqerr"]), o["numel"], K, B, async_op=True)
+        h2 = all_gather_codes(codes + 1, None, torch.tensor(2.0 * o["sqerr"]), o["numel"], K, B, async_op=True)
+        a_codes, a_grain, a_mean = h1.wait()
+        b_codes, b_grain, b_mean = h2.wait()
+        assert torch.equal(a_codes, g_codes) and torch.equal(a_grain, g_grain) and float(a_mean) == float(mean)
+        assert torch.equal(b_codes, g_codes + 1) and b_grain is None and abs(float(b_mean) - 2 * float(mean)) < 1e-6 * float(mean)
         q.put((rank, g_codes.numpy(), g_grain.numpy(), float(mean)))
     finally:
         dist.destroy_process_group()
