@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ / TCP / TCC counter passes for the dominant kernel (separate --pmc runs, kernel-trace only).
+# SQ counter passes for the dominant kernel (separate --pmc runs, kernel-trace only).
+# (A pass with TCP_* / TA_* counters aborted rocprofv3 on this pool and hung until the time limit: SQ only.)
 # usage (on the GPU box): bash tools/pmc_sq.sh <outdir>
 OUT=${1:-gpurun_out/pmc_sq}
 mkdir -p $OUT
@@ -13,13 +14,6 @@ done <<'LIST'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_MISC
 SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL
-TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum
-TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_BUSY_avr TCC_TAG_STALL_sum
-SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_WAVES SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA
 LIST
 cd $GRAFT_REPO_ROOT
-python3 - <<'PY'
-import csv, glob, collections, os, sys
-out = os.environ.get("OUTDIR", sys.argv[1] if len(sys.argv) > 1 else "")
-PY
 python3 tools/pmc_sq_parse.py $OUT
