@@ -30,6 +30,19 @@
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
 #include "dvq_common.h"
 
+// z is read once and z_q written once per launch: stream them past L2 (nt) so that the codebook
+// image and the fp32 codebook rows keep their lines
+#ifndef DVQ_NT
+#define DVQ_NT 1
+#endif
+#if DVQ_NT
+#define DVQ_LOAD_Z(p) __builtin_nontemporal_load(p)
+#define DVQ_STORE_ZQ(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DVQ_LOAD_Z(p) (*(p))
+#define DVQ_STORE_ZQ(p, v) (*(p) = (v))
+#endif
+
 struct DvqF16Meta {
     int ok;         // 1: codebook finite and representable; 0: every token goes to the exact list
     int b_exp;      // eh = fp16(2^b e),  2^b max|e| in [2^14, 2^15)
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
         for (int s = 0; s < S16; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = zp[(size_t)(16 * s + j) * HW];
+            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
     }
     f16x8 zh[S16];
     float xn, thr2W;
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                     for (int j = 0; j < 8; ++j) {
                         float e = eg[q][j >> 2][j & 3];
                         float diff = __fsub_rn(e, zf[s][j]);
-                        if (zqp != nullptr) zqp[(size_t)(16 * s + j) * HW] = __fadd_rn(zf[s][j], diff);
+                        if (zqp != nullptr) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[s][j], diff));
                         lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
                     }
                 }

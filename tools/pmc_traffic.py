@@ -3,7 +3,7 @@ into profiles/pmc_traffic.json: HBM bytes per launch of the filter kernel, with 
 correction calibrated on the exact kernel's known z read (same 4-B-per-lane access pattern)."""
 import csv, glob, json, sys, collections
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
