@@ -51,13 +51,24 @@ __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__rest
     }
 }
 
+__global__ __launch_bounds__(256) void ema_zero_kernel(float *__restrict__ a, size_t na, float *__restrict__ b, size_t nb)
+{
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = i0; i < na; i += stride) a[i] = 0.0f;
+    for (size_t i = i0; i < nb; i += stride) b[i] = 0.0f;
+}
+
 int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
                               float *cluster_size, float *vectors_sum, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(cluster_size, 0, (size_t)K * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(vectors_sum, 0, (size_t)K * D * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    // zeroed by a kernel, not hipMemsetAsync: memset nodes misbehave under hipGraph replay on ROCm 7.2
+    {
+        size_t n = (size_t)K * D;
+        int blocks = (int)((n / 4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(ema_zero_kernel, dim3(blocks), dim3(256), 0, st, cluster_size, (size_t)K, vectors_sum, n);
+    }
     hipLaunchKernelGGL(ema_accumulate_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, z, codes, D, HW, N, K,
                        cluster_size, vectors_sum);
     return (int)hipGetLastError();

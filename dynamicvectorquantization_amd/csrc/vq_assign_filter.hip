@@ -627,6 +627,11 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     }
 }
 
+__global__ void zero_counters_kernel(int *__restrict__ counters)
+{
+    if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -718,8 +723,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     int *exact_list = (int *)((char *)ws_extra + 256);
     char *records = (char *)ws_extra + 256 + align256((size_t)N * sizeof(int));
     const int cap = rec_capacity(N);
-    hipError_t e = hipMemsetAsync(counters, 0, 32, st);     // [0] queue, [1] exact list, [4] finalize ticket
-    if (e != hipSuccess) return (int)e;
+    // [0] queue, [1] exact list, [4] finalize ticket.  A kernel rather than hipMemsetAsync: cheaper than
+    // the runtime's fill kernel, and the op stays a pure chain of kernel nodes under hipGraph capture.
+    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, st, counters);
     int rc;
     switch (D) {
     case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;

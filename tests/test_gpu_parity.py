@@ -415,3 +415,47 @@ def test_filter_mode_matches_exact_mode_on_random_sweep():
     spec.loader.exec_module(fuzz)
     bad, n = fuzz.run(80, seed=777, verbose=False)
     assert n == 80 and bad == 0
+
+
+def test_hot_path_is_graph_capturable(dev):
+    """gate + select + VQ assign captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed on new
+    inputs: same bits as the eager launches (the ABI never allocates or synchronises)"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    from dynamicvectorquantization_amd.router import entropy_gate, route_select_dual
+    B, K, D = 4, 1024, 256
+    E = torch.from_numpy(synth.codebook_trained(K, D)).to(dev)
+    En = E.cpu().numpy()
+    mk = lambda seed: (torch.from_numpy(synth.z_tokens(En, B, 32, 32, seed)).to(dev),
+                       torch.from_numpy(synth.z_tokens(En, B, 16, 16, seed + 1)).to(dev),
+                       torch.from_numpy(synth.entropy_map(seed + 2, B, 16, 16)).to(dev))
+    hf, hc, ent = mk(9100)
+    prep = _CodebookPrep()
+    h_dual = torch.empty_like(hf); grain = torch.empty((B, 16, 16), dtype=torch.int64, device=dev)
+    cmask = torch.empty((B, 1, 32, 32), device=dev); zq = torch.empty_like(hf)
+    codes = torch.empty((B, 32, 32), dtype=torch.int64, device=dev); loss = torch.empty(2, device=dev)
+    gate = torch.empty((B, 16, 16, 2), dtype=torch.int64, device=dev)
+
+    def step():
+        gate.copy_(entropy_gate(ent, 1.6777750253677368))
+        route_select_dual(gate, hc, hf, out=(h_dual, grain, cmask))
+        vq_assign(h_dual, E, prep, cmask, beta=0.25, out=(zq, codes, loss))
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()                                   # warm-up: prep, workspace, kernel attributes
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    hf2, hc2, ent2 = mk(9200)
+    hf.copy_(hf2); hc.copy_(hc2); ent.copy_(ent2)
+    g.replay()
+    torch.cuda.synchronize()
+    got = (zq.clone(), codes.clone(), loss.clone(), grain.clone())
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(got[1], codes) and torch.equal(got[0], zq) and torch.equal(got[3], grain)
+    assert torch.equal(got[2], loss)
