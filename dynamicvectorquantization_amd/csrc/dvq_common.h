@@ -93,7 +93,7 @@ struct DvqLossTail {
     double inv_numel;
     float beta;
 };
-#define DVQ_EXACT_LIST_BLOCKS 256   // grid of the list-mode exact kernel (it walks the list in chunks)
+#define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
 // per-launch host-side error plumbing (dvq_abi.hip)
 void dvq_set_error(const char *fmt, ...);

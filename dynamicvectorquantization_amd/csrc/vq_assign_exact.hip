@@ -21,7 +21,7 @@
 // Compute-bound on the fp32 MFMA rate (2*K*D flop per token).
 #include "dvq_common.h"
 
-template <int D>
+template <int D, bool LIST>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
     const float *__restrict__ mask, int HW, int K, long N,
@@ -39,14 +39,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const int c = lane & 31, h = lane >> 5;
     // tokens: the dense range [0, N) (one 128-token chunk per block), or (pass 2 of the filter path)
     // the entries of a work list, which a small grid walks in 128-entry chunks
-    const int cnt = (list != nullptr) ? *list_count : 0;
+    const int cnt = LIST ? *list_count : 0;
     double block_sum = 0.0;
-    for (long chunk = blockIdx.x; list == nullptr ? chunk == (long)blockIdx.x : chunk * 128 < cnt;
-         chunk += gridDim.x) {
+    long chunk = blockIdx.x;
+    for (int it = 0; LIST ? chunk * 128 < cnt : it < 1; ++it, chunk += gridDim.x) {   // dense: exactly once
     long n = (chunk * 4 + wave) * 32 + c;
     bool valid = n < N;
     long nn = valid ? n : N - 1;
-    if (list != nullptr) {
+    if (LIST) {
         valid = n < cnt;
         n = list[valid ? n : 0];
         nn = n;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     };
 
     const int T = dvq_num_tiles(K);
-    __syncthreads();                          // (list mode, next chunk) everyone is done with the buffers
+    if (LIST) __syncthreads();                // (next chunk) everyone is done with the buffers
     stage(0, lds);
 
     // ---- xn: ATen-order sum of squares of this token (both lanes of a token get the same value)
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-    if (tail.loss != nullptr) {
+    if (LIST && tail.loss != nullptr) {
         // fused loss finalize: the block that takes the last ticket sums every partial of the op
         // (fixed order -> the result does not depend on which block that is)
         int *flag = (int *)lds + 16;
@@ -302,14 +302,21 @@ static int launch_exact(const float *z, const float *tiles, const float *E, cons
     static bool attr_set = false;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D>,
+        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
     int blocks = (int)((N + 127) / 128);
-    if (list != nullptr && blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
-    hipLaunchKernelGGL(vq_assign_exact_kernel<D>, dim3(blocks), dim3(256), shmem, st,
-                       z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
+    if (list != nullptr) {
+        if (blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
+        hipLaunchKernelGGL((vq_assign_exact_kernel<D, true>), dim3(blocks), dim3(256), shmem, st,
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
+    } else {
+        hipLaunchKernelGGL((vq_assign_exact_kernel<D, false>), dim3(blocks), dim3(256), shmem, st,
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
+    }
     return (int)hipGetLastError();
 }
 
