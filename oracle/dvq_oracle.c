@@ -36,6 +36,9 @@
  * written with fmaf()).
  */
 #include <math.h>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -118,10 +121,13 @@ int dvq_oracle_vq_assign_nchw(const float *z, const float *E, const float *mask,
                               float *zq, int64_t *codes, double *sqerr,
                               float *dmin)
 {
-    enum { JB = 64 };
+    /* Register tile: TB tokens x JB codes advance together through k.  Every (token, code) output
+     * is still its own strictly sequential k = 0..D-1 fmaf chain (vfmadd231ps is the same fused
+     * operation per lane), so the tiling changes speed only, never a bit of the result. */
+    enum { JB = 32, TB = 4, DMAX = 1024 };
+    if (D > DMAX) return -3;
     float *en = (float *)malloc(sizeof(float) * (size_t)K);
-    /* transposed copy ET[k][j] so JB independent chains advance together; each
-     * chain is still the strictly sequential k = 0..D-1 fmaf chain. */
+    /* transposed copy ET[k][j] so JB independent chains advance together */
     float *ET = (float *)malloc(sizeof(float) * (size_t)K * (size_t)D);
     if (!en || !ET) { free(en); free(ET); return -1; }
     dvq_oracle_codebook_norms(E, K, D, en);
@@ -129,54 +135,89 @@ int dvq_oracle_vq_assign_nchw(const float *z, const float *E, const float *mask,
         for (int k = 0; k < D; ++k) ET[(long)k * K + j] = E[(long)j * D + k];
     long N = (long)B * HW;
     double total = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : total)
-    for (long n = 0; n < N; ++n) {
-        long b = n / HW, hw = n % HW;
-        const float *zt = z + b * (long)D * HW + hw;
-        float xn = dvq_oracle_sumsq(zt, D, HW);
-        float zl[1024];
-        float *zc = zl;
-        if (D > 1024) zc = (float *)malloc(sizeof(float) * (size_t)D);
-        for (int k = 0; k < D; ++k) zc[k] = zt[(long)k * HW];
-        float best = 0.0f;
-        long bi = -1;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total)
+    for (long n0 = 0; n0 < N; n0 += TB) {
+        int tn = (N - n0 < TB) ? (int)(N - n0) : TB;
+        float zc[TB][DMAX];
+        float xn[TB], best[TB];
+        long bi[TB];
+        for (int t = 0; t < TB; ++t) {
+            long n = n0 + (t < tn ? t : tn - 1);          /* ragged tail: repeat the last token */
+            long b = n / HW, hw = n % HW;
+            const float *zt = z + b * (long)D * HW + hw;
+            xn[t] = dvq_oracle_sumsq(zt, D, HW);
+            for (int k = 0; k < D; ++k) zc[t][k] = zt[(long)k * HW];
+            best[t] = 0.0f;
+            bi[t] = -1;
+        }
         for (int j0 = 0; j0 < K; j0 += JB) {
             int jn = K - j0 < JB ? K - j0 : JB;
-            float acc[JB];
-            for (int j = 0; j < JB; ++j) acc[j] = 0.0f;
+            float acc[TB][JB];
             if (jn == JB) {
-                for (int k = 0; k < D; ++k) {
-                    const float *__restrict et = ET + (long)k * K + j0;
-                    float zk = zc[k];
-                    for (int j = 0; j < JB; ++j) acc[j] = fmaf(zk, et[j], acc[j]);
-                }
-            } else {
+#if defined(__AVX2__) && defined(__FMA__)
+                __m256 a[TB][JB / 8];
+                for (int t = 0; t < TB; ++t)
+                    for (int v = 0; v < JB / 8; ++v) a[t][v] = _mm256_setzero_ps();
                 for (int k = 0; k < D; ++k) {
                     const float *et = ET + (long)k * K + j0;
-                    float zk = zc[k];
-                    for (int j = 0; j < jn; ++j) acc[j] = fmaf(zk, et[j], acc[j]);
+                    __m256 e0 = _mm256_loadu_ps(et), e1 = _mm256_loadu_ps(et + 8);
+                    __m256 e2 = _mm256_loadu_ps(et + 16), e3 = _mm256_loadu_ps(et + 24);
+                    for (int t = 0; t < TB; ++t) {
+                        __m256 zk = _mm256_set1_ps(zc[t][k]);
+                        a[t][0] = _mm256_fmadd_ps(zk, e0, a[t][0]);
+                        a[t][1] = _mm256_fmadd_ps(zk, e1, a[t][1]);
+                        a[t][2] = _mm256_fmadd_ps(zk, e2, a[t][2]);
+                        a[t][3] = _mm256_fmadd_ps(zk, e3, a[t][3]);
+                    }
+                }
+                for (int t = 0; t < TB; ++t)
+                    for (int v = 0; v < JB / 8; ++v) _mm256_storeu_ps(&acc[t][8 * v], a[t][v]);
+#else
+                for (int t = 0; t < TB; ++t)
+                    for (int j = 0; j < JB; ++j) acc[t][j] = 0.0f;
+                for (int k = 0; k < D; ++k) {
+                    const float *__restrict et = ET + (long)k * K + j0;
+                    for (int t = 0; t < TB; ++t) {
+                        float zk = zc[t][k];
+                        for (int j = 0; j < JB; ++j) acc[t][j] = fmaf(zk, et[j], acc[t][j]);
+                    }
+                }
+#endif
+            } else {
+                for (int t = 0; t < TB; ++t)
+                    for (int j = 0; j < JB; ++j) acc[t][j] = 0.0f;
+                for (int k = 0; k < D; ++k) {
+                    const float *et = ET + (long)k * K + j0;
+                    for (int t = 0; t < TB; ++t) {
+                        float zk = zc[t][k];
+                        for (int j = 0; j < jn; ++j) acc[t][j] = fmaf(zk, et[j], acc[t][j]);
+                    }
                 }
             }
-            for (int j = 0; j < jn; ++j) {
-                float bias = xn + en[j0 + j];
-                float d = bias - 2.0f * acc[j];   /* 2*dot exact; one rounding */
-                if (bi < 0 || take_min(d, best)) { best = d; bi = j0 + j; }
+            for (int t = 0; t < tn; ++t)
+                for (int j = 0; j < jn; ++j) {
+                    float bias = xn[t] + en[j0 + j];
+                    float d = bias - 2.0f * acc[t][j];   /* 2*dot exact; one rounding */
+                    if (bi[t] < 0 || take_min(d, best[t])) { best[t] = d; bi[t] = j0 + j; }
+                }
+        }
+        for (int t = 0; t < tn; ++t) {
+            long n = n0 + t;
+            long b = n / HW, hw = n % HW;
+            codes[n] = bi[t];
+            if (dmin) dmin[n] = best[t];
+            const float *e = E + bi[t] * (long)D;
+            float m = mask ? mask[n] : 1.0f;
+            double accd = 0.0;
+            for (int k = 0; k < D; ++k) {
+                float diff = e[k] - zc[t][k];
+                if (zq) zq[b * (long)D * HW + (long)k * HW + hw] = zc[t][k] + diff;
+                float sq = diff * diff;
+                float w = sq * m;
+                accd += (double)w;
             }
+            total += accd;
         }
-        codes[n] = bi;
-        if (dmin) dmin[n] = best;
-        const float *e = E + bi * (long)D;
-        float m = mask ? mask[n] : 1.0f;
-        double accd = 0.0;
-        for (int k = 0; k < D; ++k) {
-            float diff = e[k] - zc[k];
-            if (zq) zq[b * (long)D * HW + (long)k * HW + hw] = zc[k] + diff;
-            float sq = diff * diff;
-            float w = sq * m;
-            accd += (double)w;
-        }
-        total += accd;
-        if (zc != zl) free(zc);
     }
     if (sqerr) *sqerr = total;
     free(en);

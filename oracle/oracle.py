@@ -87,7 +87,7 @@ def token_distances(z_token, E):
     return d
 
 
-def vq_assign_nchw(z, E, mask=None, want_zq=True, want_dmin=False):
+def vq_assign_nchw(z, E, mask=None, want_zq=True, want_dmin=False, out=None):
     """VectorQuantize2 / VectorQuantizer2 forward core on z [B, D, H, W] (or [B, D, HW]).
 
     Returns dict(codes [B, HW] i64, zq [B, D, ...] f32 or None,
@@ -102,8 +102,12 @@ def vq_assign_nchw(z, E, mask=None, want_zq=True, want_dmin=False):
     pm = None
     if mask is not None:
         mask, pm = _f32(np.asarray(mask).reshape(B, HW))
-    zq = np.empty_like(z) if want_zq else None
-    codes = np.empty((B, HW), np.int64)
+    if out is not None:                       # (zq, codes) to reuse: fresh 100-MB arrays page-fault every call
+        zq, codes = out
+        assert zq.shape == z.shape and zq.dtype == np.float32 and codes.shape == (B, HW) and codes.dtype == np.int64
+    else:
+        zq = np.empty_like(z) if want_zq else None
+        codes = np.empty((B, HW), np.int64)
     dmin = np.empty((B, HW), np.float32) if want_dmin else None
     sq = ctypes.c_double(0.0)
     rc = lib().dvq_oracle_vq_assign_nchw(
@@ -156,16 +160,20 @@ def _gate_ptr(gate):
     return g, g.ctypes.data_as(ctypes.c_void_p), 0
 
 
-def route_select_dual(gate, h_coarse, h_fine):
-    """EncoderDual.py:134-149.  gate [B, hc, wc, 2] (f32 logits or int64)."""
+def route_select_dual(gate, h_coarse, h_fine, out=None):
+    """EncoderDual.py:134-149.  gate [B, hc, wc, 2] (f32 logits or int64).  out = (h_dual, indices, mask) to reuse."""
     gate, pg, is_i64 = _gate_ptr(np.asarray(gate))
     hcz, pc = _f32(h_coarse)
     hf, pf = _f32(h_fine)
     B, C, hc, wc = hcz.shape
     assert hf.shape == (B, C, 2 * hc, 2 * wc) and gate.shape == (B, hc, wc, 2)
-    out = np.empty_like(hf)
-    ind = np.empty((B, hc, wc), np.int64)
-    cm = np.empty((B, 1, 2 * hc, 2 * wc), np.float32)
+    if out is not None:
+        out, ind, cm = out
+        assert out.shape == hf.shape and ind.shape == (B, hc, wc) and cm.shape == (B, 1, 2 * hc, 2 * wc)
+    else:
+        out = np.empty_like(hf)
+        ind = np.empty((B, hc, wc), np.int64)
+        cm = np.empty((B, 1, 2 * hc, 2 * wc), np.float32)
     lib().dvq_oracle_route_select_dual(pg, ctypes.c_int(is_i64), pc, pf, ctypes.c_int(B),
                                        ctypes.c_int(C), ctypes.c_int(hc), ctypes.c_int(wc),
                                        out.ctypes.data_as(_f32p), ind.ctypes.data_as(_i64p),
