@@ -20,6 +20,7 @@
 // prepared 32-code LDS tile images (double-buffered global->LDS DMA, one barrier per tile).
 // Compute-bound on the fp32 MFMA rate (2*K*D flop per token).
 #include "dvq_common.h"
+#include <type_traits>
 
 template <int D, bool LIST>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
@@ -153,18 +154,24 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
 
     // ---- z_q = z + (e - z), loss partial sum((e - z)^2 * m)
     float lsum = 0.0f;
-    if (zq != nullptr || partials != nullptr) {
+    if ((zq != nullptr || partials != nullptr) && valid) {
         const float *ep = E + (size_t)code * D + h;
         const float m = (mask != nullptr) ? mask[nn] : 1.0f;
-        float *zqp = zq ? zq + zbase : nullptr;
+        // the zq test is a scalar branch on the kernel argument, taken once (inside the loop, on the
+        // per-lane pointer, it turned every store into its own exec-masked branch)
+        auto finish = [&](auto store_tag) {
+            constexpr bool STORE = decltype(store_tag)::value;
+            float *zqp = STORE ? zq + zbase : nullptr;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {          // fully unrolled: zr[] must stay in registers
-            float e = ep[2 * s];
-            float diff = __fsub_rn(e, zr[s]);
-            if (zqp != nullptr && valid) zqp[(size_t)2 * s * HW] = __fadd_rn(zr[s], diff);
-            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-        }
-        if (!valid) lsum = 0.0f;
+            for (int s = 0; s < S; ++s) {          // fully unrolled: zr[] must stay in registers
+                float e = ep[2 * s];
+                float diff = __fsub_rn(e, zr[s]);
+                if (STORE) zqp[(size_t)2 * s * HW] = __fadd_rn(zr[s], diff);
+                lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+            }
+        };
+        if (zq != nullptr) finish(std::true_type{});
+        else finish(std::false_type{});
     }
     block_sum += (double)lsum;
     }   // chunk loop

@@ -29,6 +29,7 @@
 //                                 <= 2^(a+b) [u(1+u)(xn+en) + (u + gamma_D)(1+gamma_D) ||z|| ||e_j||]
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
 #include "dvq_common.h"
+#include <type_traits>
 
 // z is read once and z_q written once per launch: stream them past L2 (nt) so that the codebook
 // image and the fp32 codebook rows keep their lines
@@ -423,29 +424,37 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if (h == 0) codes[n] = (long long)code;
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
-            float *zqp = zq ? zq + token_base() : nullptr;
             const float m = (mask != nullptr) ? mask[n] : 1.0f;
             constexpr int SB = (S16 < 4) ? S16 : 4;
+            // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
+            // inside the loop on the per-lane pointer every one of the 128 stores became its own
+            // exec-masked branch to an out-of-line block.
+            auto finish = [&](auto store_tag) {
+                constexpr bool STORE = decltype(store_tag)::value;
+                float *zqp = STORE ? zq + token_base() : nullptr;
 #pragma unroll
-            for (int s0 = 0; s0 < S16; s0 += SB) {
-                f32x4 eg[SB][2];
+                for (int s0 = 0; s0 < S16; s0 += SB) {
+                    f32x4 eg[SB][2];
 #pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
-                    eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
-                }
+                    for (int q = 0; q < SB; ++q) {
+                        eg[q][0] = *(const f32x4 *)(ep + 16 * (s0 + q));
+                        eg[q][1] = *(const f32x4 *)(ep + 16 * (s0 + q) + 4);
+                    }
 #pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    const int s = s0 + q;
+                    for (int q = 0; q < SB; ++q) {
+                        const int s = s0 + q;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float e = eg[q][j >> 2][j & 3];
-                        float diff = __fsub_rn(e, zf[s][j]);
-                        if (zqp != nullptr) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[s][j], diff));
-                        lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                        for (int j = 0; j < 8; ++j) {
+                            float e = eg[q][j >> 2][j & 3];
+                            float diff = __fsub_rn(e, zf[s][j]);
+                            if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[s][j], diff));
+                            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                        }
                     }
                 }
-            }
+            };
+            if (zq != nullptr) finish(std::true_type{});
+            else finish(std::false_type{});
         }
     }
     if (partials != nullptr) {
