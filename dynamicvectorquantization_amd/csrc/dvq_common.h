@@ -86,13 +86,18 @@ __device__ __forceinline__ void argmin_merge(float &d, int &i, float d2, int i2)
 // Loss finalize fused into the last kernel of the filter path (vq_assign_exact_kernel in list
 // mode): the block that draws the last ticket sums partials[0 .. nparts) and writes loss[0..1].
 struct DvqLossTail {
-    float *loss;              // nullptr = no fused finalize
+    float *loss;              // nullptr = no fused loss finalize
     const double *partials;
-    int *ticket;              // zeroed by the op's counter memset
+    int *ticket;              // zeroed at the start of the op
     int nparts;
     double inv_numel;
     float beta;
+    int *counters;            // nullptr = no queue bookkeeping; else counters[0] = total queued tokens
+    int shard_cap;
 };
+#define DVQ_QSHARDS 64        // the pass-1 -> resolver queue is sharded this many ways (power of two)
+#define DVQ_QCOUNT0 8         // counters[DVQ_QCOUNT0 + shard] = tokens queued in that shard
+#define DVQ_COUNTER_BYTES 512
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
 // per-launch host-side error plumbing (dvq_abi.hip)

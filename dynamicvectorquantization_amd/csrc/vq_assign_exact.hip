@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-    if (LIST && tail.loss != nullptr) {
+    if (LIST && (tail.loss != nullptr || tail.counters != nullptr)) {
         // fused loss finalize: the block that takes the last ticket sums every partial of the op
         // (fixed order -> the result does not depend on which block that is)
         int *flag = (int *)lds + 16;
@@ -196,7 +196,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
             *flag = (old == (int)gridDim.x - 1);
         }
         __syncthreads();
-        if (*flag) {
+        if (*flag && tid == 0 && tail.counters != nullptr) {   // bookkeeping for dvq_vq_assign_fallback_count_offset
+            int q = 0;
+            for (int i = 0; i < DVQ_QSHARDS; ++i) {
+                int v = tail.counters[DVQ_QCOUNT0 + i];
+                q += v < tail.shard_cap ? v : tail.shard_cap;
+            }
+            tail.counters[0] = q;
+        }
+        if (*flag && tail.loss != nullptr) {
             __threadfence();
             // partials of the earlier kernels are plain memory by now; this kernel's own need
             // device-coherent loads (they were written by blocks on other XCDs)
@@ -345,7 +353,7 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      hipStream_t st)
 {
     const float *tiles = prep;
-    const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f};
+    const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f, nullptr, 0};
     switch (D) {
     case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
     case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);

@@ -63,8 +63,8 @@ static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per
 static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup
 
 // record of one queued token (written by pass 1, read by the resolver)
-//   [zh: D*2 B in fragment order s,h,8][zf: D*4 B in channel order][meta 32 B]
-__host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 6 + 32; }
+//   [zf: D*4 B in channel order][meta 32 B]   (the resolver re-derives the fp16 fragments: same RNE conversion)
+__host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; }
 struct RecMeta { int n; float xn; float thr; float seed_scale; int prov; int pad[3]; };
 
 // ---------------------------------------------------------------------------------------------
@@ -186,6 +186,13 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
 {
     float r;     // plain v_max_f32: no canonicalising pre-ops (fmaxf() adds two per call)
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float vmax3_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -365,10 +372,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #undef DVQ_RD
         const float om = m1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float g = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-            m2 = __builtin_amdgcn_fmed3f(m1, m2, g);
-            m1 = vmax_raw(m1, g);
+        for (int r = 0; r < 16; r += 2) {
+            // running top-2 over the pair (g0, g1): with m2 <= m1 the new second-best is
+            // max(m2, med3(m1, g0, g1)) and the new best max3(m1, g0, g1): 2.5 VALU ops per score
+            float g0 = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+            float g1 = __uint_as_float((__float_as_uint(acc[r + 1]) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+            float md = __builtin_amdgcn_fmed3f(m1, g0, g1);
+            m1 = vmax3_raw(m1, g0, g1);
+            m2 = vmax_raw(m2, md);
         }
         t1 = (m1 != om) ? t : t1;
     }
@@ -392,32 +403,18 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     }
     const bool valid = n >= 0;
     bool hopeless = !(code < K) || !(thr == thr);
-    int slot = -1;
-    if (valid && !hopeless && !final_ok) {
-        if (h == 0) slot = atomicAdd(&counters[0], 1);
-        slot = __shfl(slot, c);
-        if (slot >= rec_cap) { hopeless = true; slot = -1; }
-    }
+    // undecided tokens are queued for the resolver.  The slot comes from an atomic whose result is not
+    // needed until the record is written, so: bump the shard counter now (one atomic per wave, lane 0,
+    // by the number of undecided tokens), run the z_q / loss phase while it is in flight, and only then
+    // read it back and dump the records.
+    const bool undecided = valid && !hopeless && !final_ok;
+    const unsigned long long umask = __ballot(undecided && h == 0);
+    const int shard = blockIdx.x & (DVQ_QSHARDS - 1);
+    int slot_raw = 0;
+    if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
     if (valid && hopeless && h == 0) {
         int pos = atomicAdd(&counters[1], 1);
         exact_list[pos] = n;
-    }
-    if (slot >= 0) {
-        char *rec = records + (size_t)slot * rec_bytes(D);
-#pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            *(f16x8 *)(rec + (s * 2 + h) * 16) = zh[s];
-            f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
-            f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
-            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h) * 4) = lo;
-            *(f32x4 *)(rec + D * 2 + (16 * s + 8 * h + 4) * 4) = hi;
-        }
-        if (h == 0) {
-            RecMeta rm;
-            rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
-            rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
-            *(RecMeta *)(rec + (size_t)D * 6) = rm;
-        }
     }
     float lsum = 0.0f;
     if (valid && !hopeless) {
@@ -455,6 +452,35 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             };
             if (zq != nullptr) finish(std::true_type{});
             else finish(std::false_type{});
+        }
+    }
+    if (umask != 0ull) {                                    // wave-uniform
+        const int base = __shfl(slot_raw, 0);
+        int slot = base + (int)__popcll(umask & ((1ull << c) - 1ull));   // rank among the wave's undecided tokens
+        slot = undecided ? slot : -1;
+        if (undecided && slot >= rec_cap) {                 // shard full: full exact evaluation instead; the
+            if (h == 0) {                                   // provisional code / z_q written above are overwritten
+                int pos = atomicAdd(&counters[1], 1);       // by the exact-list kernel, the loss term is dropped here
+                exact_list[pos] = n;
+            }
+            lsum = 0.0f;
+            slot = -1;
+        }
+        if (slot >= 0) {
+            char *rec = records + ((size_t)shard * rec_cap + slot) * rec_bytes(D);
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
+                f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
+                *(f32x4 *)(rec + (16 * s + 8 * h) * 4) = lo;
+                *(f32x4 *)(rec + (16 * s + 8 * h + 4) * 4) = hi;
+            }
+            if (h == 0) {
+                RecMeta rm;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
+                rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
+                *(RecMeta *)(rec + (size_t)D * 4) = rm;
+            }
         }
     }
     if (partials != nullptr) {
@@ -502,9 +528,12 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    int total = counters[0];
+    // block -> (shard, chunk): the first DVQ_QSHARDS blocks take chunk 0 of every shard, and so on
+    const int shard = blockIdx.x & (DVQ_QSHARDS - 1), chunk = blockIdx.x / DVQ_QSHARDS;
+    int total = counters[DVQ_QCOUNT0 + shard];
     total = total < rec_cap ? total : rec_cap;
-    const int base = blockIdx.x * RES_SLOTS;
+    total += shard * rec_cap;                                   // end of this shard's filled run
+    const int base = shard * rec_cap + chunk * RES_SLOTS;
     if (base >= total) {
         if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
         return;
@@ -517,8 +546,19 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const char *rec = records + (size_t)(live ? base + c : base) * rec_bytes(D);
     f16x8 zh[S16];
 #pragma unroll
-    for (int s = 0; s < S16; ++s) zh[s] = *(const f16x8 *)(rec + (s * 2 + h) * 16);
-    const RecMeta rm = *(const RecMeta *)(rec + (size_t)D * 6);
+    for (int s = 0; s < S16; ++s) {                    // same RNE f32 -> f16 conversion as pass 1
+        const f32x4 lo = *(const f32x4 *)(rec + (16 * s + 8 * h) * 4);
+        const f32x4 hi = *(const f32x4 *)(rec + (16 * s + 8 * h + 4) * 4);
+        u32x4 packed;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            f32x2 vv = {j2 < 2 ? lo[2 * j2] : hi[2 * j2 - 4], j2 < 2 ? lo[2 * j2 + 1] : hi[2 * j2 - 3]};
+            f16x2 hh = __builtin_convertvector(vv, f16x2);
+            packed[j2] = __builtin_bit_cast(unsigned, hh);
+        }
+        zh[s] = __builtin_bit_cast(f16x8, packed);
+    }
+    const RecMeta rm = *(const RecMeta *)(rec + (size_t)D * 4);
     const float thr = live ? rm.thr : __builtin_inff();
     __syncthreads();
 
@@ -563,9 +603,9 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const unsigned pc = cand[i];
         const int sl = (int)(pc >> 20), code = (int)(pc & 0xFFFFFu);
         const char *r2 = records + (size_t)(base + sl) * rec_bytes(D);
-        const f32x4 *zv = (const f32x4 *)(r2 + D * 2);
+        const f32x4 *zv = (const f32x4 *)r2;
         const f32x4 *ev = (const f32x4 *)(E + (size_t)code * D);
-        const float xn = ((const RecMeta *)(r2 + (size_t)D * 6))->xn;
+        const float xn = ((const RecMeta *)(r2 + (size_t)D * 4))->xn;
         float acc = 0.0f;
 #pragma unroll 16
         for (int q = 0; q < D / 4; ++q) {
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     // ---- winners; slots whose winner differs from pass 1 are rewritten
     if (tid < RES_SLOTS && base + tid < total) {
         const char *r2 = records + (size_t)(base + tid) * rec_bytes(D);
-        const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 6);
+        const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
             int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
             exact_list[pos] = m2.n;                   // pass 1's loss term for it is taken back below
@@ -605,14 +645,14 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const int sl = rewrite[i] >> 20, win = rewrite[i] & 0xFFFFF;
         const bool take_back_only = win == 0xFFFFF;   // token went to the exact list
         const char *r2 = records + (size_t)(base + sl) * rec_bytes(D);
-        const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 6);
+        const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         const long n = m2.n;
         const long bimg = n / HW;
         const int hw = (int)(n - bimg * HW);
         const float m = (mask != nullptr) ? mask[n] : 1.0f;
         float delta = 0.0f;
         for (int k0 = lane * 4; k0 < D; k0 += 256) {
-            f32x4 zv = *(const f32x4 *)(r2 + D * 2 + k0 * 4);
+            f32x4 zv = *(const f32x4 *)(r2 + k0 * 4);
             f32x4 eo = *(const f32x4 *)(E + (size_t)m2.prov * D + k0);
             f32x4 en_ = take_back_only ? eo : *(const f32x4 *)(E + (size_t)win * D + k0);
 #pragma unroll
@@ -638,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
 
 __global__ void zero_counters_kernel(int *__restrict__ counters)
 {
-    if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < DVQ_QCOUNT0 + DVQ_QSHARDS; i += blockDim.x) counters[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,14 +690,17 @@ int dvq_launch_exact_list(const float *z, const float *prep, const float *E, con
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-static int rec_capacity(long N)
+// slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
+static int shard_capacity(long N)
 {
     long cap = N / 8;
     if (cap < 4096) cap = 4096;
-    if (cap > N) cap = N;
-    cap = (cap + RES_SLOTS - 1) / RES_SLOTS * RES_SLOTS;
-    return (int)cap;
+    long per = (cap + DVQ_QSHARDS - 1) / DVQ_QSHARDS;
+    per = (per + RES_SLOTS - 1) / RES_SLOTS * RES_SLOTS;
+    return (int)per;
 }
+
+static int rec_capacity(long N) { return DVQ_QSHARDS * shard_capacity(N); }
 
 bool dvq_filter_supported(int D, int HW, int K, long N)
 {
@@ -665,11 +708,13 @@ bool dvq_filter_supported(int D, int HW, int K, long N)
     return (D == 64 || D == 128 || D == 256) && N < (1L << 31) && K < (1 << 20);
 }
 
-// ws_extra: [counters 256 B][exact list N ints][records cap * rec_bytes]
+// ws_extra: [counters DVQ_COUNTER_BYTES][exact list N ints][records cap * rec_bytes]
+// counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
+// [1] exact-list count, [4] finalize ticket, [DVQ_QCOUNT0 ..] per-shard queue counts
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
-    return 256 + align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
+    return DVQ_COUNTER_BYTES + align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -711,11 +756,11 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
     }
     const int nb1 = (int)((N + 127) / 128);
     hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap);
+                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
     if (pass1_only) return (int)hipGetLastError();
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), 0, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
-                       exact_list, records, cap);
+                       exact_list, records, cap / DVQ_QSHARDS);
     return (int)hipGetLastError();
 }
 
@@ -729,8 +774,8 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const char *img = base + 256;
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     int *counters = (int *)ws_extra;
-    int *exact_list = (int *)((char *)ws_extra + 256);
-    char *records = (char *)ws_extra + 256 + align256((size_t)N * sizeof(int));
+    int *exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
+    char *records = (char *)ws_extra + DVQ_COUNTER_BYTES + align256((size_t)N * sizeof(int));
     const int cap = rec_capacity(N);
     // [0] queue, [1] exact list, [4] finalize ticket.  A kernel rather than hipMemsetAsync: cheaper than
     // the runtime's fill kernel, and the op stays a pure chain of kernel nodes under hipGraph capture.
@@ -746,7 +791,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
     // the list kernel is the last of the op: it also sums all partials into loss[0..1]
     const DvqLossTail tail = {partials ? loss : nullptr, partials, counters + 4, dvq_filter_nparts(N),
-                              1.0 / ((double)N * D), beta};
+                              1.0 / ((double)N * D), beta, counters, cap / DVQ_QSHARDS};
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
                                  exact_list, counters + 1, tail, st);
 }
