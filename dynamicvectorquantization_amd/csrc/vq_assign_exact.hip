@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     // tokens: the dense range [0, N) (one 128-token chunk per block), or (pass 2 of the filter path)
     // the entries of a work list, which a small grid walks in 128-entry chunks
     const int cnt = LIST ? *list_count : 0;
+    // list mode: only the blocks that have list entries take part (block 0 always does, it may have to
+    // finalize on its own) -- an empty list costs one block, not a grid of ticket atomics
+    int nwork = 1;
+    if (LIST) {
+        nwork = (cnt + 127) / 128;
+        nwork = nwork < (int)gridDim.x ? nwork : (int)gridDim.x;
+        nwork = nwork > 1 ? nwork : 1;
+        if ((int)blockIdx.x >= nwork) return;
+    }
     double block_sum = 0.0;
     long chunk = blockIdx.x;
     for (int it = 0; LIST ? chunk * 128 < cnt : it < 1; ++it, chunk += gridDim.x) {   // dense: exactly once
@@ -191,9 +200,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         int *flag = (int *)lds + 16;
         __syncthreads();
         if (tid == 0) {
-            __threadfence();
-            int old = atomicAdd(tail.ticket, 1);
-            *flag = (old == (int)gridDim.x - 1);
+            if (nwork == 1) {
+                *flag = 1;
+            } else {
+                __threadfence();
+                int old = atomicAdd(tail.ticket, 1);
+                *flag = (old == nwork - 1);
+            }
         }
         __syncthreads();
         if (*flag && tid == 0 && tail.counters != nullptr) {   // bookkeeping for dvq_vq_assign_fallback_count_offset
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
                 s2 += tail.partials[i + 512]; s3 += tail.partials[i + 768];
             }
             for (; i < nprev; i += 256) s0 += tail.partials[i];
-            for (i = nprev + tid; i < tail.nparts; i += 256)
+            for (i = nprev + tid; i < nprev + nwork; i += 256)     // only the blocks that took part wrote theirs
                 s1 += __hip_atomic_load(tail.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
