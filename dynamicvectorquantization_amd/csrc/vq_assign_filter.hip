@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
             const float m = (mask != nullptr) ? mask[n] : 1.0f;
-            constexpr int SB = (S16 < 4) ? S16 : 4;
+            constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
             // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
             // inside the loop on the per-lane pointer every one of the 128 stores became its own
             // exec-masked branch to an out-of-line block.
