@@ -292,6 +292,7 @@ void dvq_oracle_route_select_dual(const void *gate, int gate_is_i64,
                                     : argmax_f32((const float *)gate + cell * 2, 2);
                 indices[cell] = g;
             }
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c)
             for (int y = 0; y < H; ++y)
@@ -324,6 +325,7 @@ void dvq_oracle_route_select_triple(const void *gate, int gate_is_i64,
     for (long cell = 0; cell < (long)B * hc * wc; ++cell)
         indices[cell] = gate_is_i64 ? argmax_i64((const int64_t *)gate + cell * 3, 3)
                                     : argmax_f32((const float *)gate + cell * 3, 3);
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c)
             for (int y = 0; y < H; ++y)

@@ -13,10 +13,11 @@ fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 N, D = 256 * 1024, 256
 known_read = N * D * 4 + 32 * (D * 4 + D * 4 + 8)            # z + the 32-code f32 tile image
-cal = [v for v in fetch["vq_assign_exact_kernel<256>"][:4]]
+cal_key = [k for k in fetch if k.startswith("vq_assign_exact_kernel<256") and "true" not in k][0]   # dense instantiation
+cal = [v for v in fetch[cal_key][:4]]
 cal_kib = sum(cal[1:]) / len(cal[1:])
 factor = known_read / (cal_kib * 1024.0)
-out = {"calibration": {"kernel": "vq_assign_exact_kernel<256> K=32 codes-only", "known_read_bytes": known_read,
+out = {"calibration": {"kernel": "vq_assign_exact_kernel<256, false> K=32 codes-only", "known_read_bytes": known_read,
                        "FETCH_SIZE_raw_bytes": cal_kib * 1024.0, "fetch_correction_factor": factor}}
 def avg(per, name):
     v = per[name]
