@@ -59,4 +59,22 @@ out["cfg5_modes_bit_identical"] = bool(torch.equal(c0, c1) and torch.equal(zq0, 
 flops = 2.0 * 16384 * 256 * 64 * 1024
 out["cfg5_exact_tflops"] = flops / (te * 1e-3) / 1e12
 out["cfg5_filter_tflops_equiv"] = flops / (tf * 1e-3) / 1e12
+# row f3: patch-entropy map of configs[2] (B=256 images 3x256x256), fused kernel vs the reference's op sequence as torch ops
+from dynamicvectorquantization_amd.entropy import Entropy
+img = t(synth.images_flat_noise(5000, 64)[0])
+ef, et = Entropy(16, 256, 256, fused=True).to(dev), Entropy(16, 256, 256, fused=False).to(dev)
+with torch.no_grad():
+    out["entropy_map_B64_fused_ms"] = timeit(lambda: ef(img), n=10, warm=3)
+    out["entropy_map_B64_torch_ops_ms"] = timeit(lambda: et(img), n=5, warm=2)
+# row f1: permuter forward on configs[2]-shaped codes (B=256)
+from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+perm = DualGrainSeperatePermuter(coarse_hw=16, fine_hw=32, content_pad_code=1024, content_eos_code=1025,
+                                 coarse_position_pad_code=256, coarse_position_eos_code=257,
+                                 fine_position_pad_code=1024, fine_position_eos_code=1025, fine_position_order="region-first").to(dev) if True else None
+codes = torch.randint(0, 1024, (256, 16, 16), device=dev).repeat_interleave(2, 1).repeat_interleave(2, 2)
+grainm = torch.from_numpy(synth.grain_gate_dual(4002, 256, 16, 16).argmax(-1)).to(dev)
+try:
+    out["permuter_forward_B256_ms"] = timeit(lambda: perm(codes, grainm), n=10, warm=3)
+except Exception as ex:
+    out["permuter_forward_B256_ms"] = "n/a: %s" % ex
 print(json.dumps(out, indent=1))
