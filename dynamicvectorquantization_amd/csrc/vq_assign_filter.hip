@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
         NEXT
         DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+        __builtin_amdgcn_s_setprio(1);
         if (S16 == 16) {
             // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
             // then overlaps the MFMA already in the pipe instead of preceding the whole chain
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         }
 #undef DVQ_MM
 #undef DVQ_RD
+        __builtin_amdgcn_s_setprio(0);
         const float om = m1;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
