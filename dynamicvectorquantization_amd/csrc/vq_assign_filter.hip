@@ -260,10 +260,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     float zf[S16][8];
     {
         const float *zp = z + token_base();
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int s = 0; s < S16; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
+        __builtin_amdgcn_s_setprio(0);
     }
     f16x8 zh[S16];
     float xn, thr2W;
