@@ -459,3 +459,24 @@ def test_hot_path_is_graph_capturable(dev):
     torch.cuda.synchronize()
     assert torch.equal(got[1], codes) and torch.equal(got[0], zq) and torch.equal(got[3], grain)
     assert torch.equal(got[2], loss)
+
+
+def test_filter_queue_overflow_falls_back_to_exact(dev):
+    """a codebook with widely mixed norms leaves most tokens undecided: every shard of the resolver queue
+    fills up and the remainder goes through the exact list; output still equals the exact mode bit for bit"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    rng = np.random.default_rng(3)
+    K, D, B = 1024, 256, 16
+    E = synth.codebook_trained(K, D, seed=77)
+    E = np.ascontiguousarray(E * np.exp2(rng.integers(-5, 5, size=(K, 1))).astype(np.float32))
+    zt = torch.from_numpy(synth.z_tokens(E, B, 32, 32, 4242)).to(dev)
+    Et = torch.from_numpy(E).to(dev)
+    mask = torch.from_numpy(np.where(rng.random((B, 1, 32, 32)) < 0.5, 1.0, 0.25).astype(np.float32)).to(dev)
+    pe, pf = _CodebookPrep(), _CodebookPrep()
+    zq0, c0, l0 = vq_assign(zt, Et, pe, mask, mode=_lib.MODE_EXACT)
+    zq1, c1, l1 = vq_assign(zt, Et, pf, mask, mode=_lib.MODE_FILTER)
+    queued, listed = pf.fallback_count()
+    assert queued == 4096 and listed > 1000, (queued, listed)        # 64 shards x 64 slots full, the rest listed
+    assert torch.equal(c0, c1) and torch.equal(zq0, zq1)
+    assert abs(float(l0[1]) - float(l1[1])) <= 1e-6 * abs(float(l0[1]))
