@@ -7,16 +7,19 @@
 //                                                   Linear [-> SiLU | ReLU -> Linear]
 // which is 8-10 launches and ~5 passes over the branch features in the reference.  Here:
 //   1. gn_stats_kernel   one pass over every branch: (mean, rstd) per (image, group).
-//   2. w1_tile_kernel    hidden-layer weight -> 32-row MFMA tile images (same layout as the codebook
-//                        tiles of vq_assign_exact.hip).
+//   2. w1_split_kernel   hidden-layer weight -> 32-row MFMA tile images, split w = hi + lo with
+//                        hi = fp16(w), lo = fp16(w - hi) (22 significand bits between them).
 //   3. router_gate_kernel  one workgroup per 32 coarse cells: pools the raw features (the average of
 //                        normalised pixels is the normalised average), applies the GroupNorm affine,
-//                        keeps the [32 x F] feature tile in LDS, multiplies it with the hidden layer on
-//                        the fp32 matrix cores (v_mfma_f32_32x32x2_f32; fp32 because the logits decide
-//                        an argmax downstream), applies the activation and contracts with the output
-//                        layer in the MFMA epilogue.  The [cells x F] concat, its NHWC copy and the
-//                        hidden activations never reach HBM.
-// fp32 with a different summation order than ATen/MKL: tolerance parity (logits 1e-4), by design.
+//                        keeps the [32 x F] feature tile in LDS (also split hi + lo), multiplies it with
+//                        the hidden layer on the fp16 matrix cores as hi*hi + hi*lo + lo*hi with fp32
+//                        accumulation (3 MFMAs at 16x the fp32-MFMA rate; the dropped lo*lo term is
+//                        2^-22 relative, i.e. fp32-grade products -- the logits decide an argmax
+//                        downstream), applies the activation and contracts with the output layer in the
+//                        MFMA epilogue.  The [cells x F] concat, its NHWC copy and the hidden activations
+//                        never reach HBM.
+// A different summation order than ATen/MKL and 2^-22 instead of 2^-24 products: tolerance parity
+// (logits within 1e-4 of the reference, ~1e-6 in practice), by design.
 #include "dvq_common.h"
 
 struct DvqGateArgs {
@@ -65,19 +68,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(DvqGateArgs a, float2 *__
     }
 }
 
-// ---- 2. hidden-layer weight W1 [Hid, F] -> tile images: img[t][kg][c][p] = W1[32t + c][8kg + 2(p&3) + (p>>2)]
-__global__ __launch_bounds__(256) void w1_tile_kernel(const float *__restrict__ W1, int Hid, int F,
-                                                      float *__restrict__ tiles)
+// ---- 2. hidden-layer weight W1 [Hid, F] -> split fp16 tile images (Fp = F rounded up to 16, S = Fp/16):
+//   imgH / imgL [t][s][lane = 32h + c][j < 8] = hi / lo of W1[32t + c][16s + 8h + j]   (zero padded)
+__global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__ W1, int Hid, int F, int Fp,
+                                                       _Float16 *__restrict__ imgH, _Float16 *__restrict__ imgL)
 {
-    const size_t per_tile = (size_t)32 * F;
+    const size_t per_tile = (size_t)32 * Fp;
     const size_t total = (size_t)((Hid + 31) / 32) * per_tile;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int t = (int)(i / per_tile);
         const int r = (int)(i - (size_t)t * per_tile);
-        const int kg = r >> 8, c = (r >> 3) & 31, p = r & 7;
-        const int k = kg * 8 + 2 * (p & 3) + (p >> 2);
-        const int row = t * 32 + c;
-        tiles[i] = (row < Hid) ? W1[(size_t)row * F + k] : 0.0f;
+        const int s16 = r >> 9, lane = (r >> 3) & 63, j = r & 7;
+        const int k = 16 * s16 + 8 * (lane >> 5) + j;
+        const int row = t * 32 + (lane & 31);
+        const float w = (row < Hid && k < F) ? W1[(size_t)row * F + k] : 0.0f;
+        const _Float16 hi = (_Float16)w;
+        imgH[i] = hi;
+        imgL[i] = (_Float16)(w - (float)hi);
     }
 }
 
@@ -85,21 +92,26 @@ __global__ __launch_bounds__(256) void w1_tile_kernel(const float *__restrict__ 
 // ACT: 0 = single Linear (no hidden layer), 1 = SiLU, 2 = ReLU.  G = logits per cell (2 / 3).
 template <int G>
 __global__ __launch_bounds__(256) void router_gate_kernel(
-    DvqGateArgs a, const float2 *__restrict__ stats, const float *__restrict__ w1_tiles,
-    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
-    int Hid, int act, float *__restrict__ gate)
+    DvqGateArgs a, const float2 *__restrict__ stats, const _Float16 *__restrict__ imgH,
+    const _Float16 *__restrict__ imgL, const float *__restrict__ b1, const float *__restrict__ W2,
+    const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate)
 {
-    extern __shared__ __attribute__((aligned(16))) float X[];      // [F/8][32 cells][8] (+ reduction scratch)
+    // LDS: XH | XL halves [Fp/16][64 lanes = 32h + cell][8] each (B operands), then bias / output rows
+    extern __shared__ __attribute__((aligned(16))) float X[];
     const int F = a.nb * a.C;
+    const int Fp = (F + 15) & ~15;
+    _Float16 *XH = (_Float16 *)X, *XL = XH + 32 * Fp;
+    __shared__ unsigned s_amax;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const long ncell = (long)a.B * a.hc * a.wc;
     const long cell0 = (long)blockIdx.x * 32;
 
-    // ---- feature tile: pooled + normalised, in MFMA B-operand order.  A thread keeps one cell
-    // (tid & 31) and walks channels (tid >> 5) + 8i, eight independent loads in flight.
-    {
+    // ---- feature tile: pooled + normalised, split into fp16 hi + lo, in MFMA B-operand order.  A thread
+    // keeps one cell (tid & 31) and walks channels (tid >> 5) + 8i, eight independent loads in flight.
+    auto build = [&](float xscale) -> float {
+        float vmax = 0.0f;
         const int cell = tid & 31;
         const long cg = cell0 + cell;
         const bool live = cg < ncell;
@@ -108,6 +120,11 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
         const int rem = (int)(cgl - (long)b * a.hc * a.wc);
         const int y = rem / a.wc, x = rem - y * a.wc;
         const int cpg = a.groups > 0 ? a.C / a.groups : 1;
+        for (int k = F + (tid >> 5); k < Fp; k += 8) {      // zero the k padding
+            const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
+            XH[idx] = (_Float16)0.0f;
+            XL[idx] = (_Float16)0.0f;
+        }
         for (int br = 0; br < a.nb; ++br) {
             const int sc = a.scale[br];
             const int Wb = a.wc * sc;
@@ -135,9 +152,13 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
                     const float2 ms = st[ch / cpg];
                     v = (v - ms.x) * ms.y * gw[ch] + gb[ch];
                 }
+                v = live ? v * xscale : 0.0f;
+                vmax = fmaxf(vmax, fabsf(v));
                 const int k = br * a.C + ch;
-                const int pp = ((k & 7) >> 1) | ((k & 1) << 2);
-                X[((k >> 3) * 32 + cell) * 8 + pp] = live ? v : 0.0f;
+                const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
+                const _Float16 hi = (_Float16)v;
+                XH[idx] = hi;
+                XL[idx] = (_Float16)(v - (float)hi);
             };
             int ch = tid >> 5;
             for (; ch + 56 < a.C; ch += 64) {
@@ -149,13 +170,33 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
             }
             for (; ch < a.C; ch += 8) put(ch, pooled(ch));
         }
+        return vmax;
+    };
+    // features beyond the fp16 range (possible with normalization_type "none") are handled by an exact
+    // power-of-two rescale of the whole tile, undone on the fp32 accumulators
+    if (tid == 0) s_amax = 0u;
+    __syncthreads();
+    float inv_scale = 1.0f;
+    {
+        float vmax = build(1.0f);
+        atomicMax(&s_amax, __float_as_uint(vmax));          // non-negative floats order like their bits
+        __syncthreads();
+        const float wgmax = __uint_as_float(s_amax);
+        if (!(wgmax < 16384.0f) && wgmax < __builtin_inff()) {           // workgroup-uniform, rare
+            int e;
+            (void)frexpf(wgmax, &e);                                      // wgmax = m * 2^e, m in [0.5, 1)
+            const float xs = ldexpf(1.0f, 10 - e);                        // brings the maximum to ~2^10
+            inv_scale = ldexpf(1.0f, e - 10);
+            __syncthreads();
+            (void)build(xs);
+        }
     }
     __syncthreads();
 
     float part[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) part[g] = 0.0f;
-    float *PB = X + 32 * F;                            // hidden bias + output-layer rows: [1 + G][Hid]
+    float *PB = X + 32 * Fp;                           // hidden bias + output-layer rows: [1 + G][Hid]
     if (act != 0) {
         for (int i = tid; i < Hid; i += 256) {
             PB[i] = b1[i];
@@ -168,8 +209,8 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
         // single Linear: gate[cell][g] = W2[g][:] . x + b2[g]; 8 threads per cell split k
         const int cell = tid >> 3, sub = tid & 7;
         for (int k = sub; k < F; k += 8) {
-            const int pp = ((k & 7) >> 1) | ((k & 1) << 2);
-            const float xv = X[((k >> 3) * 32 + cell) * 8 + pp];
+            const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
+            const float xv = ((float)XH[idx] + (float)XL[idx]) * inv_scale;
 #pragma unroll
             for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(W2[(size_t)g * F + k], xv, part[g]);
         }
@@ -188,52 +229,42 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     }
 
     __syncthreads();
-    // ---- hidden layer on the fp32 matrix cores: wave w takes hidden-row tiles w, w + 4, ...
+    // ---- hidden layer on the fp16 matrix cores (split operands): wave w takes hidden-row tiles w, w + 4, ...
     const int T = (Hid + 31) / 32;
-    const float *xp = X + c * 8 + 4 * h;
+    const int S = Fp / 16;
+    const f16x8 *xh = (const f16x8 *)XH + lane, *xl = (const f16x8 *)XL + lane;      // + s * 64 per k-step
     for (int t = wave; t < T; t += 4) {
-        const float *ap = w1_tiles + (size_t)t * 32 * F + c * 8 + 4 * h;
+        const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
+        const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const int KG = F / 8;
-        int kg0 = 0;
-        f32x4 av[8];                                   // A fragments of the current 8-step group (from L2)
-        if (KG >= 8) {
+        int s0 = 0;
+        for (; s0 + 4 <= S; s0 += 4) {                 // 8 A fragments (L2) in flight per wave
+            f16x8 vh[4], vl[4], bh[4], bl[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = *(const f32x4 *)(ap + u * 256);
-        }
-        for (; kg0 + 8 <= KG; kg0 += 8) {
-            f32x4 an[8], xv[8];
-            const bool more = kg0 + 16 <= KG;          // prefetch the next group under this one's MFMAs
+            for (int u = 0; u < 4; ++u) { vh[u] = ah[(s0 + u) * 64]; vl[u] = al[(s0 + u) * 64]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) an[u] = more ? *(const f32x4 *)(ap + (kg0 + 8 + u) * 256) : av[u];
+            for (int u = 0; u < 4; ++u) { bh[u] = xh[(s0 + u) * 64]; bl[u] = xl[(s0 + u) * 64]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = *(const f32x4 *)(xp + (kg0 + u) * 256);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], xv[u][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], xv[u][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][2], xv[u][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][3], xv[u][3], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[u], bh[u], acc, 0, 0, 0);   // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bl[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bh[u], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = an[u];
         }
-        for (; kg0 < KG; ++kg0) {
-            const f32x4 a1 = *(const f32x4 *)(ap + kg0 * 256);
-            const f32x4 x1 = *(const f32x4 *)(xp + kg0 * 256);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], x1[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], x1[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], x1[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], x1[3], acc, 0, 0, 0);
+        for (; s0 < S; ++s0) {
+            const f16x8 vh = ah[s0 * 64], vl = al[s0 * 64], bh = xh[s0 * 64], bl = xl[s0 * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, acc, 0, 0, 0);
         }
         // epilogue: bias, activation, contraction with the output layer (rows of this lane)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (j < Hid) {
-                const float yv = acc[r] + PB[j];
+                const float yv = acc[r] * inv_scale + PB[j];
                 const float hv = (act == 1) ? yv / (1.0f + expf(-yv)) : (yv > 0.0f ? yv : 0.0f);
 #pragma unroll
                 for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(PB[(1 + g) * Hid + j], hv, part[g]);
@@ -264,12 +295,12 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
 // ---------------------------------------------------------------------------------------------
 static size_t align256r(size_t x) { return (x + 255) / 256 * 256; }
 
-// ws: [stats nb*B*groups float2][W1 tile images ceil(Hid/32)*32*F floats]
+// ws: [stats nb*B*groups float2][W1 hi image | W1 lo image: ceil(Hid/32)*32*Fp halves each]
 size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int groups, int Hid)
 {
-    const size_t F = (size_t)nb * C;
+    const size_t Fp = ((size_t)nb * C + 15) / 16 * 16;
     return align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)) +
-           align256r((size_t)((Hid + 31) / 32) * 32 * F * sizeof(float)) + 256;
+           align256r((size_t)((Hid + 31) / 32) * 32 * Fp * 2 * sizeof(_Float16)) + 256;
 }
 
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
@@ -285,28 +316,29 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         a.scale[i] = 1 << i;
     }
     a.nb = nb; a.B = B; a.C = C; a.hc = hc; a.wc = wc; a.groups = groups; a.eps = eps;
-    const int F = nb * C;
+    const int F = nb * C, Fp = (F + 15) & ~15;
     float2 *stats = (float2 *)ws;
-    float *tiles = (float *)((char *)ws + align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)));
+    _Float16 *imgH = (_Float16 *)((char *)ws + align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)));
+    _Float16 *imgL = imgH + (size_t)((Hid + 31) / 32) * 32 * Fp;
     if (groups > 0)
         hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups, nb), dim3(256), 0, st, a, stats);
     if (act != 0) {
-        size_t total = (size_t)((Hid + 31) / 32) * 32 * F;
+        size_t total = (size_t)((Hid + 31) / 32) * 32 * Fp;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(w1_tile_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, tiles);
+        hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL);
     }
     const long ncell = (long)B * hc * wc;
     const unsigned grid = (unsigned)((ncell + 31) / 32);
-    const size_t shmem = ((size_t)32 * F + (size_t)(1 + nb) * Hid) * sizeof(float);
+    const size_t shmem = ((size_t)32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
     if (nb == 2) {
         static bool set2 = false;
-        if (!set2) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set2 = true; }
-        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(256), shmem, st, a, stats, tiles, b1, W2, b2, Hid, act, gate);
+        if (!set2) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set2 = true; }
+        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
     } else {
         static bool set3 = false;
-        if (!set3) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set3 = true; }
-        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(256), shmem, st, a, stats, tiles, b1, W2, b2, Hid, act, gate);
+        if (!set3) { (void)hipFuncSetAttribute((const void *)router_gate_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set3 = true; }
+        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
     }
     return (int)hipGetLastError();
 }

@@ -143,7 +143,8 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
  * num_branches nb = 2 (h_median must be NULL; h_fine is 2x the coarse grid) or 3 (median 2x, fine 4x).
  * h_* are [B, C, rows, cols] f32 NCHW; num_groups == 0 means normalization_type "none" (gn_* ignored),
  * otherwise gn_w_* / gn_b_* are the [C] affine parameters of each branch's GroupNorm(num_groups, C, eps).
- * gate [B, hc, wc, nb] f32 logits.  C % 8 == 0, nb*C <= 1280.  fp32 throughout (fp32 matrix cores);
+ * gate [B, hc, wc, nb] f32 logits.  C % 8 == 0, nb*C <= 1280.  The hidden layer runs on the fp16 matrix
+ * cores with both operands split hi + lo (hi*hi + hi*lo + lo*hi, fp32 accumulation: 2^-22 products);
  * summation order differs from ATen/MKL: logits equal the reference within 1e-4, not bit for bit.
  */
 #define DVQ_ACT_NONE 0

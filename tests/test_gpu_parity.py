@@ -283,6 +283,7 @@ def test_feature_router_logits(dev, which):
     ("triple", "group-32", "2layer-fc-ReLu", 2, 8, 8),
     ("triple", "none", "2layer-fc-SiLu", 1, 3, 2),
     ("triple", "group-16", "1layer-fc", 5, 8, 8),
+    ("dual", "none", "2layer-fc-SiLu", 2, 4, 4),
 ])
 def test_fused_router_gate_matches_torch_ops(dev, which, norm, gate_type, B, hc, wc):
     """the fused kernel (no_grad) against the same module evaluated with differentiable torch ops
@@ -298,7 +299,9 @@ def test_fused_router_gate_matches_torch_ops(dev, which, norm, gate_type, B, hc,
                 p_.copy_(torch.randn_like(p_) * 0.5 + (1.0 if n_.endswith("weight") else 0.0))
     t = lambda a: torch.from_numpy(a).to(dev)
     nbr = 2 if which == "dual" else 3
-    feats = [t(synth.features(700 + i, B, Cc, hc << i, wc << i) * np.float32(1.5) + np.float32(0.3)) for i in range(nbr)]
+    # un-normalised 2-layer case: features far beyond the fp16 range exercise the tile rescale
+    mag = np.float32(3.0e5) if (norm == "none" and gate_type != "1layer-fc" and which == "dual") else np.float32(1.5)
+    feats = [t(synth.features(700 + i, B, Cc, hc << i, wc << i) * mag + np.float32(0.3)) for i in range(nbr)]
     kw = dict(h_coarse=feats[0], h_fine=feats[-1])
     if nbr == 3:
         kw["h_median"] = feats[1]
