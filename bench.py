@@ -43,13 +43,37 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs under a 16-CPU quota; 256 OpenMP threads there just get throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p_ + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(E, B_gpu, target_s):
     """the oracle (explicit-order C restatement of what the reference's torch-CPU path computes)
     timed on this box's host cores on a bounded sample of the same workload"""
     from dynamicvectorquantization_amd import synth
     from oracle import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)      # the oracle's OpenMP team
+    except Exception:
+        pass
     nb = min(B_gpu, 64)
     hf = synth.z_tokens(E, nb, 32, 32, 2903)
     hc = synth.z_tokens(E, nb, 16, 16, 2913)
