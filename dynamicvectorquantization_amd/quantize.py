@@ -95,6 +95,11 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
         zq = torch.empty_like(z) if want_zq else None
         codes = torch.empty((B,) + tuple(z.shape[2:]), dtype=torch.int64, device=z.device)
         loss = torch.empty(2, dtype=torch.float32, device=z.device) if want_loss else None
+    if B * HW == 0:
+        # empty batch: what the reference's torch ops give (empty codes / z_q, mean of nothing = NaN)
+        if loss is not None:
+            loss.fill_(float("nan"))
+        return zq, codes, loss
     ws = prep.workspace(B, D, HW, K, mode, z.device)
     with torch.cuda.device(z.device):
         pbuf = prep.get(codebook)

@@ -27,6 +27,8 @@ def entropy_gate(entropy, threshold):
     """[...] f32 entropy -> [..., 2] int64 gate = cat[(ent <= thr), (ent > thr)] (RouterDual.py:54-56)."""
     entropy = _lib.require_cuda_f32(entropy, "entropy")
     gate = torch.empty(tuple(entropy.shape) + (2,), dtype=torch.int64, device=entropy.device)
+    if entropy.numel() == 0:
+        return gate
     with torch.cuda.device(entropy.device):
         _lib.check(_lib_handle.dvq_entropy_gate_f32(entropy.data_ptr(), entropy.numel(), float(threshold),
                                                     gate.data_ptr(), _lib.stream_ptr(entropy.device)),
@@ -65,6 +67,8 @@ def route_select_dual(gate, h_coarse, h_fine, out=None):
         h_dual = torch.empty_like(h_fine)
         indices = torch.empty((B, hc, wc), dtype=torch.int64, device=h_fine.device)
         cmask = torch.empty((B, 1, 2 * hc, 2 * wc), dtype=torch.float32, device=h_fine.device)
+    if h_dual.numel() == 0:
+        return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
     with torch.cuda.device(h_fine.device):
         _lib.check(_lib_handle.dvq_route_select_dual_f32(
             g.data_ptr(), gdt, h_coarse.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
@@ -92,6 +96,8 @@ def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
         h_triple = torch.empty_like(h_fine)
         indices = torch.empty((B, hc, wc), dtype=torch.int64, device=h_fine.device)
         cmask = torch.empty((B, 1, 4 * hc, 4 * wc), dtype=torch.float32, device=h_fine.device)
+    if h_triple.numel() == 0:
+        return {"h_triple": h_triple, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
     with torch.cuda.device(h_fine.device):
         _lib.check(_lib_handle.dvq_route_select_triple_f32(
             g.data_ptr(), gdt, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,

@@ -483,3 +483,19 @@ def test_filter_queue_overflow_falls_back_to_exact(dev):
     assert queued == 4096 and listed > 1000, (queued, listed)        # 64 shards x 64 slots full, the rest listed
     assert torch.equal(c0, c1) and torch.equal(zq0, zq1)
     assert abs(float(l0[1]) - float(l1[1])) <= 1e-6 * abs(float(l0[1]))
+
+
+def test_empty_batch(dev):
+    """B = 0: empty codes / z_q / routed features and a NaN loss, as the reference's torch ops return"""
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import entropy_gate, route_select_dual
+    vq = VectorQuantize2(64, 64).to(dev).eval()
+    z = torch.empty((0, 64, 8, 8), device=dev)
+    with torch.no_grad():
+        zq, loss, (_, _, codes) = vq(z, codebook_mask=torch.empty((0, 1, 8, 8), device=dev))
+    assert zq.shape == (0, 64, 8, 8) and codes.shape == (0, 8, 8) and codes.dtype == torch.int64
+    assert bool(torch.isnan(loss))
+    gate = entropy_gate(torch.empty((0, 4, 4), device=dev), 1.0)
+    assert gate.shape == (0, 4, 4, 2) and gate.dtype == torch.int64
+    out = route_select_dual(gate, torch.empty((0, 64, 4, 4), device=dev), z)
+    assert out["h_dual"].shape == (0, 64, 8, 8) and out["indices"].shape == (0, 4, 4)
