@@ -100,5 +100,16 @@ struct DvqLossTail {
 #define DVQ_COUNTER_BYTES 512
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
+// Kernels with more than 64 KiB of dynamic LDS need the per-device opt-in once; `done` is the caller's
+// static bitmask (one bit per device ordinal, so a process driving several GPUs opts in on each).
+static inline void dvq_allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;     // shared bit: always re-apply
+    if (dev != 63 && ((*done >> dev) & 1ull)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev != 63) *done |= 1ull << dev;
+}
+
 // per-launch host-side error plumbing (dvq_abi.hip)
 void dvq_set_error(const char *fmt, ...);

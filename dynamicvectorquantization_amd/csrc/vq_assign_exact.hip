@@ -327,15 +327,10 @@ static int launch_exact(const float *z, const float *tiles, const float *E, cons
                         int HW, int K, long N, float *zq, long long *codes, double *partials,
                         const int *list, const int *list_count, DvqLossTail tail, hipStream_t st)
 {
-    static bool attr_set = false;
+    static unsigned long long done_dense = 0, done_list = 0;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void *)vq_assign_exact_kernel<D, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_set = true;
-    }
+    dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, false>, (int)shmem, &done_dense);
+    dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, true>, (int)shmem, &done_list);
     int blocks = (int)((N + 127) / 128);
     if (list != nullptr) {
         if (blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;

@@ -758,13 +758,9 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
                          long long *codes, double *partials, int *counters, int *exact_list,
                          char *records, int cap, bool pass1_only, hipStream_t st)
 {
-    static bool attr_set = false;
+    static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)vq_assign_filter_kernel<D>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem1);
-        attr_set = true;
-    }
+    dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
     const int nb1 = (int)((N + 127) / 128);
     hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
                        E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
