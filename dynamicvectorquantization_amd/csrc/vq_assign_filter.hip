@@ -65,7 +65,8 @@ static constexpr int RES_CAND = 512;              // resolver: candidate pairs p
 // record of one queued token (written by pass 1, read by the resolver)
 //   [zf: D*4 B in channel order][meta 32 B]   (the resolver re-derives the fp16 fragments: same RNE conversion)
 __host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; }
-struct RecMeta { int n; float xn; float thr; float seed_scale; int prov; int pad[3]; };
+struct RecMeta { int n; float xn; float thr; float seed_scale; unsigned long long best; int prov; int pad; };   // 32 B
+//   best: merged (distance, code) key of the sliced resolver (large K), ~0 = none yet; written ~0 by pass 1
 
 // ---------------------------------------------------------------------------------------------
 // prep: meta (scale, norm maxima, finiteness), fp16 tile images, rounding-residual norm
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             if (h == 0) {
                 RecMeta rm;
                 rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
-                rm.pad[0] = rm.pad[1] = rm.pad[2] = 0;
+                rm.best = ~0ull; rm.pad = 0;
                 *(RecMeta *)(rec + (size_t)D * 4) = rm;
             }
         }
@@ -525,8 +526,12 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
     const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
-    int *__restrict__ counters, int *__restrict__ exact_list, const char *__restrict__ records, int rec_cap)
+    int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
+    int nslice, int *__restrict__ chunk_sync)
 {
+    // Large codebooks: the code tiles are cut into `nslice` slices (blockIdx.y); each slice resolves its
+    // candidates locally, merges its per-token best into the record with a 64-bit atomicMin, and the
+    // slice that arrives last at the chunk's ticket does the rewrite.  nslice == 1: all of it in LDS.
     constexpr int S16 = D / 16;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
@@ -545,11 +550,15 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     total = total < rec_cap ? total : rec_cap;
     total += shard * rec_cap;                                   // end of this shard's filled run
     const int base = shard * rec_cap + chunk * RES_SLOTS;
+    const int slice = blockIdx.y;
     if (base >= total) {
-        if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
+        if (partials != nullptr && tid == 0 && slice == 0) partials[blockIdx.x] = 0.0;
         return;
     }
     const int T = dvq_num_tiles(K);
+    int tps = (T + nslice - 1) / nslice;                        // tiles per slice, a multiple of 4
+    tps = (tps + 3) & ~3;
+    const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
 
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     __syncthreads();
 
     // ---- enumerate: every code whose approximate score reaches best - 2W
-    for (int t = wave; t < T; t += 4) {
+    for (int t = t_begin + wave; t < t_end; t += 4) {
         const char *tile = img + (size_t)t * TILE_STRIDE;
         const float *enr = (const float *)(tile + IMG_BYTES) + 4 * h;      // accumulator seeds of the tile      // accumulator seeds of the tile
         f16x8 a[S16];
@@ -606,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     }
     __syncthreads();
     const int ncand_raw = misc[0];
-    const bool overflow = ncand_raw > RES_CAND;       // hand the whole group to the exact list
+    bool overflow = ncand_raw > RES_CAND;             // hand the whole group to the exact list
     const int ncand = overflow ? 0 : ncand_raw;
 
     // ---- exact chains: one thread per (token, candidate)
@@ -631,6 +640,31 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         atomicMin(&best[sl], order_key(d, code));
     }
     __syncthreads();
+
+    if (nslice > 1) {
+        // merge across slices through the records; the last slice of this chunk carries on
+        int *ticket = chunk_sync + 2 * blockIdx.x, *oflag = ticket + 1;
+        if (tid < RES_SLOTS && base + tid < total && best[tid] != ~0ull) {
+            RecMeta *gm = (RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
+            atomicMin(&gm->best, best[tid]);
+        }
+        if (overflow && tid == 0) atomicOr(oflag, 1);
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            misc[2] = (atomicAdd(ticket, 1) == nslice - 1);
+        }
+        __syncthreads();
+        if (!misc[2]) return;                          // not the last slice (its partial is written by the last)
+        __threadfence();
+        if (tid < RES_SLOTS && base + tid < total) {
+            const RecMeta *gm = (const RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
+            best[tid] = __hip_atomic_load(&gm->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        overflow = misc[3] != 0;
+    }
 
     // ---- winners; slots whose winner differs from pass 1 are rewritten
     if (tid < RES_SLOTS && base + tid < total) {
@@ -687,9 +721,10 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     }
 }
 
-__global__ void zero_counters_kernel(int *__restrict__ counters)
+__global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict__ chunk_sync, int nsync)
 {
     for (int i = threadIdx.x; i < DVQ_QCOUNT0 + DVQ_QSHARDS; i += blockDim.x) counters[i] = 0;
+    for (int i = threadIdx.x; i < nsync; i += blockDim.x) chunk_sync[i] = 0;      // sliced resolver only
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -719,13 +754,23 @@ bool dvq_filter_supported(int D, int HW, int K, long N)
     return (D == 64 || D == 128 || D == 256) && N < (1L << 31) && K < (1 << 20);
 }
 
-// ws_extra: [counters DVQ_COUNTER_BYTES][exact list N ints][records cap * rec_bytes]
+// resolver slices over the code tiles: 1 up to 64 tiles (K <= 2048), then one per 64 tiles, at most 8
+static int resolver_slices(int K)
+{
+    int T = dvq_num_tiles(K);
+    int ns = (T + 63) / 64;
+    return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+}
+
+// ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk]
+//           [exact list N ints][records cap * rec_bytes]
 // counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
 // [1] exact-list count, [4] finalize ticket, [DVQ_QCOUNT0 ..] per-shard queue counts
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
-    return DVQ_COUNTER_BYTES + align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
+    return DVQ_COUNTER_BYTES + align256((size_t)rec_capacity(N) / RES_SLOTS * 2 * sizeof(int)) +
+           align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -756,7 +801,7 @@ template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
                          const float *E, const float *mask, int HW, int K, long N, float *zq,
                          long long *codes, double *partials, int *counters, int *exact_list,
-                         char *records, int cap, bool pass1_only, hipStream_t st)
+                         char *records, int cap, bool pass1_only, int *chunk_sync, hipStream_t st)
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
@@ -765,9 +810,10 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
     hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
                        E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
     if (pass1_only) return (int)hipGetLastError();
-    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS), dim3(256), 0, st, img, meta,
+    const int nslice = resolver_slices(K);
+    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS, nslice), dim3(256), 0, st, img, meta,
                        en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
-                       exact_list, records, cap / DVQ_QSHARDS);
+                       exact_list, records, cap / DVQ_QSHARDS, nslice, chunk_sync);
     return (int)hipGetLastError();
 }
 
@@ -781,17 +827,20 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const char *img = base + 256;
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     int *counters = (int *)ws_extra;
-    int *exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
-    char *records = (char *)ws_extra + DVQ_COUNTER_BYTES + align256((size_t)N * sizeof(int));
     const int cap = rec_capacity(N);
+    int *chunk_sync = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
+    const size_t sync_bytes = align256((size_t)cap / RES_SLOTS * 2 * sizeof(int));
+    int *exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
+    char *records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
     // [0] queue, [1] exact list, [4] finalize ticket.  A kernel rather than hipMemsetAsync: cheaper than
     // the runtime's fill kernel, and the op stays a pure chain of kernel nodes under hipGraph capture.
-    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, st, counters);
+    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, counters, chunk_sync,
+                       resolver_slices(K) > 1 ? cap / RES_SLOTS * 2 : 0);
     int rc;
     switch (D) {
-    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
-    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
-    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, st); break;
+    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
+    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
+    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;
