@@ -2,7 +2,7 @@
 """Benchmark of the DQ-VAE vector-quantization hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch that is already resident in HBM:
-    entropy-threshold gate -> dual-granularity route select (+ codebook_mask)
+    entropy-threshold gate + dual-granularity route select (+ codebook_mask), fused in one kernel
     -> VQ nearest-codebook assignment (codes, z_q, masked commitment loss)
 on BASELINE.json configs[2] (dqvae-entropy-dual-r05: B=256 per GPU, 32x32x256 latents, K=1024).
 The 1x1 quant_conv between select and VQ is a vendor GEMM outside the path
@@ -123,7 +123,7 @@ def main():
     from dynamicvectorquantization_amd import _lib, synth
     from dynamicvectorquantization_amd.encode import all_gather_codes
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
-    from dynamicvectorquantization_amd.router import entropy_gate, route_select_dual
+    from dynamicvectorquantization_amd.router import route_select_dual_entropy
 
     B, K, D, H, W = a.batch, a.codes, 256, 32, 32
     mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
@@ -144,9 +144,11 @@ def main():
     loss = torch.empty(2, dtype=torch.float32, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+
     def step(i=None):
-        gate = entropy_gate(ent, thr)
-        route_select_dual(gate, h_coarse, h_fine, out=(h_dual, grain, cmask))
+        # entropy-threshold gate + routing tail: one kernel (the int64 gate is written as a by-product)
+        route_select_dual_entropy(ent, thr, h_coarse, h_fine, out=(h_dual, grain, cmask, gate))
         if i is not None:
             ev[i][0].record()
         vq_assign(h_dual, E, prep, cmask, beta=0.25, mode=mode, out=(zq, codes, loss))

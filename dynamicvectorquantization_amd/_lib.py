@@ -27,7 +27,7 @@ EXPORTS = (
     "dvq_version", "dvq_last_error_string", "dvq_codebook_prep_bytes", "dvq_codebook_prepare_f32",
     "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_fallback_count_offset",
     "dvq_embed_gather_f32",
-    "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_triple_f32",
+    "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
     "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
 
@@ -73,6 +73,8 @@ def _load():
     lib.dvq_entropy_gate_f32.argtypes = [vp, i64, f32, vp, vp]
     lib.dvq_route_select_dual_f32.restype = i32
     lib.dvq_route_select_dual_f32.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.dvq_route_select_dual_entropy_f32.restype = i32
+    lib.dvq_route_select_dual_entropy_f32.argtypes = [vp, f32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.dvq_route_select_triple_f32.restype = i32
     lib.dvq_route_select_triple_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.dvq_ema_accumulate_nchw_f32.restype = i32

@@ -31,9 +31,10 @@ size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
                              float *loss, hipStream_t st);
-int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
+int dvq_launch_route_select(int G, int gate_mode, const void *gate, const float *h_coarse,
                             const float *h_median, const float *h_fine, int B, int C, int hc, int wc,
-                            float *h_out, long long *indices, float *cmask, hipStream_t st);
+                            float *h_out, long long *indices, float *cmask, float thr, long long *gate_out,
+                            hipStream_t st);
 int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate, hipStream_t st);
 int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
                             hipStream_t st);
@@ -194,7 +195,20 @@ int dvq_route_select_dual_f32(const void *gate, int gate_dtype, const float *h_c
     if (rc) return rc;
     if (wc % 2 != 0) { dvq_set_error("dvq_route_select_dual_f32: wc=%d must be even (rows move as 16-byte pieces)", wc); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_route_select(2, gate_dtype == DVQ_GATE_I64, gate, h_coarse, nullptr, h_fine, B, C, hc, wc,
-                                          h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_dual");
+                                          h_out, (long long *)indices, cmask, 0.0f, nullptr, (hipStream_t)stream), "route_select_dual");
+}
+
+int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, const float *h_coarse,
+                                      const float *h_fine, int B, int C, int hc, int wc,
+                                      float *h_out, int64_t *indices, float *cmask, int64_t *gate_out,
+                                      void *stream)
+{
+    int rc = route_args_ok("dvq_route_select_dual_entropy_f32", entropy, DVQ_GATE_F32, h_coarse, h_fine, B, C, hc, wc, h_out, indices, cmask);
+    if (rc) return rc;
+    if (wc % 2 != 0) { dvq_set_error("dvq_route_select_dual_entropy_f32: wc=%d must be even (rows move as 16-byte pieces)", wc); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_route_select(2, 2, entropy, h_coarse, nullptr, h_fine, B, C, hc, wc,
+                                          h_out, (long long *)indices, cmask, threshold, (long long *)gate_out,
+                                          (hipStream_t)stream), "route_select_dual_entropy");
 }
 
 int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h_coarse,
@@ -205,7 +219,7 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype, const float *h
     if (rc) return rc;
     if (!h_median) { dvq_set_error("dvq_route_select_triple_f32: null h_median"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_route_select(3, gate_dtype == DVQ_GATE_I64, gate, h_coarse, h_median, h_fine, B, C, hc, wc,
-                                          h_out, (long long *)indices, cmask, (hipStream_t)stream), "route_select_triple");
+                                          h_out, (long long *)indices, cmask, 0.0f, nullptr, (hipStream_t)stream), "route_select_triple");
 }
 
 int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int D, int HW, int K,

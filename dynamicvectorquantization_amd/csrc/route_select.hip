@@ -10,11 +10,15 @@
 // 16 B, consecutive lanes consecutive addresses; LDS only holds the image's grain map (1 B / cell).
 #include "dvq_common.h"
 
-template <int G, bool I64>
-__device__ __forceinline__ int gate_argmax(const void *gate, size_t cell)
+// MODE 0: f32 gate logits, 1: int64 gate, 2: f32 entropy map + threshold (the fixed-entropy router fused in:
+// gate = [(ent <= thr), (ent > thr)], whose argmax is (ent > thr); NaN compares false twice -> 0)
+template <int G, int MODE>
+__device__ __forceinline__ int gate_argmax(const void *gate, size_t cell, float thr)
 {
     // torch.argmax semantics: first maximal value wins, NaN counts as the maximum
-    if (I64) {
+    if (MODE == 2) {
+        return (((const float *)gate)[cell] > thr) ? 1 : 0;
+    } else if (MODE == 1) {
         const long long *g = (const long long *)gate + cell * G;
         long long best = g[0];
         int bi = 0;
@@ -45,12 +49,13 @@ __device__ __forceinline__ int gate_argmax(const void *gate, size_t cell)
 constexpr int PLANES_PER_BLOCK = 8;
 constexpr int MAX_CELLS = 4096;                 // grain map bytes kept in LDS (64 x 64 coarse cells)
 
-template <int G, bool I64>
+template <int G, int MODE>
 __global__ __launch_bounds__(256) void route_select_kernel(
     const void *__restrict__ gate, const float *__restrict__ h_coarse,
     const float *__restrict__ h_median, const float *__restrict__ h_fine,
     int B, int C, int hc, int wc,
-    float *__restrict__ h_out, long long *__restrict__ indices, float *__restrict__ cmask)
+    float *__restrict__ h_out, long long *__restrict__ indices, float *__restrict__ cmask,
+    float thr, long long *__restrict__ gate_out)
 {
     constexpr int SC = (G == 2) ? 2 : 4;          // fine pixels per coarse cell edge
     __shared__ unsigned char grain[MAX_CELLS];
@@ -63,11 +68,11 @@ __global__ __launch_bounds__(256) void route_select_kernel(
     const bool in_lds = ncell <= MAX_CELLS;
     if (in_lds) {
         for (int cell = threadIdx.x; cell < ncell; cell += 256)
-            grain[cell] = (unsigned char)gate_argmax<G, I64>(gate, (size_t)b * ncell + cell);
+            grain[cell] = (unsigned char)gate_argmax<G, MODE>(gate, (size_t)b * ncell + cell, thr);
         __syncthreads();
     }
     auto grain_of = [&](int cell) -> int {
-        return in_lds ? (int)grain[cell] : gate_argmax<G, I64>(gate, (size_t)b * ncell + cell);
+        return in_lds ? (int)grain[cell] : gate_argmax<G, MODE>(gate, (size_t)b * ncell + cell, thr);
     };
     for (int p = p0; p < p1; ++p) {
         const size_t plane = (size_t)b * C + p;
@@ -90,6 +95,19 @@ __global__ __launch_bounds__(256) void route_select_kernel(
                 if (y % SC == 0) {
                     if (x % SC == 0) indices[(size_t)b * ncell + cell0] = g0;
                     if (cx1 != cx0) indices[(size_t)b * ncell + cell0 + 1] = g1;
+                    if (MODE == 2 && gate_out != nullptr) {        // the router's int64 gate, a by-product
+                        const float *ent = (const float *)gate + (size_t)b * ncell;
+                        if (x % SC == 0) {
+                            const float e = ent[cell0];
+                            longlong2 gg; gg.x = (e <= thr) ? 1 : 0; gg.y = (e > thr) ? 1 : 0;
+                            *(longlong2 *)(gate_out + 2 * ((size_t)b * ncell + cell0)) = gg;
+                        }
+                        if (cx1 != cx0) {
+                            const float e = ent[cell0 + 1];
+                            longlong2 gg; gg.x = (e <= thr) ? 1 : 0; gg.y = (e > thr) ? 1 : 0;
+                            *(longlong2 *)(gate_out + 2 * ((size_t)b * ncell + cell0 + 1)) = gg;
+                        }
+                    }
                 }
                 continue;
             }
@@ -165,19 +183,19 @@ static int grid_for(size_t items)
     return (int)blocks;
 }
 
-int dvq_launch_route_select(int G, int gate_i64, const void *gate, const float *h_coarse,
+int dvq_launch_route_select(int G, int gate_mode, const void *gate, const float *h_coarse,
                             const float *h_median, const float *h_fine, int B, int C, int hc, int wc,
-                            float *h_out, long long *indices, float *cmask, hipStream_t st)
+                            float *h_out, long long *indices, float *cmask, float thr, long long *gate_out,
+                            hipStream_t st)
 {
     dim3 grid((C + 1 + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK, B < 65535 ? B : 65535), block(256);
-    if (G == 2 && gate_i64)
-        hipLaunchKernelGGL((route_select_kernel<2, true>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
-    else if (G == 2)
-        hipLaunchKernelGGL((route_select_kernel<2, false>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
-    else if (gate_i64)
-        hipLaunchKernelGGL((route_select_kernel<3, true>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
-    else
-        hipLaunchKernelGGL((route_select_kernel<3, false>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask);
+#define DVQ_SEL(GG, MM) hipLaunchKernelGGL((route_select_kernel<GG, MM>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask, thr, gate_out)
+    if (G == 2 && gate_mode == 2) DVQ_SEL(2, 2);
+    else if (G == 2 && gate_mode == 1) DVQ_SEL(2, 1);
+    else if (G == 2) DVQ_SEL(2, 0);
+    else if (gate_mode == 1) DVQ_SEL(3, 1);
+    else DVQ_SEL(3, 0);
+#undef DVQ_SEL
     return (int)hipGetLastError();
 }
 

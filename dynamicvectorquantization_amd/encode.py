@@ -17,13 +17,16 @@ asynchronously under the next batch's kernels.
 import torch
 import torch.distributed as dist
 
-from .router import route_select_dual, route_select_triple
+from .router import DualGrainFixedEntropyRouter, route_select_dual, route_select_dual_entropy, route_select_triple
 
 
 def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0):
     """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode."""
-    gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
-    sel = route_select_dual(gate, h_coarse, h_fine)
+    if isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda:
+        sel = route_select_dual_entropy(entropy, router.fine_grain_threshold, h_coarse, h_fine)   # gate fused in
+    else:
+        gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
+        sel = route_select_dual(gate, h_coarse, h_fine)
     h = sel["h_dual"]
     if quant_conv is not None:
         h = quant_conv(h)

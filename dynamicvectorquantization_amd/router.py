@@ -77,6 +77,34 @@ def route_select_dual(gate, h_coarse, h_fine, out=None):
     return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
 
 
+def route_select_dual_entropy(entropy, threshold, h_coarse, h_fine, out=None):
+    """DualGrainFixedEntropyRouter.forward + the routing tail of DualGrainEncoder.forward in ONE kernel
+    (RouterDual.py:53-57 + EncoderDual.py:134-156): entropy [B, hc, wc] f32 -> the same dict as
+    route_select_dual, "gate" being the router's int64 gate permuted to [B, 2, hc, wc].
+    out = (h_dual, indices, codebook_mask, gate[B, hc, wc, 2] int64) to reuse buffers."""
+    entropy = _lib.require_cuda_f32(entropy, "entropy")
+    h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
+    h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
+    B, C, hc, wc = h_coarse.shape
+    if tuple(h_fine.shape) != (B, C, 2 * hc, 2 * wc) or tuple(entropy.shape) != (B, hc, wc):
+        raise ValueError("shape mismatch: entropy %s h_coarse %s h_fine %s" %
+                         (tuple(entropy.shape), tuple(h_coarse.shape), tuple(h_fine.shape)))
+    if out is not None:
+        h_dual, indices, cmask, gate = out
+    else:
+        h_dual = torch.empty_like(h_fine)
+        indices = torch.empty((B, hc, wc), dtype=torch.int64, device=h_fine.device)
+        cmask = torch.empty((B, 1, 2 * hc, 2 * wc), dtype=torch.float32, device=h_fine.device)
+        gate = torch.empty((B, hc, wc, 2), dtype=torch.int64, device=h_fine.device)
+    if h_dual.numel() > 0:
+        with torch.cuda.device(h_fine.device):
+            _lib.check(_lib_handle.dvq_route_select_dual_entropy_f32(
+                entropy.data_ptr(), float(threshold), h_coarse.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
+                h_dual.data_ptr(), indices.data_ptr(), cmask.data_ptr(), gate.data_ptr(),
+                _lib.stream_ptr(h_fine.device)), "dvq_route_select_dual_entropy_f32")
+    return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
+
+
 def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
     """gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
     -> dict(h_triple, indices, codebook_mask, gate) as TripleGrainEncoder.forward (EncoderTriple.py:178-183);

@@ -116,6 +116,13 @@ int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
  *   gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
  *   cmask values 0.0625 / 0.25 / 1.0
  */
+/* The fixed-entropy router (RouterDual.py:46-57) fused into the dual select: entropy [B, hc, wc] f32,
+ * gate = [(entropy <= threshold), (entropy > threshold)]; outputs as dvq_route_select_dual_f32 plus,
+ * if gate_out != NULL, the router's int64 gate [B, hc, wc, 2] (DualGrainEncoder returns it). */
+int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, const float *h_coarse,
+                                      const float *h_fine, int B, int C, int hc, int wc,
+                                      float *h_out, int64_t *indices, float *cmask, int64_t *gate_out,
+                                      void *stream);
 int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 const float *h_coarse, const float *h_median,
                                 const float *h_fine, int B, int C, int hc, int wc,

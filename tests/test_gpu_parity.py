@@ -499,3 +499,25 @@ def test_empty_batch(dev):
     assert gate.shape == (0, 4, 4, 2) and gate.dtype == torch.int64
     out = route_select_dual(gate, torch.empty((0, 64, 4, 4), device=dev), z)
     assert out["h_dual"].shape == (0, 64, 8, 8) and out["indices"].shape == (0, 4, 4)
+
+
+def test_route_select_dual_entropy_fused(dev, oracle_mod):
+    """entropy router fused into the select kernel == entropy_gate + route_select_dual == oracle, incl. NaN / threshold ties"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import entropy_gate, route_select_dual, route_select_dual_entropy
+    B, Cc, hc_, wc_ = 3, 40, 6, 8
+    thr = 1.6777750253677368
+    ent = synth.entropy_map(881, B, hc_, wc_)
+    ent[0, 0, 0] = np.float32(thr); ent[0, 0, 1] = np.nan; ent[1, 2, 3] = np.inf; ent[2, 5, 7] = -np.inf
+    hc, hf = synth.features(882, B, Cc, hc_, wc_), synth.features(883, B, Cc, 2 * hc_, 2 * wc_)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    fused = route_select_dual_entropy(t(ent), thr, t(hc), t(hf))
+    gate = entropy_gate(t(ent), thr)
+    ref = route_select_dual(gate, t(hc), t(hf))
+    for k in ("h_dual", "indices", "codebook_mask"):
+        assert torch.equal(fused[k], ref[k]), k
+    assert torch.equal(fused["gate"], gate.permute(0, 3, 1, 2)) and fused["gate"].dtype == torch.int64
+    og = oracle_mod.entropy_gate(ent, thr)
+    o = oracle_mod.route_select_dual(og, hc, hf)
+    for k in ("h_dual", "indices", "codebook_mask"):
+        assert np.array_equal(fused[k].cpu().numpy(), o[k]), k
