@@ -21,6 +21,9 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, int iters)
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc1, 0, 0, 0);
             }
+        } else if (KIND == 2) {                       // ONE dependent accumulator chain
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 64; ++u) v = __builtin_fmaf(v, 1.0001f, 0.5f);
@@ -34,28 +37,31 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, int iters)
     if (acc0[0] + acc1[3] + v == 12345.678f) out[0] = 0;
 }
 
-int main()
+#include <cstdlib>
+int main(int argc, char **argv)
 {
     const int blocks = 2048, iters = 20000;
+    const int wgs = argc > 1 ? atoi(argv[1]) : 2048;   // kind 2: 256 = one wave per SIMD, 512 = two, ...
     unsigned long long *d, *h = new unsigned long long[2 * blocks];
     hipMalloc(&d, sizeof(unsigned long long) * 2 * blocks);
-    for (int kind = 0; kind < 2; ++kind) {
+    for (int kind = 0; kind < 3; ++kind) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             if (kind == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, d, iters);
+            else if (kind == 2) hipLaunchKernelGGL(probe<2>, dim3(wgs), dim3(256), 0, 0, d, iters);
             else hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d, iters);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(h, d, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
             double sc = 0, rc = 0;
-            for (int i = 0; i < blocks; ++i) { sc += h[2 * i]; rc += h[2 * i + 1]; }
+            for (int i = 0; i < (kind == 2 ? wgs : blocks); ++i) { sc += h[2 * i]; rc += h[2 * i + 1]; }
             double ghz = sc / rc * 0.1;
-            double mfma_per_simd = (double)blocks * 4 /*waves*/ * iters * 16.0 / 1024.0;
-            printf("%s rep %d: %.2f ms, memtime/memrealtime -> %.3f GHz (if memtime ticks at shader clock)", kind == 0 ? "mfma" : "valu", rep, ms, ghz);
-            if (kind == 0) printf(", %.1f ns per MFMA per SIMD = %.2f GHz at 32 cycles/MFMA", ms * 1e6 / mfma_per_simd, 32.0 / (ms * 1e6 / mfma_per_simd));
+            double mfma_per_simd = (double)(kind == 2 ? wgs : blocks) * 4 /*waves*/ * iters * 16.0 / 1024.0;
+            printf("%s rep %d: %.2f ms, memtime/memrealtime -> %.3f GHz (if memtime ticks at shader clock)", kind == 0 ? "mfma 2 chains" : (kind == 2 ? "mfma 1 chain " : "valu"), rep, ms, ghz);
+            if (kind != 1) printf(", %.1f ns per MFMA per SIMD = %.2f GHz at 32 cycles/MFMA", ms * 1e6 / mfma_per_simd, 32.0 / (ms * 1e6 / mfma_per_simd));
             printf("\n");
         }
     }
