@@ -59,6 +59,9 @@ static constexpr float PACK_E = 1.93e-6f;         // 2^-19 (1 + margin)
 static constexpr float REF_XN = 1.2e-7f;          // 2u
 static constexpr float REF_RE = 1.6e-5f;          // u + gamma_256 (D <= 256)
 static constexpr float DVQ_SEED_PAD = -3.0e38f;
+#ifndef DVQ_WIDE_MIN_K
+#define DVQ_WIDE_MIN_K 8192      // codebook size from which pass 1 takes the two-blocks-per-wave form (A/B: +8 % at 16384, none at 4096)
+#endif
 static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per workgroup
 static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup
 
@@ -508,6 +511,318 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// pass 1, large codebooks ("wide" form, D = 256): a wave scores TWO blocks of 32 tokens against every
+// code tile, so each A fragment read from LDS feeds two MFMAs and the ring DMA / barrier per tile are
+// amortised over 32 MFMAs instead of 16.  There is no room left for the fp32 copy of z (the two blocks'
+// fp16 fragments take 128 VGPRs): z is read again in the epilogue -- 2 KiB per token next to the
+// >= 2 MiB of codebook every token is scored against.  Same top-2 tracking, same bound, same queue,
+// records and outputs as vq_assign_filter_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, int nparts_pass1)
+{
+    constexpr int NW = 4;
+    constexpr int S16 = D / 16;
+    static_assert(S16 == 16, "the wide form is written for D = 256");
+    constexpr int IMG_BYTES = S16 * 1024;
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;
+    constexpr int CPW = (S16 + NW - 1) / NW;
+    constexpr int PER_TILE = CPW + 1;
+    constexpr int NBUF = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int T = dvq_num_tiles(K);
+    const float sB = meta->scale_b;
+
+    auto issue_piece = [&](int t, int q) {
+        const int tt = (t < T) ? t : T - 1;
+        const char *src = img + (size_t)tt * TILE_STRIDE;
+        if (q < CPW) {
+            int chunk = wave * CPW + q;
+            glds16(src + chunk * 1024 + lane * 16, lds + (t & (NBUF - 1)) * IMG_BYTES + chunk * 1024);
+        } else {
+            glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
+        }
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    int nn[2];                                               // token of this lane in block u, -1 = past the end
+    size_t zbase[2];                                         // element offset of its channel 8h
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long n_raw = ((long)tile_id * NW + wave) * 64 + 32 * u + c;
+        nn[u] = (n_raw < N) ? (int)n_raw : -1;
+        const long q = (nn[u] >= 0) ? nn[u] : N - 1;
+        const long bimg = q / HW;
+        zbase[u] = ((size_t)bimg * D + 8 * h) * HW + (size_t)(q - bimg * HW);
+    }
+
+    // ---- prologue: per block, z in batches of four k-steps -> fp16 fragments, exact-order norm, bound
+    f16x8 zh[2][S16];
+    float xn[2], thr2W[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float *zp = z + zbase[u];
+        float pa[2][8];
+        float amax = 0.0f, zeta2 = 0.0f;
+        const float *zpb = zp;                              // advances by four k-steps per batch
+#pragma unroll
+        for (int sb = 0; sb < S16; sb += 4) {
+            float zf[4][8];
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zf[q][j] = DVQ_LOAD_Z(zpb + (size_t)(16 * q + j) * HW);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = sb + q;
+                u32x4 packed;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const float v0 = zf[q][2 * j2], v1 = zf[q][2 * j2 + 1];
+                    const float q0 = sq_rn(v0), q1 = sq_rn(v1);
+                    pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
+                    pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
+                    amax = vmax_abs(amax, v0);
+                    amax = vmax_abs(amax, v1);
+                    f32x2 vv = {v0, v1};
+                    f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    packed[j2] = __builtin_bit_cast(unsigned, hh);
+                    const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];     // exact
+                    zeta2 = __builtin_fmaf(r0, r0, zeta2);
+                    zeta2 = __builtin_fmaf(r1, r1, zeta2);
+                }
+                zh[u][s] = __builtin_bit_cast(f16x8, packed);
+            }
+            // one batch of 32 loads at a time (register budget): the next batch's addresses depend,
+            // opaquely, on this batch's last converted fragment
+            zpb += (size_t)64 * HW;
+            asm volatile("" : "+v"(zpb) : "v"(zh[u][sb + 3]));
+        }
+        float t8[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
+            float a0_ = h == 0 ? pa[0][l] : o0;
+            float a1_ = h == 0 ? o0 : pa[0][l];
+            float a2_ = h == 0 ? pa[1][l] : o1;
+            float a3_ = h == 0 ? o1 : pa[1][l];
+            t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0_, a1_), a2_), a3_);
+        }
+        float x = t8[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) x = __fadd_rn(x, t8[l]);
+        xn[u] = x;
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        zeta2 += __shfl_xor(zeta2, 32);
+        const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
+        const bool bad = !(x < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok
+                         || !((0.5f * sB * enmax) < 1.0e37f);
+        const float zeta = sqrtf(zeta2) * 1.001f;
+        const float Rh = sqrtf(x) * 1.00001f;
+        const float zn_ = Rh + zeta;
+        const float ehn = sB * emax + etamax;
+        float Wv = zeta * ehn + zn_ * etamax
+                   + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
+                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
+                   + sB * (REF_XN * (x + enmax) + REF_RE * Rh * emax);
+        thr2W[u] = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+    }
+    const float seed_scale = -0.5f * sB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
+
+    // ---- code loop: 32 MFMAs per tile and wave, every A fragment used for both token blocks
+    float m1[2] = {-__builtin_inff(), -__builtin_inff()}, m2[2] = {-__builtin_inff(), -__builtin_inff()};
+    int t1[2] = {0, 0};
+    for (int t = 0; t < T; ++t) {
+        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc0[4 * g + q] = e4[q]; acc1[4 * g + q] = e4[q]; }
+        }
+        if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
+        asm volatile("" ::: "memory");
+        const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                    lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+        f16x8 a0, a1, a2, a3;
+        asm volatile("" : "+v"(acc0), "+v"(acc1));
+        __builtin_amdgcn_sched_barrier(0);
+#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+#define DVQ_MM2(src, S, WAIT, NEXT)                                                     \
+        asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[0][S], acc0, 0, 0, 0);    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[1][S], acc1, 0, 0, 0);    \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
+        NEXT
+        DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+        __builtin_amdgcn_s_setprio(1);
+        DVQ_MM2(a0, 0, 3, ) DVQ_MM2(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM2(a2, 2, 3, ) DVQ_MM2(a3, 3, 3, )
+        DVQ_MM2(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM2(a1, 5, 3, ) DVQ_MM2(a2, 6, 3, ) DVQ_MM2(a3, 7, 3, issue_piece(t + 3, 2);)
+        DVQ_MM2(a0, 8, 3, ) DVQ_MM2(a1, 9, 3, ) DVQ_MM2(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM2(a3, 11, 3, )
+        DVQ_MM2(a0, 12, 3, ) DVQ_MM2(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM2(a2, 14, 1, ) DVQ_MM2(a3, 15, 0, )
+#undef DVQ_MM2
+#undef DVQ_RD
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float om = m1[u];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = u == 0 ? acc0[r] : acc1[r], v1 = u == 0 ? acc0[r + 1] : acc1[r + 1];
+                float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
+                float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+                float md = __builtin_amdgcn_fmed3f(m1[u], g0, g1);
+                m1[u] = vmax3_raw(m1[u], g0, g1);
+                m2[u] = vmax_raw(m2[u], md);
+            }
+            t1[u] = (m1[u] != om) ? t : t1[u];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+
+    // ---- decisions for both blocks, one queue atomic per wave
+    int code[2];
+    float thr[2];
+    bool undecided[2], hopeless[2], valid[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float o1 = __shfl_xor(m1[u], 32), o2 = __shfl_xor(m2[u], 32);
+        const int ot = __shfl_xor(t1[u], 32);
+        const bool other_wins = (o1 > m1[u]) || (o1 == m1[u] && h == 1);
+        const float best = other_wins ? o1 : m1[u];
+        const float second = fmaxf(other_wins ? m1[u] : o1, fmaxf(m2[u], o2));
+        const int wt = other_wins ? ot : t1[u];
+        const int wh = other_wins ? (h ^ 1) : h;
+        const int r = (int)(__float_as_uint(best) & 15u);
+        code[u] = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
+        thr[u] = best - thr2W[u];
+        const bool final_ok = (best - second) > thr2W[u];
+        valid[u] = nn[u] >= 0;
+        hopeless[u] = !(code[u] < K) || !(thr[u] == thr[u]);
+        undecided[u] = valid[u] && !hopeless[u] && !final_ok;
+    }
+    const unsigned long long um0 = __ballot(undecided[0] && h == 0), um1 = __ballot(undecided[1] && h == 0);
+    const int shard = blockIdx.x & (DVQ_QSHARDS - 1);
+    int slot_raw = 0;
+    const int nund = (int)__popcll(um0) + (int)__popcll(um1);
+    if (nund != 0 && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], nund);
+    int slot[2] = {-1, -1};
+    if (nund != 0) {                                        // wave-uniform
+        const int base = __shfl(slot_raw, 0);
+        const unsigned long long lt = (1ull << c) - 1ull;
+        slot[0] = undecided[0] ? base + (int)__popcll(um0 & lt) : -1;
+        slot[1] = undecided[1] ? base + (int)__popcll(um0) + (int)__popcll(um1 & lt) : -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (slot[u] >= rec_cap) { hopeless[u] = true; slot[u] = -1; }     // shard full -> exact list
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (valid[u] && hopeless[u] && h == 0) {
+            int pos = atomicAdd(&counters[1], 1);
+            exact_list[pos] = nn[u];
+        }
+
+    // ---- epilogue per block: z again, chosen codebook row, z_q, loss term, record of a queued token
+    float lsum = 0.0f;
+    auto epilogue = [&](const int n, const bool active, const int cd, const size_t zb, const int sl,
+                        const float xnu, const float thru) {
+        if (!active) return;
+        if (h == 0) codes[n] = (long long)cd;
+        const float *zp = z + zb;
+        const float *ep = E + (size_t)cd * D + 8 * h;
+        const float m = (mask != nullptr) ? mask[n] : 1.0f;
+        char *rec = (sl >= 0) ? records + ((size_t)shard * rec_cap + sl) * rec_bytes(D) : nullptr;
+        auto finish = [&](auto store_tag) {
+            constexpr bool STORE = decltype(store_tag)::value;
+            float *zqp = STORE ? zq + zb : nullptr;
+            const float *zpe = zp, *epe = ep;                // advance by two k-steps per batch
+#pragma unroll
+            for (int s0 = 0; s0 < S16; s0 += 2) {
+                float zf[2][8];
+                f32x4 eg[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) zf[q][j] = DVQ_LOAD_Z(zpe + (size_t)(16 * q + j) * HW);
+                    eg[q][0] = *(const f32x4 *)(epe + 16 * q);
+                    eg[q][1] = *(const f32x4 *)(epe + 16 * q + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int s = s0 + q;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float e = eg[q][j >> 2][j & 3];
+                        float diff = __fsub_rn(e, zf[q][j]);
+                        if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[q][j], diff));
+                        lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                    }
+                    if (rec != nullptr) {
+                        f32x4 lo = {zf[q][0], zf[q][1], zf[q][2], zf[q][3]};
+                        f32x4 hi = {zf[q][4], zf[q][5], zf[q][6], zf[q][7]};
+                        *(f32x4 *)(rec + (16 * s + 8 * h) * 4) = lo;
+                        *(f32x4 *)(rec + (16 * s + 8 * h + 4) * 4) = hi;
+                    }
+                }
+                zpe += (size_t)32 * HW;
+                epe += 32;
+                asm volatile("" : "+v"(zpe), "+v"(epe) : "v"(lsum));     // next batch's loads wait for this one
+            }
+        };
+        if (zq != nullptr) finish(std::true_type{});
+        else finish(std::false_type{});
+        if (rec != nullptr && h == 0) {
+            RecMeta rm;
+            rm.n = n; rm.xn = xnu; rm.thr = thru; rm.seed_scale = seed_scale; rm.prov = cd;
+            rm.best = ~0ull; rm.pad = 0;
+            *(RecMeta *)(rec + (size_t)D * 4) = rm;
+        }
+    };
+    epilogue(nn[0], valid[0] && !hopeless[0], code[0], zbase[0], slot[0], xn[0], thr[0]);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue(nn[1], valid[1] && !hopeless[1], code[1], zbase[1], slot[1], xn[1], thr[1]);
+    if (partials != nullptr) {
+        double dsum = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        __syncthreads();
+        double *red = (double *)lds;
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) {                                     // this grid is half the standard one: fill both slots
+            partials[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (2 * (int)blockIdx.x + 1 < nparts_pass1) partials[2 * blockIdx.x + 1] = 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // resolver: queued tokens, RES_SLOTS (= 32, one MFMA column set) per workgroup.  The queue is short
 // (a few % of the tokens), so the work is spread for LATENCY: the four waves of a workgroup share
 // the same 32 tokens and each takes every fourth code tile, reading its A fragments straight from
@@ -807,8 +1122,21 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
     dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
     const int nb1 = (int)((N + 127) / 128);
-    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                       E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
+    if constexpr (D == 256) {
+        if (K >= DVQ_WIDE_MIN_K) {                           // large codebook: two token blocks per wave
+            static unsigned long long done_w = 0;
+            dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
+            hipLaunchKernelGGL(vq_assign_filter_wide_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), shmem1, st,
+                               z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records,
+                               cap / DVQ_QSHARDS, nb1);
+        } else {
+            hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                               E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
+        }
+    } else {
+        hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
+    }
     if (pass1_only) return (int)hipGetLastError();
     const int nslice = resolver_slices(K);
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS, nslice), dim3(256), 0, st, img, meta,

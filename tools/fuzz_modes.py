@@ -9,6 +9,10 @@ from dynamicvectorquantization_amd import synth, _lib
 from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
 
 
+KS = [int(k) for k in os.environ["FUZZ_KS"].split(",")] if os.environ.get("FUZZ_KS") else \
+     [1, 7, 31, 32, 33, 100, 256, 1000, 1024, 2048, 4096, 4096, 8192]      # >= 8192 takes the wide pass-1 kernel at D = 256
+
+
 def run(ncases=150, seed=12345, verbose=True):
   dev = torch.device("cuda:0")
   rng = np.random.default_rng(seed)
@@ -16,7 +20,7 @@ def run(ncases=150, seed=12345, verbose=True):
   stats = []
   for case in range(ncases):
       D = int(rng.choice([64, 128, 256, 256, 256]))
-      K = int(rng.choice([1, 7, 31, 32, 33, 100, 256, 1000, 1024, 2048, 4096]))
+      K = int(rng.choice(KS))
       B = int(rng.choice([1, 2, 3, 8])); H = int(rng.choice([1, 3, 8, 16, 32])); W = int(rng.choice([1, 5, 8, 16, 32]))
       kind = rng.choice(["trained", "default", "mixed", "dups", "tiny", "huge"])
       E = synth.codebook_trained(K, D, seed=int(rng.integers(1 << 30)))

@@ -6,7 +6,7 @@ dev = torch.device("cuda:0")
 for K in (1024, 4096, 16384):
     E = synth.codebook_trained(K, 256)
     Et = torch.from_numpy(E).to(dev)
-    z = torch.from_numpy(synth.z_tokens(E, 64, 32, 32, 2005)).to(dev)
+    z = torch.from_numpy(synth.z_tokens(E, int(os.environ.get("KS_B", "64")), 32, 32, 2005)).to(dev)
     p = _CodebookPrep()
     for _ in range(3): vq_assign(z, Et, p, None, mode=_lib.MODE_FILTER_PASS1, want_loss=False)
     torch.cuda.synchronize()
