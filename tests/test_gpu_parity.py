@@ -521,3 +521,22 @@ def test_route_select_dual_entropy_fused(dev, oracle_mod):
     o = oracle_mod.route_select_dual(og, hc, hf)
     for k in ("h_dual", "indices", "codebook_mask"):
         assert np.array_equal(fused[k].cpu().numpy(), o[k]), k
+
+
+def test_wide_kernel_codes_only_and_ragged(dev):
+    """K >= 8192 takes the two-blocks-per-wave pass-1 kernel: codes-only call (no z_q, no loss) and a token
+    count that is not a multiple of 64 agree with the exact mode"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    K, D = 8192, 256
+    E = synth.codebook_trained(K, D, seed=31)
+    Et = torch.from_numpy(E).to(dev)
+    z = torch.from_numpy(synth.z_tokens(E, 3, 7, 11, 4321)).to(dev)            # N = 231 tokens
+    pe, pf = _CodebookPrep(), _CodebookPrep()
+    _, c0, _ = vq_assign(z, Et, pe, None, want_zq=False, want_loss=False, mode=_lib.MODE_EXACT)
+    _, c1, _ = vq_assign(z, Et, pf, None, want_zq=False, want_loss=False, mode=_lib.MODE_FILTER)
+    assert torch.equal(c0, c1)
+    zq0, c2, l0 = vq_assign(z, Et, pe, None, mode=_lib.MODE_EXACT)
+    zq1, c3, l1 = vq_assign(z, Et, pf, None, mode=_lib.MODE_FILTER)
+    assert torch.equal(c2, c3) and torch.equal(zq0, zq1) and torch.equal(c0, c2)
+    assert abs(float(l0[1]) - float(l1[1])) <= 1e-6 * abs(float(l0[1]))
