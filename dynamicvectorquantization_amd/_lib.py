@@ -19,6 +19,7 @@ DVQ_OK = 0
 MODE_EXACT = 0
 MODE_FILTER = 1
 MODE_FILTER_PASS1 = 2   # profiling aid: only the dominant filter kernel
+MODE_FILTER_WIDE = 3    # testing aid: force the two-blocks-per-wave pass-1 kernel (D = 256)
 GATE_F32 = 0
 GATE_I64 = 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2

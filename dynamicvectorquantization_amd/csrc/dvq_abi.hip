@@ -26,7 +26,7 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      hipStream_t st);
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, float *loss, float beta, hipStream_t st);
+                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta, hipStream_t st);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
@@ -107,7 +107,7 @@ size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode)
     if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) return 0;
     long N = (long)B * HW;
     size_t partials = partials_bytes_for(N);
-    size_t extra = (mode == DVQ_MODE_FILTER || mode == DVQ_MODE_FILTER_PASS1) ? dvq_filter_ws_extra_bytes(D, HW, K, N) : 0;
+    size_t extra = (mode == DVQ_MODE_FILTER || mode == DVQ_MODE_FILTER_PASS1 || mode == DVQ_MODE_FILTER_WIDE) ? dvq_filter_ws_extra_bytes(D, HW, K, N) : 0;
     return partials + extra + 256;
 }
 
@@ -128,7 +128,8 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_vq_assign_nchw_f32: B=%d HW=%d K=%d must be positive", B, HW, K); return DVQ_EINVAL; }
     if (!dim_ok(D)) { dvq_set_error("dvq_vq_assign_nchw_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
-    if (pass1_only) mode = DVQ_MODE_FILTER;
+    const bool force_wide = (mode == DVQ_MODE_FILTER_WIDE);
+    if (pass1_only || force_wide) mode = DVQ_MODE_FILTER;
     if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("dvq_vq_assign_nchw_f32: unknown mode %d", mode); return DVQ_EINVAL; }
     if ((size_t)B * HW * D >= ((size_t)1 << 40)) { dvq_set_error("dvq_vq_assign_nchw_f32: tensor too large"); return DVQ_EUNSUPPORTED; }
     const long N = (long)B * HW;
@@ -145,7 +146,7 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                               (char *)ws + partials_bytes, pass1_only, loss, beta, st);
+                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, st);
         return hip_rc(rc, "vq_assign_filter");     // the loss finalize is fused into its last kernel
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,

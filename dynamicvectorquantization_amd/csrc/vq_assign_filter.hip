@@ -1116,14 +1116,15 @@ template <int D>
 static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
                          const float *E, const float *mask, int HW, int K, long N, float *zq,
                          long long *codes, double *partials, int *counters, int *exact_list,
-                         char *records, int cap, bool pass1_only, int *chunk_sync, hipStream_t st)
+                         char *records, int cap, bool pass1_only, bool force_wide, int *chunk_sync, hipStream_t st)
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
     dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
     const int nb1 = (int)((N + 127) / 128);
     if constexpr (D == 256) {
-        if (K >= DVQ_WIDE_MIN_K) {                           // large codebook: two token blocks per wave
+        if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
+                                                             // with two 256-token workgroups: two blocks per wave
             static unsigned long long done_w = 0;
             dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
             hipLaunchKernelGGL(vq_assign_filter_wide_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), shmem1, st,
@@ -1147,7 +1148,7 @@ static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta
 
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, float *loss, float beta, hipStream_t st)
+                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta, hipStream_t st)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
@@ -1166,9 +1167,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
                        resolver_slices(K) > 1 ? cap / RES_SLOTS * 2 : 0);
     int rc;
     switch (D) {
-    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
-    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
-    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, chunk_sync, st); break;
+    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
+    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
+    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;

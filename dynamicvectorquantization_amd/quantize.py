@@ -63,7 +63,7 @@ class _CodebookPrep:
         if self.ws_key is None:
             return (0, 0)
         B, D, HW, K, mode, _dev = self.ws_key
-        if mode not in (_lib.MODE_FILTER, _lib.MODE_FILTER_PASS1):
+        if mode not in (_lib.MODE_FILTER, _lib.MODE_FILTER_PASS1, _lib.MODE_FILTER_WIDE):
             return (0, 0)
         off = _lib_handle.dvq_vq_assign_fallback_count_offset(B, D, HW, K)
         c = self.ws[off:off + 8].view(torch.int32).tolist()

@@ -524,14 +524,14 @@ def test_route_select_dual_entropy_fused(dev, oracle_mod):
 
 
 def test_wide_kernel_codes_only_and_ragged(dev):
-    """K >= 8192 takes the two-blocks-per-wave pass-1 kernel: codes-only call (no z_q, no loss) and a token
-    count that is not a multiple of 64 agree with the exact mode"""
+    """K >= 8192 with >= 131072 tokens takes the two-blocks-per-wave pass-1 kernel: codes-only call (no z_q,
+    no loss) and a token count that is not a multiple of 64 agree with the exact mode"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
     K, D = 8192, 256
     E = synth.codebook_trained(K, D, seed=31)
     Et = torch.from_numpy(E).to(dev)
-    z = torch.from_numpy(synth.z_tokens(E, 3, 7, 11, 4321)).to(dev)            # N = 231 tokens
+    z = torch.from_numpy(synth.z_tokens(E, 131, 31, 33, 4321)).to(dev)         # N = 134013 tokens (odd)
     pe, pf = _CodebookPrep(), _CodebookPrep()
     _, c0, _ = vq_assign(z, Et, pe, None, want_zq=False, want_loss=False, mode=_lib.MODE_EXACT)
     _, c1, _ = vq_assign(z, Et, pf, None, want_zq=False, want_loss=False, mode=_lib.MODE_FILTER)
