@@ -60,7 +60,7 @@ static constexpr float REF_XN = 1.2e-7f;          // 2u
 static constexpr float REF_RE = 1.6e-5f;          // u + gamma_256 (D <= 256)
 static constexpr float DVQ_SEED_PAD = -3.0e38f;
 #ifndef DVQ_WIDE_MIN_K
-#define DVQ_WIDE_MIN_K 8192      // codebook size from which pass 1 takes the two-blocks-per-wave form (A/B: +8 % at 16384, none at 4096)
+#define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
 static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per workgroup
 static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup

@@ -41,7 +41,7 @@ extern "C" {
 
 #define DVQ_MODE_FILTER_PASS1 2  /* profiling aid: ONLY the fp16 filter kernel of DVQ_MODE_FILTER (the      */
 #define DVQ_MODE_FILTER_WIDE 3   /* testing aid: DVQ_MODE_FILTER with the two-blocks-per-wave pass-1 kernel     */
-                                 /* forced (D = 256); normally chosen automatically for K >= 8192 and           */
+                                 /* forced (D = 256); normally chosen automatically for K >= 2048 and           */
                                  /* >= 131072 tokens.  Same output.                                              */
                                 /* dominant kernel); queued tokens keep their provisional code, the loss   */
                                 /* is not finalised.  Not a production mode.                               */
