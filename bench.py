@@ -33,11 +33,14 @@ FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = fp32 vect
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
+    ap.add_argument("--spinup", type=int, default=100,
+                    help="untimed steps before the warmup that bring the GPU out of its idle power state "
+                         "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -172,6 +175,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(a.spinup):              # clock / power-state ramp, see --spinup
+        step()
     for _ in range(a.warmup):
         step()
     fence()
@@ -232,7 +237,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, "
                                    "K=%d, entropy gate + dual route select + VectorQuantize2 assign "
                                    "(quant_conv not in the path)" % (B, K),
-                       "global_batch": B * world, "assign_mode": a.mode,
+                       "global_batch": B * world, "assign_mode": a.mode, "spinup_steps": a.spinup,
                        "parallelism": "image-parallel x%d, RCCL all-gather of codes" % world},
             "roofline": roof,
         }
