@@ -1,33 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the DQ-VAE vector-quantization hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch that is already resident in HBM:
-    entropy-threshold gate + dual-granularity route select (+ codebook_mask), fused in one kernel
-    -> VQ nearest-codebook assignment (codes, z_q, masked commitment loss)
-on BASELINE.json configs[2] (dqvae-entropy-dual-r05: B=256 per GPU, 32x32x256 latents, K=1024).
-The 1x1 quant_conv between select and VQ is a vendor GEMM outside the path
-and is not run.  With N > 1 ranks every rank encodes its own 256 images (weak scaling) and the
-step ends by launching the (single, packed) RCCL all-gather of the emitted code / grain indices and
-the loss pair; that exchange runs asynchronously under the next step's kernels and every exchange
-is waited for and unpacked inside the timed region.
+One "step" = one pass of the hot path over one batch that is already resident in HBM.
 
-Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+  --scaling weak   (default; BASELINE configs[2], dqvae-entropy-dual-r05): every rank encodes its own
+                   B = 256 images: entropy-threshold gate + dual-granularity routing + VectorQuantize2
+                   assignment (codes, z_q, codebook_mask, grain indices, masked commitment loss).
+  --scaling strong (BASELINE configs[3], triple granularity F = 32/16/8): a fixed global batch of 1024
+                   images is split over the ranks (128 per GPU at N = 8): fused feature-router gate +
+                   triple routing + assignment.
+
+The 1x1 quant_conv between select and VQ is a vendor GEMM outside the path and
+is not run.  With N > 1 ranks the step ends by launching the single packed RCCL all-gather of the emitted
+code / grain indices and the loss pair; it runs asynchronously under the next step's kernels and every
+exchange is waited for and unpacked inside the timed region.
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line (rank 0).
+`--gpus N` with no RANK in the environment makes this process a launcher: it starts N fresh rank
+processes (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything touches a GPU, relays rank 0's
+JSON line and exits non-zero if any rank fails.  Under `python -m torch.distributed.run` (RANK set) it is
+a rank.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+THR_R05 = 1.6777750253677368   # imagenet_train JSON, key "50" (fine ratio 0.5)
 
 
 def parse():
@@ -35,15 +42,61 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="weak: images per GPU (default 256); strong: GLOBAL batch (default 1024)")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
+    ap.add_argument("--path", choices=["routed", "select"], default="routed",
+                    help="routed: one assign op straight from the encoder branches (unique tokens, no h_dual); "
+                         "select: route-select kernel writing h_dual, then the dense assign (round-1 path)")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, started before this process has made any GPU call
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(a):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 600
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs) or line is None:
+        print("bench.py launcher: rank exit codes %s%s" % (rcs, "" if line else ", no JSON line from rank 0"),
+              file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def usable_cpus():
@@ -65,48 +118,312 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(E, B_gpu, target_s):
-    """the oracle (explicit-order C restatement of what the reference's torch-CPU path computes)
-    timed on this box's host cores on a bounded sample of the same workload"""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the oracle C port, and the reference's torch-CPU op sequence
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(E, target_s):
+    """two legs on a bounded sample of the weak-scaling workload (gate + select + VQ assign):
+    (1) the oracle: explicit-order C restatement (OpenMP + AVX2) of what the reference computes;
+    (2) the reference's own op sequence as torch-CPU ops (addmm + argmin + embedding gather + masked loss,
+        quantize2_mask.py:39-46,53,131,172-182; EncoderDual.py:134-149), own code, MKL underneath --
+        this is what the reference actually executes and is ~3x slower than (1)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
     from dynamicvectorquantization_amd import synth
     from oracle import oracle
     oracle.build()
     cores = usable_cpus()
     try:
-        import ctypes
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)      # the oracle's OpenMP team
     except Exception:
         pass
-    nb = min(B_gpu, 64)
+    nb = 64
     hf = synth.z_tokens(E, nb, 32, 32, 2903)
     hc = synth.z_tokens(E, nb, 16, 16, 2913)
     ent = synth.entropy_map(5903, nb, 16, 16)
-
     # preallocated outputs, like the GPU step (fresh 64-MB numpy arrays would page-fault on every pass)
     o_sel = (np.empty_like(hf), np.empty((nb, 16, 16), np.int64), np.empty((nb, 1, 32, 32), np.float32))
     o_vq = (np.empty_like(hf), np.empty((nb, 1024), np.int64))
 
     def one_pass():
-        gate = oracle.entropy_gate(ent, 1.6777750253677368)
+        gate = oracle.entropy_gate(ent, THR_R05)
         sel = oracle.route_select_dual(gate, hc, hf, out=o_sel)
         oracle.vq_assign_nchw(sel["h_dual"], E, sel["codebook_mask"], out=o_vq)
 
-    one_pass()                                                   # warm (page-in, OpenMP team)
-    reps, t0 = 0, time.perf_counter()
-    while True:                                                  # repeat the sample for ~target_s
-        one_pass()
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_s or reps >= 10000:
-            break
-    return {"value": nb * reps / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d passes over %d images of the same workload (gate + select + VQ assign), oracle C "
-                      "port: OpenMP over 4-token x 32-code register tiles (%d threads) + AVX2 FMA chains, "
-                      "%.1f s" % (reps, nb, cores, dt)}
+    def loop(fn, seconds):
+        fn()                                                     # warm (page-in, thread teams)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or reps >= 10000:
+                return reps, dt
+
+    reps, dt = loop(one_pass, target_s * 0.6)
+    res = {"value": nb * reps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": "%d passes over %d images of the weak-scaling workload (gate + select + VQ assign), oracle C "
+                     "port: OpenMP over 4-token x 32-code register tiles (%d threads) + AVX2 FMA chains, "
+                     "%.1f s" % (reps, nb, cores, dt)}
+
+    torch.set_num_threads(cores)
+    nt = 16
+    tE = torch.from_numpy(E)
+    thf, thc, tent = torch.from_numpy(hf[:nt]), torch.from_numpy(hc[:nt]), torch.from_numpy(ent[:nt])
+    en = (tE * tE).sum(1).unsqueeze(0)
+
+    def torch_pass():
+        with torch.no_grad():
+            fine = tent > THR_R05
+            up = fine.repeat_interleave(2, -1).repeat_interleave(2, -2).unsqueeze(1)
+            h = torch.where(up, thf, thc.repeat_interleave(2, -1).repeat_interleave(2, -2))
+            m = torch.where(up, 1.0, 0.25).reshape(nt, -1, 1)
+            x = h.permute(0, 2, 3, 1).reshape(-1, 256)
+            d = torch.addmm((x * x).sum(1, keepdim=True) + en, x, tE.t(), alpha=-2.0)
+            code = d.argmin(-1)
+            e = tE.index_select(0, code)
+            loss = 1.25 * (((e - x) ** 2).reshape(nt, -1, 256) * m).mean()
+            zq = (x + (e - x)).reshape(nt, 32, 32, 256).permute(0, 3, 1, 2).contiguous()
+        return zq, code, loss
+
+    reps2, dt2 = loop(torch_pass, target_s * 0.4)
+    res["torch_ops"] = {"value": nt * reps2 / dt2, "unit": "images/s", "cores": cores, "kind": "port",
+                        "sample": "%d passes over %d images, the reference's op sequence as torch-CPU ops (where / "
+                                  "addmm / argmin / index_select / masked mean), torch %s, %d threads, %.1f s"
+                                  % (reps2, nt, torch.__version__, cores, dt2)}
+    return res
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def tile_images(base, B):
+    """[b0, ...] device tensor -> [B, ...]: image i = base[i % b0] rolled by 5 (i // b0) positions along the last
+    axis (the tokens of later images are those of the base images at other positions: same statistics)"""
+    import torch
+    b0 = base.shape[0]
+    if B <= b0:
+        return base[:B].contiguous()
+    parts = [torch.roll(base, shifts=5 * k, dims=-1) for k in range((B + b0 - 1) // b0)]
+    return torch.cat(parts, 0)[:B].contiguous()
+
+
+class WeakDual:
+    """BASELINE configs[2]: entropy router + dual routing + VectorQuantize2 assign, B images per rank"""
+    name = "dual"
+
+    def __init__(self, a, rank, world, dev):
+        import torch
+
+        from dynamicvectorquantization_amd import _lib, synth
+        from dynamicvectorquantization_amd.quantize import _CodebookPrep
+        self.a, self.dev, self.world = a, dev, world
+        B = self.B = a.batch or 256
+        self.Bglobal = B * world
+        K, D, H, W = a.codes, 256, 32, 32
+        self.K, self.D, self.H, self.W = K, D, H, W
+        self.mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
+        self.E_np = synth.codebook_trained(K, D)
+        off = rank * B
+        b0 = min(B, 256)
+        t = lambda x: torch.from_numpy(x).to(dev)
+        self.h_fine = tile_images(t(synth.z_tokens(self.E_np, b0, H, W, 2903, image_offset=off)), B)
+        self.h_coarse = tile_images(t(synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913, image_offset=off)), B)
+        self.ent = tile_images(t(synth.entropy_map(5903, b0, H // 2, W // 2, image_offset=off)), B)
+        self.E = t(self.E_np)
+        self.prep = _CodebookPrep()
+        # preallocated outputs: the step allocates nothing
+        self.h_dual = torch.empty_like(self.h_fine) if a.path == "select" else None
+        self.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
+        self.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        self.zq = torch.empty_like(self.h_fine)
+        self.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        self.loss = torch.empty(2, dtype=torch.float32, device=dev)
+        self.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+
+    def describe(self):
+        return ("BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, entropy gate + "
+                "dual routing + VectorQuantize2 assign (quant_conv not in the path)" % (self.B, self.K))
+
+    def step(self, ev=None):
+        from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
+        from dynamicvectorquantization_amd.router import route_select_dual_entropy
+        if self.a.path == "select":
+            route_select_dual_entropy(self.ent, THR_R05, self.h_coarse, self.h_fine,
+                                      out=(self.h_dual, self.grain, self.cmask, self.gate))
+            if ev:
+                ev[0].record()
+            vq_assign(self.h_dual, self.E, self.prep, self.cmask, beta=0.25, mode=self.mode,
+                      out=(self.zq, self.codes, self.loss))
+        else:
+            if ev:
+                ev[0].record()
+            vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep, entropy=self.ent, threshold=THR_R05,
+                                  beta=0.25, mode=self.mode,
+                                  out=(self.zq, self.codes, self.loss, self.grain, self.cmask, self.gate))
+        if ev:
+            ev[1].record()
+        return self.codes, self.grain, self.loss
+
+    def dominant(self, ev):
+        """the dominant kernel alone (pass 1 of the assign), same launch geometry"""
+        from dynamicvectorquantization_amd import _lib
+        from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
+        if self.a.mode == "exact":
+            ev[0].record()
+            vq_assign(self.h_dual if self.h_dual is not None else self.h_fine, self.E, self.prep_dom, self.cmask,
+                      beta=0.25, mode=_lib.MODE_EXACT, out=(self.zq, self.codes, self.loss))
+            ev[1].record()
+        elif self.a.path == "select":
+            ev[0].record()
+            vq_assign(self.h_dual, self.E, self.prep_dom, self.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                      out=(self.zq, self.codes, None))
+            ev[1].record()
+        else:
+            ev[0].record()
+            vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep_dom, entropy=self.ent,
+                                  threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                                  out=(self.zq, self.codes, None, self.grain, self.cmask, self.gate))
+            ev[1].record()
+
+    def dominant_kernel_name(self):
+        if self.a.mode == "exact":
+            return "vq_assign_exact_kernel<256>"
+        return "vq_assign_filter_kernel<256>" if self.a.path == "select" else "vq_routed_pass1_kernel<256>"
+
+    def parity(self):
+        """the step's outputs, still in HBM, against the oracle on ALL images of this rank"""
+        import numpy as np
+
+        from oracle import oracle
+        oracle.build()
+        ent, hc, hf = (x.cpu().numpy() for x in (self.ent, self.h_coarse, self.h_fine))
+        og = oracle.entropy_gate(ent, THR_R05)
+        osel = oracle.route_select_dual(og, hc, hf)
+        o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
+        codes = self.codes.cpu().numpy().reshape(self.B, -1)
+        ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
+        return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
+                "zq_mismatches": int((self.zq.cpu().numpy() != o["zq"]).sum()),
+                "grain_mismatches": int((self.grain.cpu().numpy() != osel["indices"]).sum()),
+                "mask_mismatches": int((self.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
+                "gate_mismatches": int((self.gate.cpu().numpy() != og).sum()),
+                "loss_rel_err": abs(float(self.loss[1]) - ol) / abs(ol)}
+
+
+class StrongTriple:
+    """BASELINE configs[3]: triple granularity, global batch split over the ranks: fused feature-router gate
+    + triple routing + assign"""
+    name = "triple"
+
+    def __init__(self, a, rank, world, dev):
+        import torch
+
+        from dynamicvectorquantization_amd import _lib, synth
+        from dynamicvectorquantization_amd.encode import shard_slice
+        from dynamicvectorquantization_amd.quantize import _CodebookPrep
+        from dynamicvectorquantization_amd.router import TripleGrainFeatureRouter
+        self.a, self.dev, self.world = a, dev, world
+        self.Bglobal = a.batch or 1024
+        s, e = shard_slice(self.Bglobal, rank, world)
+        B = self.B = e - s
+        K, D, H, W = a.codes, 256, 32, 32
+        self.K, self.D, self.H, self.W = K, D, H, W
+        self.mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
+        self.E_np = synth.codebook_trained(K, D)
+        b0 = min(B, 128)
+        t = lambda x: torch.from_numpy(x).to(dev)
+        self.h_fine = tile_images(t(synth.z_tokens(self.E_np, b0, 32, 32, 2104, image_offset=s)), B)
+        self.h_median = tile_images(t(synth.z_tokens(self.E_np, b0, 16, 16, 2114, image_offset=s)), B)
+        self.h_coarse = tile_images(t(synth.z_tokens(self.E_np, b0, 8, 8, 2124, image_offset=s)), B)
+        self.E = t(self.E_np)
+        self.router = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu")
+        sd = {k: torch.from_numpy(synth.seeded_param(6104, i, k, tuple(v.shape)))
+              for i, (k, v) in enumerate(self.router.state_dict().items())}
+        self.router.load_state_dict(sd)
+        self.router = self.router.to(dev).eval()
+        self.prep = _CodebookPrep()
+        self.h_triple = torch.empty_like(self.h_fine) if a.path == "select" else None
+        self.grain = torch.empty((B, 8, 8), dtype=torch.int64, device=dev)
+        self.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        self.zq = torch.empty_like(self.h_fine)
+        self.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        self.loss = torch.empty(2, dtype=torch.float32, device=dev)
+        self.logits = None
+
+    def describe(self):
+        return ("BASELINE configs[3]: triple granularity F=32/16/8, global B=%d split image-parallel (%d on this "
+                "rank), 32x32x256 latents, K=%d, fused feature-router gate + triple routing + VectorQuantize2 assign "
+                "(quant_conv not in the path)" % (self.Bglobal, self.B, self.K))
+
+    def step(self, ev=None):
+        import torch
+
+        from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
+        from dynamicvectorquantization_amd.router import route_select_triple
+        with torch.no_grad():
+            self.logits = self.router(h_fine=self.h_fine, h_median=self.h_median, h_coarse=self.h_coarse)
+            if ev:
+                ev[0].record()
+            if self.a.path == "select":
+                route_select_triple(self.logits, self.h_coarse, self.h_median, self.h_fine,
+                                    out=(self.h_triple, self.grain, self.cmask))
+                vq_assign(self.h_triple, self.E, self.prep, self.cmask, beta=0.25, mode=self.mode,
+                          out=(self.zq, self.codes, self.loss))
+            else:
+                vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep, self.logits,
+                                        beta=0.25, mode=self.mode,
+                                        out=(self.zq, self.codes, self.loss, self.grain, self.cmask))
+        if ev:
+            ev[1].record()
+        return self.codes, self.grain, self.loss
+
+    def dominant(self, ev):
+        from dynamicvectorquantization_amd import _lib
+        from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
+        ev[0].record()
+        if self.a.path == "select" or self.a.mode == "exact":
+            vq_assign(self.h_triple if self.h_triple is not None else self.h_fine, self.E, self.prep_dom, self.cmask,
+                      beta=0.25, mode=_lib.MODE_EXACT if self.a.mode == "exact" else _lib.MODE_FILTER_PASS1,
+                      out=(self.zq, self.codes, self.loss if self.a.mode == "exact" else None))
+        else:
+            vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep_dom, self.logits,
+                                    beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                                    out=(self.zq, self.codes, None, self.grain, self.cmask))
+        ev[1].record()
+
+    def dominant_kernel_name(self):
+        if self.a.mode == "exact":
+            return "vq_assign_exact_kernel<256>"
+        return "vq_assign_filter_kernel<256>" if self.a.path == "select" else "vq_routed_pass1_kernel<256>"
+
+    def parity(self):
+        """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
+        itself is a 1e-4 tolerance kernel, covered by tests/)"""
+        from oracle import oracle
+        oracle.build()
+        lg = self.logits.cpu().numpy()
+        hc, hm, hf = (x.cpu().numpy() for x in (self.h_coarse, self.h_median, self.h_fine))
+        osel = oracle.route_select_triple(lg, hc, hm, hf)
+        o = oracle.vq_assign_nchw(osel["h_triple"], self.E_np, osel["codebook_mask"])
+        codes = self.codes.cpu().numpy().reshape(self.B, -1)
+        ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
+        return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
+                "zq_mismatches": int((self.zq.cpu().numpy() != o["zq"]).sum()),
+                "grain_mismatches": int((self.grain.cpu().numpy() != osel["indices"]).sum()),
+                "mask_mismatches": int((self.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
+                "loss_rel_err": abs(float(self.loss[1]) - ol) / abs(ol)}
+
+
+# ------------------------------------------------------------------------------------------------
+def run_rank(a):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,55 +440,26 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from dynamicvectorquantization_amd import _lib, synth
-    from dynamicvectorquantization_amd.encode import all_gather_codes
-    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
-    from dynamicvectorquantization_amd.router import route_select_dual_entropy
+    from dynamicvectorquantization_amd.encode import CodeExchange
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep
 
-    B, K, D, H, W = a.batch, a.codes, 256, 32, 32
-    mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
-    E_np = synth.codebook_trained(K, D)
-    off = rank * B
-    h_fine = torch.from_numpy(synth.z_tokens(E_np, B, H, W, 2903, image_offset=off)).to(dev)
-    h_coarse = torch.from_numpy(synth.z_tokens(E_np, B, H // 2, W // 2, 2913, image_offset=off)).to(dev)
-    ent = torch.from_numpy(synth.entropy_map(5903, B, H // 2, W // 2, image_offset=off)).to(dev)
-    E = torch.from_numpy(E_np).to(dev)
-    thr = 1.6777750253677368                       # imagenet_train JSON, key "50" (ratio 0.5)
-    prep = _CodebookPrep()
-    # preallocated outputs: the step allocates nothing
-    h_dual = torch.empty_like(h_fine)
-    grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
-    cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-    zq = torch.empty_like(h_fine)
-    codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    wl = (WeakDual if a.scaling == "weak" else StrongTriple)(a, rank, world, dev)
+    wl.prep_dom = _CodebookPrep()
+    B, K, D, H, W = wl.B, wl.K, wl.D, wl.H, wl.W
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
-    gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+    xch = CodeExchange(wl.codes, wl.grain, K, wl.Bglobal, numel_per_image=H * W * D) if world > 1 else None
 
     def step(i=None):
-        # entropy-threshold gate + routing tail: one kernel (the int64 gate is written as a by-product)
-        route_select_dual_entropy(ent, thr, h_coarse, h_fine, out=(h_dual, grain, cmask, gate))
-        if i is not None:
-            ev[i][0].record()
-        vq_assign(h_dual, E, prep, cmask, beta=0.25, mode=mode, out=(zq, codes, loss))
-        if i is not None:
-            ev[i][1].record()
-        if world > 1:
+        codes, grain, loss = wl.step(ev[i] if i is not None else None)
+        if xch is not None:
             # one packed all-gather per step, in flight while the next step's kernels run; the previous
-            # step's exchange is completed (stream wait + unpack) first, so at most one is pending
-            if pending:
-                pending.pop().wait()
-            pending.append(all_gather_codes(codes, grain, loss[0] * (B * H * W * D), B * H * W * D, K, B * world,
-                                            async_op=True))
-        return codes, grain, loss[0]
-
-    pending = []
+            # step's exchange is completed (stream wait + unpack kernel) first, so at most one is pending
+            xch.finish()
+            xch.start(codes, grain, loss)
 
     def fence():
-        if pending:
-            pending.pop().wait()           # the last exchange completes inside the timed region
-        if world > 1:
+        if xch is not None:
+            xch.finish()                   # the last exchange completes inside the timed region
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,19 +478,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))     # the whole vq_assign op (all its kernels)
-    # the dominant kernel alone (same launch, DVQ_MODE_FILTER_PASS1 / the single exact kernel), HIP events
-    # on the launch stream, interleaved after the timed region so it does not perturb `value`
-    dom_mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER_PASS1
-    prep_dom = _CodebookPrep()
-    dom_loss = None if a.mode == "filter" else loss
+    parity = None
+    if not a.no_parity:
+        # every rank checks ITS images against the oracle, after the timed region, on the last step's outputs
+        parity = wl.parity()
+        if world > 1:
+            keys = sorted(k for k in parity if k != "loss_rel_err")
+            tot = torch.tensor([parity[k] for k in keys], dtype=torch.int64, device=dev)
+            dist.all_reduce(tot)
+            lr = torch.tensor([parity["loss_rel_err"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(lr, op=dist.ReduceOp.MAX)
+            parity = dict(zip(keys, (int(v) for v in tot.tolist())), loss_rel_err=float(lr.item()))
+            if xch is not None:            # the gathered global tensors agree with the local shard
+                g_codes, g_grain, _ = xch.result()
+                s0 = sum(b for b in xch.shard_sizes[:rank])
+                parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], wl.codes) and
+                                             torch.equal(g_grain[s0:s0 + B], wl.grain))
+
+    op_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))       # the assign op (all its kernels)
+    # the dominant kernel alone, HIP events on the launch stream, after the timed region
     dom_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     for i in range(-3, a.steps):
-        if i >= 0:
-            dom_ev[i][0].record()
-        vq_assign(h_dual, E, prep_dom, cmask, beta=0.25, mode=dom_mode, out=(zq, codes, dom_loss))
-        if i >= 0:
-            dom_ev[i][1].record()
+        wl.dominant(dom_ev[i] if i >= 0 else scratch)
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
     N = B * H * W
@@ -210,11 +508,13 @@ def main():
     alg_flops = 2.0 * K * D * N
     gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
     tfs = alg_flops / (dom_ms * 1e-3) / 1e12
-    traffic = None
+    traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(a.mode, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(a.mode if a.path == "select" else "routed", {}).get("hbm_bytes_per_launch")
+            tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected by tools/pmc_traffic.py; not re-measured in this run)"
         except Exception:
             traffic = None
     if a.mode == "filter":
@@ -223,29 +523,46 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
-    roof.update({"kernel": "vq_assign_filter_kernel<256>" if a.mode == "filter" else "vq_assign_exact_kernel<256>",
-                 "kernel_ms": dom_ms, "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
+    roof.update({"kernel": wl.dominant_kernel_name(), "traffic_source": tsrc,
+                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events around the pass-1 launch (a 4-us counter-zero / "
+                 "token-list kernel precedes it in the same op and is inside the bracket)",
+                 "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
+                 "algorithmic_note": "DENSE count (SURVEY.md 8d): every one of the B*H*W positions read + written once; "
+                                     "the routed path scores unique tokens only, see unique_tokens",
                  "hbm_gbps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_tflops_equiv": tfs,
-                 "whole_op_ms": kern_ms, "whole_op_hbm_gbps": alg_bytes / (kern_ms * 1e-3) / 1e9,
-                 "whole_op_note": "vq_assign op = all its kernels (filter: counter memset + filter kernel + resolver + exact-list kernel with the fused loss finalize; exact: kernel + finalize)"})
+                 "whole_op_ms": op_ms, "whole_op_hbm_gbps": alg_bytes / (op_ms * 1e-3) / 1e9})
+    if hasattr(wl, "unique_tokens"):
+        roof["unique_tokens"] = wl.unique_tokens()
     if rank == 0:
         out = {
-            "metric": "images encoded/sec (VQ hot path: gate + route select + VQ assign), 256x256 inputs, K=%d" % K,
-            "value": B * world * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "metric": "images encoded/sec (VQ hot path: gate + routing + VQ assign), 256x256 inputs, K=%d" % K,
+            "value": wl.Bglobal * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, "
-                                   "K=%d, entropy gate + dual route select + VectorQuantize2 assign "
-                                   "(quant_conv not in the path)" % (B, K),
-                       "global_batch": B * world, "assign_mode": a.mode, "spinup_steps": a.spinup,
-                       "parallelism": "image-parallel x%d, RCCL all-gather of codes" % world},
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
+                       "spinup_steps": a.spinup,
+                       "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
+                                      "per step" % world},
             "roofline": roof,
         }
+        if parity is not None:
+            bad = sum(v for k, v in parity.items() if k.endswith("_mismatches"))
+            out["parity_checked"] = bool(bad == 0 and parity["loss_rel_err"] <= 1e-5 and parity.get("exchange_ok", True))
+            out["code_mismatches"] = parity["code_mismatches"]
+            out["parity"] = parity
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(E_np, B, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))          # nothing above has touched a GPU
+    run_rank(a)
 
 
 if __name__ == "__main__":

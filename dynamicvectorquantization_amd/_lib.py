@@ -20,14 +20,19 @@ MODE_EXACT = 0
 MODE_FILTER = 1
 MODE_FILTER_PASS1 = 2   # profiling aid: only the dominant filter kernel
 MODE_FILTER_WIDE = 3    # testing aid: force the two-blocks-per-wave pass-1 kernel (D = 256)
+FILTER_MODES = (MODE_FILTER, MODE_FILTER_PASS1, MODE_FILTER_WIDE)
 GATE_F32 = 0
 GATE_I64 = 1
+GATE_ENTROPY = 2        # routed assign only: entropy map + threshold
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "dvq_version", "dvq_last_error_string", "dvq_codebook_prep_bytes", "dvq_codebook_prepare_f32",
     "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_fallback_count_offset",
     "dvq_embed_gather_f32",
+    "dvq_vq_assign_routed_workspace_bytes", "dvq_vq_assign_routed_dual_f32", "dvq_vq_assign_routed_triple_f32",
+    "dvq_vq_assign_routed_fallback_count_offset",
+    "dvq_exchange_bytes", "dvq_exchange_pack", "dvq_exchange_unpack", "dvq_set_pass1_variant",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
     "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
@@ -68,6 +73,24 @@ def _load():
     lib.dvq_vq_assign_fallback_count_offset.argtypes = [i32, i32, i32, i32]
     lib.dvq_vq_assign_nchw_f32.restype = i32
     lib.dvq_vq_assign_nchw_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_vq_assign_routed_workspace_bytes.restype = sz
+    lib.dvq_vq_assign_routed_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
+    lib.dvq_vq_assign_routed_fallback_count_offset.restype = sz
+    lib.dvq_vq_assign_routed_fallback_count_offset.argtypes = [i32, i32, i32, i32, i32, i32]
+    lib.dvq_vq_assign_routed_dual_f32.restype = i32
+    lib.dvq_vq_assign_routed_dual_f32.argtypes = [vp, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32,
+                                                  vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_vq_assign_routed_triple_f32.restype = i32
+    lib.dvq_vq_assign_routed_triple_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32,
+                                                    vp, vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_set_pass1_variant.restype = i32
+    lib.dvq_set_pass1_variant.argtypes = [i32, i32]
+    lib.dvq_exchange_bytes.restype = sz
+    lib.dvq_exchange_bytes.argtypes = [i64, i64, i32, i32]
+    lib.dvq_exchange_pack.restype = i32
+    lib.dvq_exchange_pack.argtypes = [vp, vp, vp, ctypes.c_double, i32, i32, i64, i64, i32, vp, vp]
+    lib.dvq_exchange_unpack.restype = i32
+    lib.dvq_exchange_unpack.argtypes = [vp, i32, i32, i64, i64, i32, vp, vp, vp, vp]
     lib.dvq_embed_gather_f32.restype = i32
     lib.dvq_embed_gather_f32.argtypes = [vp, i32, i32, vp, i64, vp, vp]
     lib.dvq_entropy_gate_f32.restype = i32

@@ -6,7 +6,8 @@
 #include "../../include/dvq.h"
 #include "dvq_common.h"
 
-#define DVQ_VERSION 100   // 0.1.0
+#define DVQ_VERSION 200   // 0.2.0
+#define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
 
@@ -21,12 +22,20 @@ void dvq_set_error(const char *fmt, ...)
 // launchers implemented next to their kernels
 int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st);
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st);
+struct DvqRouted;
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                     hipStream_t st);
+                     const DvqRouted *rv, hipStream_t st);
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta, hipStream_t st);
+                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
+                      const DvqRouted *rv, hipStream_t st);
+int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
+                      const float *h_median, const float *h_fine, const void *prep, const float *E,
+                      int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
+                      float *loss, long long *indices, float *cmask, long long *gate_out,
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st);
+size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
@@ -56,6 +65,13 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
                            int B, int C, int hc, int wc, int groups, float eps,
                            const float *W1, const float *b1, const float *W2, const float *b2,
                            int Hid, int act, float *gate, void *ws, hipStream_t st);
+
+int dvq_choose_pass1_variant(int dense, int routed);
+size_t dvq_xch_bytes(long cpi, long gpi, int b_max, int num_codes);
+int dvq_launch_xch_pack(const long long *codes, const long long *grain, const float *loss, double numel, int b_local,
+                        int b_max, long cpi, long gpi, int num_codes, void *buf, hipStream_t st);
+int dvq_launch_xch_unpack(const void *gathered, int world, int global_batch, long cpi, long gpi, int num_codes,
+                          long long *codes, long long *grain, float *mean, hipStream_t st);
 
 static int hip_rc(int rc, const char *what)
 {
@@ -146,11 +162,11 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, st);
+                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, nullptr, st);
         return hip_rc(rc, "vq_assign_filter");     // the loss finalize is fused into its last kernel
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
-                              (long long *)codes, partials, st);
+                              (long long *)codes, partials, nullptr, st);
         if (rc) return hip_rc(rc, "vq_assign_exact");
         nparts = (int)((N + 127) / 128);
     }
@@ -159,6 +175,100 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
         if (rc) return hip_rc(rc, "vq_loss_finalize");
     }
     return DVQ_OK;
+}
+
+static int routed_dims(int nb, int hc, int wc, int *SC)
+{
+    *SC = (nb == 2) ? 2 : 4;
+    return (nb == 2 || nb == 3) && hc > 0 && wc > 0 && (long)hc * wc <= DVQ_ROUTE_MAX_CELLS_ABI;
+}
+
+size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int hc, int wc, int K, int mode)
+{
+    int SC;
+    if (B <= 0 || D <= 0 || K <= 0 || !routed_dims(num_branches, hc, wc, &SC)) return 0;
+    const int HWout = SC * hc * SC * wc;
+    const long N = (long)B * HWout;
+    (void)mode;                                          // sized for the filter path in every mode
+    return partials_bytes_for(N) + dvq_filter_ws_extra_bytes(D, HWout, K, N) +
+           dvq_routed_tables_bytes(num_branches, B, hc, wc) + 256;
+}
+
+size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K)
+{
+    int SC;
+    (void)D; (void)K;
+    if (B <= 0 || !routed_dims(num_branches, hc, wc, &SC)) return 0;
+    return partials_bytes_for((long)B * SC * hc * SC * wc);
+}
+
+static int routed_common(const char *fn, int nb, const void *gate, int gate_kind, float threshold,
+                         const float *h_coarse, const float *h_median, const float *h_fine,
+                         const float *codebook, const void *prep, int B, int D, int hc, int wc, int K, float beta,
+                         float *zq, int64_t *codes, float *loss, int64_t *indices, float *cmask, int64_t *gate_out,
+                         void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    if (!gate || !h_coarse || !h_fine || !codebook || !prep || !codes || !indices || !cmask || (nb == 3 && !h_median)) {
+        dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL;
+    }
+    if (B <= 0 || hc <= 0 || wc <= 0 || K <= 0) { dvq_set_error("%s: B=%d hc=%d wc=%d K=%d must be positive", fn, B, hc, wc, K); return DVQ_EINVAL; }
+    if (gate_kind != DVQ_GATE_F32 && gate_kind != DVQ_GATE_I64 && gate_kind != DVQ_GATE_ENTROPY) { dvq_set_error("%s: gate_kind %d", fn, gate_kind); return DVQ_EINVAL; }
+    if (gate_kind == DVQ_GATE_ENTROPY && nb != 2) { dvq_set_error("%s: the entropy gate is a dual-granularity router", fn); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    int SC;
+    if (!routed_dims(nb, hc, wc, &SC)) { dvq_set_error("%s: hc*wc=%ld exceeds %d coarse cells", fn, (long)hc * wc, DVQ_ROUTE_MAX_CELLS_ABI); return DVQ_EUNSUPPORTED; }
+    if (nb == 2 && wc % 2 != 0) { dvq_set_error("%s: wc=%d must be even (codebook_mask rows move as 16-byte pieces)", fn, wc); return DVQ_EUNSUPPORTED; }
+    const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
+    if (pass1_only) mode = DVQ_MODE_FILTER;
+    if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("%s: unknown mode %d", fn, mode); return DVQ_EINVAL; }
+    const long N = (long)B * SC * hc * SC * wc;
+    if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40) || B > 32768) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, SC * hc * SC * wc, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!ws || ws_bytes < dvq_vq_assign_routed_workspace_bytes(nb, B, D, hc, wc, K, mode)) {
+        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_routed_workspace_bytes(nb, B, D, hc, wc, K, mode));
+        return DVQ_EWORKSPACE;
+    }
+    if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    double *partials = loss ? (double *)ws : nullptr;
+    const size_t pbytes = partials_bytes_for(N);
+    const int gmode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
+    int rc = dvq_launch_routed(nb, gmode, gate, threshold, h_coarse, h_median, h_fine, prep, codebook, B, D, hc, wc, K,
+                               beta, zq, (long long *)codes, loss, (long long *)indices, cmask, (long long *)gate_out,
+                               partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st);
+    if (rc) return hip_rc(rc, fn);
+    if (mode == DVQ_MODE_EXACT && loss) {
+        rc = dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
+        if (rc) return hip_rc(rc, "vq_loss_finalize");
+    }
+    return DVQ_OK;
+}
+
+int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,
+                                  const float *h_coarse, const float *h_fine,
+                                  const float *codebook, const void *prep,
+                                  int B, int D, int hc, int wc, int K, float beta,
+                                  float *zq, int64_t *codes, float *loss,
+                                  int64_t *indices, float *cmask, int64_t *gate_out,
+                                  void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    return routed_common("dvq_vq_assign_routed_dual_f32", 2, gate, gate_kind, threshold, h_coarse, nullptr, h_fine,
+                         codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, gate_out, ws, ws_bytes,
+                         mode, stream);
+}
+
+int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
+                                    const float *h_coarse, const float *h_median, const float *h_fine,
+                                    const float *codebook, const void *prep,
+                                    int B, int D, int hc, int wc, int K, float beta,
+                                    float *zq, int64_t *codes, float *loss,
+                                    int64_t *indices, float *cmask,
+                                    void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    if (!h_median) { dvq_set_error("dvq_vq_assign_routed_triple_f32: null h_median"); return DVQ_EINVAL; }
+    return routed_common("dvq_vq_assign_routed_triple_f32", 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine,
+                         codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, nullptr, ws, ws_bytes,
+                         mode, stream);
 }
 
 int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx, int64_t n,
@@ -336,6 +446,50 @@ int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *
                                               (const long long *)coarse_position, (const long long *)fine_position,
                                               B, Lc, Lf, hc, wc, coarse_position_eos, fine_position_eos,
                                               (long long *)target, (hipStream_t)stream), "permute_backward");
+}
+
+int dvq_set_pass1_variant(int dense_variant, int routed_variant)
+{
+    if (dvq_choose_pass1_variant(dense_variant, routed_variant) != 0) {
+        dvq_set_error("dvq_set_pass1_variant: dense in -2..3, routed in {-2, 0..3}");
+        return DVQ_EINVAL;
+    }
+    return DVQ_OK;
+}
+
+size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes)
+{
+    if (codes_per_image <= 0 || grain_per_image < 0 || b_max <= 0 || num_codes <= 0) return 0;
+    return dvq_xch_bytes((long)codes_per_image, (long)grain_per_image, b_max, num_codes);
+}
+
+int dvq_exchange_pack(const int64_t *codes, const int64_t *grain, const float *loss, double numel, int b_local,
+                      int b_max, int64_t codes_per_image, int64_t grain_per_image, int num_codes, void *buf,
+                      void *stream)
+{
+    if (!codes || !buf) { dvq_set_error("dvq_exchange_pack: null pointer"); return DVQ_EINVAL; }
+    if (b_local < 0 || b_max <= 0 || b_local > b_max || codes_per_image <= 0 || grain_per_image < 0 || num_codes <= 0) {
+        dvq_set_error("dvq_exchange_pack: bad sizes"); return DVQ_EINVAL;
+    }
+    if (grain_per_image > 0 && !grain) { dvq_set_error("dvq_exchange_pack: null grain"); return DVQ_EINVAL; }
+    if (((uintptr_t)buf & 7) != 0) { dvq_set_error("dvq_exchange_pack: buffer must be 8-byte aligned"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_xch_pack((const long long *)codes, grain_per_image > 0 ? (const long long *)grain : nullptr,
+                                      loss, numel, b_local, b_max, (long)codes_per_image, (long)grain_per_image,
+                                      num_codes, buf, (hipStream_t)stream), "exchange_pack");
+}
+
+int dvq_exchange_unpack(const void *gathered, int world, int global_batch, int64_t codes_per_image,
+                        int64_t grain_per_image, int num_codes, int64_t *codes, int64_t *grain, float *mean,
+                        void *stream)
+{
+    if (!gathered || !codes) { dvq_set_error("dvq_exchange_unpack: null pointer"); return DVQ_EINVAL; }
+    if (world <= 0 || global_batch <= 0 || codes_per_image <= 0 || grain_per_image < 0 || num_codes <= 0) {
+        dvq_set_error("dvq_exchange_unpack: bad sizes"); return DVQ_EINVAL;
+    }
+    if (grain_per_image > 0 && !grain) { dvq_set_error("dvq_exchange_unpack: null grain"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_xch_unpack(gathered, world, global_batch, (long)codes_per_image, (long)grain_per_image,
+                                        num_codes, (long long *)codes, grain_per_image > 0 ? (long long *)grain : nullptr,
+                                        mean, (hipStream_t)stream), "exchange_unpack");
 }
 
 }  // extern "C"

@@ -101,14 +101,18 @@ struct DvqLossTail {
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
 // Kernels with more than 64 KiB of dynamic LDS need the per-device opt-in once; `done` is the caller's
-// static bitmask (one bit per device ordinal, so a process driving several GPUs opts in on each).
-static inline void dvq_allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *done)
+// static bitmask (one bit per device ordinal, so a process driving several GPUs opts in on each; relaxed
+// atomics: two host threads may both apply the attribute, which is idempotent).  Returns the HIP error
+// of hipFuncSetAttribute (0 = ok).
+static inline int dvq_allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *done)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;     // shared bit: always re-apply
-    if (dev != 63 && ((*done >> dev) & 1ull)) return;
-    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (dev != 63) *done |= 1ull << dev;
+    if (dev != 63 && ((__atomic_load_n(done, __ATOMIC_RELAXED) >> dev) & 1ull)) return 0;
+    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc != hipSuccess) return (int)rc;
+    if (dev != 63) __atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELAXED);
+    return 0;
 }
 
 // per-launch host-side error plumbing (dvq_abi.hip)

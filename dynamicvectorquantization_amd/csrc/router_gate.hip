@@ -333,11 +333,11 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     const size_t shmem = ((size_t)32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
     if (nb == 2) {
         static unsigned long long done2 = 0;
-        dvq_allow_dynamic_lds((const void *)router_gate_kernel<2>, 160 * 1024 - 256, &done2);
+        { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<2>, 160 * 1024 - 256, &done2); if (rc) return rc; }
         hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
     } else {
         static unsigned long long done3 = 0;
-        dvq_allow_dynamic_lds((const void *)router_gate_kernel<3>, 160 * 1024 - 256, &done3);
+        { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<3>, 160 * 1024 - 256, &done3); if (rc) return rc; }
         hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
     }
     return (int)hipGetLastError();

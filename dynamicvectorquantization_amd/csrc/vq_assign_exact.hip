@@ -19,16 +19,18 @@
 // 0-31 / 32-63 read two 128-B runs of consecutive tokens per load) and streams the codebook as
 // prepared 32-code LDS tile images (double-buffered global->LDS DMA, one barrier per tile).
 // Compute-bound on the fp32 MFMA rate (2*K*D flop per token).
-#include "dvq_common.h"
+#include "dvq_filter.h"
 #include <type_traits>
 
-template <int D, bool LIST>
+// ROUTED: the tokens are the unique tokens of a routed batch (dvq_filter.h: DvqRouted), addressed in the
+// encoder branches; token ids are slot*32 + lane, a token covers rep x rep output positions.
+template <int D, bool LIST, bool ROUTED>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
     const float *__restrict__ mask, int HW, int K, long N,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     const int *__restrict__ list, const int *__restrict__ list_count,
-    DvqLossTail tail)
+    DvqLossTail tail, const DvqRouted rv)
 {
     constexpr int S = D / 2;                         // MFMA steps (2 k each)
     constexpr int TILE_FLOATS = 32 * D + 64;
@@ -61,14 +63,29 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         n = list[valid ? n : 0];
         nn = n;
     }
-    const long b = nn / HW;
-    const int hw = (int)(nn - b * HW);
-    const size_t zbase = ((size_t)b * D + h) * HW + hw;      // channel k = 2s + h at zbase + 2s*HW
-    const float *zp = z + zbase;
+    const float *zp;                                   // channel h of the token; channel k = 2s + h at zp + 2s*stride
+    int stride, rep = 1, Wout = 0, HWo = HW;
+    if (ROUTED) {
+        int g;
+        const DvqTok tk = dvq_routed_lookup(rv, (int)(nn >> 5), (int)(nn & 31), g);
+        valid = valid && tk.valid;
+        stride = tk.stride;
+        zp = tk.src + (size_t)h * stride;
+        n = nn = tk.n;
+        rep = tk.rep;
+        Wout = rv.Wout;
+        HWo = rv.HWout;
+    } else {
+        const long b = nn / HW;
+        stride = HW;
+        zp = z + ((size_t)b * D + h) * HW + (size_t)(nn - b * HW);
+    }
+    const long bout = nn / HWo;
+    const size_t zqbase = ((size_t)bout * D + h) * HWo + (size_t)(nn - bout * HWo);
 
     float zr[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) zr[s] = zp[(size_t)2 * s * HW];
+    for (int s = 0; s < S; ++s) zr[s] = zp[(size_t)2 * s * stride];
 
     auto stage = [&](int t, float *buf) {
         const char *src = (const char *)(tiles + (size_t)t * TILE_FLOATS);
@@ -159,7 +176,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         argmin_merge(best, bidx, ob, oi);
     }
     const int code = (bidx == 0x7fffffff) ? 0 : bidx;    // every distance +inf -> index 0
-    if (valid && h == 0) codes[n] = (long long)code;
+    if (valid && h == 0) {
+        if (!ROUTED) {
+            codes[n] = (long long)code;
+        } else {
+            for (int ry = 0; ry < rep; ++ry)
+                for (int rx = 0; rx < rep; ++rx) codes[n + (long)ry * Wout + rx] = (long long)code;
+        }
+    }
 
     // ---- z_q = z + (e - z), loss partial sum((e - z)^2 * m)
     float lsum = 0.0f;
@@ -170,17 +194,26 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
         // per-lane pointer, it turned every store into its own exec-masked branch)
         auto finish = [&](auto store_tag) {
             constexpr bool STORE = decltype(store_tag)::value;
-            float *zqp = STORE ? zq + zbase : nullptr;
+            float *zqp = STORE ? zq + zqbase : nullptr;
 #pragma unroll
             for (int s = 0; s < S; ++s) {          // fully unrolled: zr[] must stay in registers
                 float e = ep[2 * s];
                 float diff = __fsub_rn(e, zr[s]);
-                if (STORE) zqp[(size_t)2 * s * HW] = __fadd_rn(zr[s], diff);
+                if (STORE) {
+                    const float v = __fadd_rn(zr[s], diff);
+                    if (!ROUTED) {
+                        zqp[(size_t)2 * s * HWo] = v;
+                    } else {
+                        for (int ry = 0; ry < rep; ++ry)
+                            for (int rx = 0; rx < rep; ++rx) zqp[(size_t)2 * s * HWo + (size_t)ry * Wout + rx] = v;
+                    }
+                }
                 lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
             }
         };
         if (zq != nullptr) finish(std::true_type{});
         else finish(std::false_type{});
+        if (ROUTED) lsum *= (float)(rep * rep);
     }
     block_sum += (double)lsum;
     }   // chunk loop
@@ -322,52 +355,62 @@ int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st
     return (int)hipGetLastError();
 }
 
-template <int D>
+template <int D, bool ROUTED>
 static int launch_exact(const float *z, const float *tiles, const float *E, const float *mask,
                         int HW, int K, long N, float *zq, long long *codes, double *partials,
-                        const int *list, const int *list_count, DvqLossTail tail, hipStream_t st)
+                        const int *list, const int *list_count, DvqLossTail tail, const DvqRouted &rv,
+                        hipStream_t st)
 {
     static unsigned long long done_dense = 0, done_list = 0;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
-    dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, false>, (int)shmem, &done_dense);
-    dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, true>, (int)shmem, &done_list);
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, false, ROUTED>, (int)shmem, &done_dense);
+    if (rc) return rc;
+    rc = dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, true, ROUTED>, (int)shmem, &done_list);
+    if (rc) return rc;
     int blocks = (int)((N + 127) / 128);
     if (list != nullptr) {
         if (blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
-        hipLaunchKernelGGL((vq_assign_exact_kernel<D, true>), dim3(blocks), dim3(256), shmem, st,
-                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
+        hipLaunchKernelGGL((vq_assign_exact_kernel<D, true, ROUTED>), dim3(blocks), dim3(256), shmem, st,
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv);
     } else {
-        hipLaunchKernelGGL((vq_assign_exact_kernel<D, false>), dim3(blocks), dim3(256), shmem, st,
-                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail);
+        hipLaunchKernelGGL((vq_assign_exact_kernel<D, false, ROUTED>), dim3(blocks), dim3(256), shmem, st,
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv);
     }
     return (int)hipGetLastError();
 }
 
-// pass 2 of the filter path: the tokens listed in list[0 .. *list_count)
+static const DvqRouted kNoRoute = {};
+
+// pass 2 of the filter path: the tokens listed in list[0 .. *list_count); rv != nullptr: routed token ids
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                          const int *list, const int *list_count, DvqLossTail tail, hipStream_t st)
+                          const int *list, const int *list_count, DvqLossTail tail, const DvqRouted *rv,
+                          hipStream_t st)
 {
+    if (rv != nullptr) {
+        switch (D) {
+        case 64:  return launch_exact<64, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
+        case 128: return launch_exact<128, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
+        case 256: return launch_exact<256, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
+        default:  return -1000;
+        }
+    }
     switch (D) {
-    case 64:  return launch_exact<64>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
-    case 128: return launch_exact<128>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
-    case 256: return launch_exact<256>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, st);
+    case 64:  return launch_exact<64, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
+    case 128: return launch_exact<128, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
+    case 256: return launch_exact<256, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
     default:  return -1000;
     }
 }
 
+// every token by the exact chain; rv != nullptr: the unique tokens of a routed batch (N = worst-case
+// token count = B * HWout; ids beyond the last slot are invalid)
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                     hipStream_t st)
+                     const DvqRouted *rv, hipStream_t st)
 {
-    const float *tiles = prep;
     const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f, nullptr, 0};
-    switch (D) {
-    case 64:  return launch_exact<64>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
-    case 128: return launch_exact<128>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
-    case 256: return launch_exact<256>(z, tiles, E, mask, HW, K, N, zq, codes, partials, nullptr, nullptr, none, st);
-    default:  return -1000;
-    }
+    return dvq_launch_exact_list(z, prep, E, mask, D, HW, K, N, zq, codes, partials, nullptr, nullptr, none, rv, st);
 }
 
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,

@@ -28,7 +28,8 @@
 //   reference side, d = fl(fl(xn+en) - 2 dotc), dotc the D-term fp32 chain:
 //                                 <= 2^(a+b) [u(1+u)(xn+en) + (u + gamma_D)(1+gamma_D) ||z|| ||e_j||]
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
-#include "dvq_common.h"
+#include "dvq_filter.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // z is read once and z_q written once per launch: stream them past L2 (nt) so that the codebook
@@ -44,32 +45,9 @@
 #define DVQ_STORE_ZQ(p, v) (*(p) = (v))
 #endif
 
-struct DvqF16Meta {
-    int ok;         // 1: codebook finite and representable; 0: every token goes to the exact list
-    int b_exp;      // eh = fp16(2^b e),  2^b max|e| in [2^14, 2^15)
-    float scale_b;  // 2^b
-    float emax;     // >= max_j ||e_j||
-    float enmax;    // max_j en_j
-    float etamax;   // >= max_j ||2^b e_j - eh_j||
-    float pad[10];
-};
-
-static constexpr float GAMMA_P = 1.2207031e-4f;   // 2^-13
-static constexpr float PACK_E = 1.93e-6f;         // 2^-19 (1 + margin)
-static constexpr float REF_XN = 1.2e-7f;          // 2u
-static constexpr float REF_RE = 1.6e-5f;          // u + gamma_256 (D <= 256)
-static constexpr float DVQ_SEED_PAD = -3.0e38f;
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
-static constexpr int RES_SLOTS = 32;              // resolver: queued tokens per workgroup
-static constexpr int RES_CAND = 512;              // resolver: candidate pairs per workgroup
-
-// record of one queued token (written by pass 1, read by the resolver)
-//   [zf: D*4 B in channel order][meta 32 B]   (the resolver re-derives the fp16 fragments: same RNE conversion)
-__host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; }
-struct RecMeta { int n; float xn; float thr; float seed_scale; unsigned long long best; int prov; int pad; };   // 32 B
-//   best: merged (distance, code) key of the sliced resolver (large K), ~0 = none yet; written ~0 by pass 1
 
 // ---------------------------------------------------------------------------------------------
 // prep: meta (scale, norm maxima, finiteness), fp16 tile images, rounding-residual norm
@@ -186,27 +164,6 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
     }
 }
 
-__device__ __forceinline__ float vmax_raw(float a, float b)
-{
-    float r;     // plain v_max_f32: no canonicalising pre-ops (fmaxf() adds two per call)
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float vmax_abs(float a, float b)
-{
-    float r;     // max(a, |b|) in one instruction (source modifier instead of a separate v_and)
-    asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float vmax3_raw(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // pass 1: 4-wave workgroups of 128 consecutive tokens, TWO per CU (<= 256 VGPRs).  A wave keeps its
 // 32 tokens twice in registers -- fp32 (D/2 VGPRs, read once, reused for z_q and the resolver
@@ -318,20 +275,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         zeta2 += __shfl_xor(zeta2, 32);
-        const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
-        const bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok
-                         || !((0.5f * sB * enmax) < 1.0e37f);
-        const float zeta = sqrtf(zeta2) * 1.001f;
-        const float Rh = sqrtf(xn) * 1.00001f;
-        const float zn_ = Rh + zeta;
-        const float ehn = sB * emax + etamax;
-        float Wv = zeta * ehn + zn_ * etamax
-                   + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
-                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
-                   + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
-        thr2W = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+        thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     }
-    const float seed_scale = -0.5f * sB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
@@ -492,8 +437,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             }
             if (h == 0) {
                 RecMeta rm;
-                rm.n = n; rm.xn = xn; rm.thr = thr; rm.seed_scale = seed_scale; rm.prov = code;
-                rm.best = ~0ull; rm.pad = 0;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = n; rm.prov = code;
+                rm.best = ~0ull; rm.rep = 1;
                 *(RecMeta *)(rec + (size_t)D * 4) = rm;
             }
         }
@@ -633,20 +578,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
         xn[u] = x;
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         zeta2 += __shfl_xor(zeta2, 32);
-        const float emax = meta->emax, enmax = meta->enmax, etamax = meta->etamax;
-        const bool bad = !(x < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok
-                         || !((0.5f * sB * enmax) < 1.0e37f);
-        const float zeta = sqrtf(zeta2) * 1.001f;
-        const float Rh = sqrtf(x) * 1.00001f;
-        const float zn_ = Rh + zeta;
-        const float ehn = sB * emax + etamax;
-        float Wv = zeta * ehn + zn_ * etamax
-                   + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
-                   + PACK_E * sB * (Rh * emax + 0.5f * enmax)
-                   + sB * (REF_XN * (x + enmax) + REF_RE * Rh * emax);
-        thr2W[u] = bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+        thr2W[u] = dvq_filter_threshold(x, amax, zeta2, sB, meta);
     }
-    const float seed_scale = -0.5f * sB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
 
     // ---- code loop: 32 MFMAs per tile and wave, every A fragment used for both token blocks
@@ -798,8 +731,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
         else finish(std::false_type{});
         if (rec != nullptr && h == 0) {
             RecMeta rm;
-            rm.n = n; rm.xn = xnu; rm.thr = thru; rm.seed_scale = seed_scale; rm.prov = cd;
-            rm.best = ~0ull; rm.pad = 0;
+            rm.n = n; rm.xn = xnu; rm.thr = thru; rm.tokid = n; rm.prov = cd;
+            rm.best = ~0ull; rm.rep = 1;
             *(RecMeta *)(rec + (size_t)D * 4) = rm;
         }
     };
@@ -842,8 +775,10 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    int nslice, int *__restrict__ chunk_sync)
+    int nslice, int *__restrict__ chunk_sync, int Wout)
 {
+    // HW = positions per image of the OUTPUT grid; a routed token (RecMeta.rep > 1) covers rep x rep
+    // positions, rows Wout apart, all rewritten with the same values.
     // Large codebooks: the code tiles are cut into `nslice` slices (blockIdx.y); each slice resolves its
     // candidates locally, merges its per-token best into the record with a 64-bit atomicMin, and the
     // slice that arrives last at the chunk's ticket does the rewrite.  nslice == 1: all of it in LDS.
@@ -987,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
             int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
-            exact_list[pos] = m2.n;                   // pass 1's loss term for it is taken back below
+            exact_list[pos] = m2.tokid;               // pass 1's loss term for it is taken back below
             pos = atomicAdd(&misc[1], 1);
             rewrite[pos] = (tid << 20) | 0xFFFFF;
         } else {
@@ -1007,6 +942,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const char *r2 = records + (size_t)(base + sl) * rec_bytes(D);
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         const long n = m2.n;
+        const int rep = m2.rep;
         const long bimg = n / HW;
         const int hw = (int)(n - bimg * HW);
         const float m = (mask != nullptr) ? mask[n] : 1.0f;
@@ -1018,13 +954,20 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float dn = __fsub_rn(en_[j], zv[j]), dold = __fsub_rn(eo[j], zv[j]);
-                if (zq != nullptr && !take_back_only)
-                    zq[((size_t)bimg * D + k0 + j) * HW + hw] = __fadd_rn(zv[j], dn);
+                if (zq != nullptr && !take_back_only) {
+                    float *zp = zq + ((size_t)bimg * D + k0 + j) * HW + hw;
+                    const float v = __fadd_rn(zv[j], dn);
+                    for (int ry = 0; ry < rep; ++ry)
+                        for (int rx = 0; rx < rep; ++rx) zp[(size_t)ry * Wout + rx] = v;
+                }
                 float tn = take_back_only ? 0.0f : __fmul_rn(__fmul_rn(dn, dn), m);
                 delta += tn - __fmul_rn(__fmul_rn(dold, dold), m);
             }
         }
-        if (lane == 0 && !take_back_only) codes[n] = (long long)win;
+        if (lane == 0 && !take_back_only)
+            for (int ry = 0; ry < rep; ++ry)
+                for (int rx = 0; rx < rep; ++rx) codes[n + (long)ry * Wout + rx] = (long long)win;
+        delta *= (float)(rep * rep);
         dsum += (double)delta;
     }
     if (partials != nullptr) {
@@ -1047,7 +990,8 @@ __global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict
 // ---------------------------------------------------------------------------------------------
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                          const int *list, const int *list_count, DvqLossTail tail, hipStream_t st);
+                          const int *list, const int *list_count, DvqLossTail tail, const DvqRouted *rv,
+                          hipStream_t st);
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -1104,79 +1048,235 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// partials layout: [pass 1: ceil(N/128)][resolver: cap/RES_SLOTS][exact list: min(ceil(N/128), DVQ_EXACT_LIST_BLOCKS)]
+// partials layout: [pass 1: np1 = its grid][resolver: cap/RES_SLOTS][exact list: min(ceil(N/128), DVQ_EXACT_LIST_BLOCKS)]
 static int list_blocks(long N)
 {
     long nb = (N + 127) / 128;
     return (int)(nb < DVQ_EXACT_LIST_BLOCKS ? nb : DVQ_EXACT_LIST_BLOCKS);
 }
-int dvq_filter_nparts(long N) { return (int)((N + 127) / 128) + rec_capacity(N) / RES_SLOTS + list_blocks(N); }
+
+// ---- low-register pass 1 (vq_assign_routed.hip)
+int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, int nblocks, hipStream_t st);
+int dvq_pass1_tokens_per_block(int variant);
+int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
+                              long long *indices, float *cmask, long long *gate_out, int *counts,
+                              unsigned short *cells, int *seg_base, int nseg, int *ticket, hipStream_t st);
+
+// Which pass-1 kernel: DVQ_PASS1_VARIANT = -1 legacy (fp32 copy of z in registers, 2 waves / SIMD; the wide
+// form for large codebooks), 0..3 the low-register forms of vq_assign_routed.hip.  The routed op always
+// takes a low-register form (DVQ_ROUTED_VARIANT, default 0).
+static int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    int x = atoi(v);
+    return (x < lo || x > hi) ? dflt : x;
+}
+#ifndef DVQ_PASS1_DEFAULT
+#define DVQ_PASS1_DEFAULT -1
+#endif
+#ifndef DVQ_ROUTED_DEFAULT
+#define DVQ_ROUTED_DEFAULT 0
+#endif
+static int g_dense_variant = -2, g_routed_variant = -2;      // -2: not chosen yet (environment / default)
+static int dense_variant()
+{
+    int v = __atomic_load_n(&g_dense_variant, __ATOMIC_RELAXED);
+    if (v == -2) { v = env_int("DVQ_PASS1_VARIANT", DVQ_PASS1_DEFAULT, -1, 3); __atomic_store_n(&g_dense_variant, v, __ATOMIC_RELAXED); }
+    return v;
+}
+static int routed_variant()
+{
+    int v = __atomic_load_n(&g_routed_variant, __ATOMIC_RELAXED);
+    if (v == -2) { v = env_int("DVQ_ROUTED_VARIANT", DVQ_ROUTED_DEFAULT, 0, 3); __atomic_store_n(&g_routed_variant, v, __ATOMIC_RELAXED); }
+    return v;
+}
+// tuning / testing aid (dvq_set_pass1_variant): -2 keeps the current choice
+int dvq_choose_pass1_variant(int dense, int routed)
+{
+    if (dense < -2 || dense > 3 || routed < -2 || routed > 3 || routed == -1) return -1;
+    if (dense != -2) __atomic_store_n(&g_dense_variant, dense, __ATOMIC_RELAXED);
+    if (routed != -2) __atomic_store_n(&g_routed_variant, routed, __ATOMIC_RELAXED);
+    return 0;
+}
+
+struct FilterWs {
+    int *counters, *chunk_sync, *exact_list;
+    char *records;
+    int cap;
+};
+
+static FilterWs carve_ws(void *ws_extra, long N, int D)
+{
+    FilterWs w;
+    w.counters = (int *)ws_extra;
+    w.cap = rec_capacity(N);
+    w.chunk_sync = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
+    const size_t sync_bytes = align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
+    w.exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
+    w.records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
+    (void)D;
+    return w;
+}
 
 template <int D>
-static int launch_filter(const float *z, const char *img, const DvqF16Meta *meta, const float *en_all,
-                         const float *E, const float *mask, int HW, int K, long N, float *zq,
-                         long long *codes, double *partials, int *counters, int *exact_list,
-                         char *records, int cap, bool pass1_only, bool force_wide, int *chunk_sync, hipStream_t st)
+static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
+                               const float *mask, int HW, int K, long N, float *zq, long long *codes,
+                               double *partials, const FilterWs &w, bool force_wide, hipStream_t st)
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
-    dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
+    if (rc) return rc;
     const int nb1 = (int)((N + 127) / 128);
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
                                                              // with two 256-token workgroups: two blocks per wave
             static unsigned long long done_w = 0;
-            dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
+            rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
+            if (rc) return rc;
             hipLaunchKernelGGL(vq_assign_filter_wide_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), shmem1, st,
-                               z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records,
-                               cap / DVQ_QSHARDS, nb1);
-        } else {
-            hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                               E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
+                               z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                               w.cap / DVQ_QSHARDS, nb1);
+            return (int)hipGetLastError();
         }
-    } else {
-        hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap / DVQ_QSHARDS);
     }
-    if (pass1_only) return (int)hipGetLastError();
-    const int nslice = resolver_slices(K);
-    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(cap / RES_SLOTS, nslice), dim3(256), 0, st, img, meta,
-                       en_all, E, mask, HW, K, zq, codes, partials ? partials + nb1 : nullptr, counters,
-                       exact_list, records, cap / DVQ_QSHARDS, nslice, chunk_sync);
+    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                       E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records, w.cap / DVQ_QSHARDS);
     return (int)hipGetLastError();
 }
 
+template <int D>
+static int launch_resolver(const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
+                           const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
+                           const FilterWs &w, int Wout, hipStream_t st)
+{
+    const int nslice = resolver_slices(K);
+    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(w.cap / RES_SLOTS, nslice), dim3(256), 0, st, img, meta,
+                       en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
+                       w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout);
+    return (int)hipGetLastError();
+}
+
+static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
+                             const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
+                             const FilterWs &w, int Wout, hipStream_t st)
+{
+    switch (D) {
+    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
+    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
+    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
+    default:  return -1000;
+    }
+}
+
+// Dense op: z [B, D, HW].  Routed op (rv != nullptr): the unique tokens of rv; N = B * HWout (the
+// all-fine worst case sizes the workspace and the grids), mask = the codebook_mask the prepass wrote.
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
-                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta, hipStream_t st)
+                      void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
+                      const DvqRouted *rv, hipStream_t st)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
     const DvqF16Meta *meta = (const DvqF16Meta *)base;
     const char *img = base + 256;
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
-    int *counters = (int *)ws_extra;
-    const int cap = rec_capacity(N);
-    int *chunk_sync = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
-    const size_t sync_bytes = align256((size_t)cap / RES_SLOTS * 2 * sizeof(int));
-    int *exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
-    char *records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
-    // [0] queue, [1] exact list, [4] finalize ticket.  A kernel rather than hipMemsetAsync: cheaper than
-    // the runtime's fill kernel, and the op stays a pure chain of kernel nodes under hipGraph capture.
-    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, counters, chunk_sync,
-                       resolver_slices(K) > 1 ? cap / RES_SLOTS * 2 : 0);
-    int rc;
-    switch (D) {
-    case 64:  rc = launch_filter<64>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
-    case 128: rc = launch_filter<128>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
-    case 256: rc = launch_filter<256>(z, img, meta, en_all, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, cap, pass1_only, force_wide, chunk_sync, st); break;
-    default:  return -1000;
+    const FilterWs w = carve_ws(ws_extra, N, D);
+    const bool routed = rv != nullptr;
+    if (!routed) {
+        // [0] queue, [1] exact list, [4] finalize ticket, [5] prepass ticket.  A kernel rather than
+        // hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of kernel
+        // nodes under hipGraph capture.  (The routed op zeroes them before its prepass.)
+        hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
+                           resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
+    }
+    const int variant = routed ? routed_variant() : ((force_wide || D != 256) ? -1 : dense_variant());
+    int rc, np1;
+    if (variant < 0) {
+        np1 = (int)((N + 127) / 128);
+        switch (D) {
+        case 64:  rc = launch_legacy_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
+        case 128: rc = launch_legacy_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
+        case 256: rc = launch_legacy_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
+        default:  return -1000;
+        }
+    } else {
+        const int tpb = dvq_pass1_tokens_per_block(variant);
+        np1 = (int)((N + tpb - 1) / tpb);
+        P1Args a;
+        a.z = z; a.HW = HW; a.N = N;
+        if (routed) a.rv = *rv; else a.rv = DvqRouted{};
+        a.img = img; a.meta = meta; a.E = E; a.mask = mask; a.K = K; a.zq = zq; a.codes = codes;
+        a.partials = partials; a.counters = w.counters; a.exact_list = w.exact_list; a.records = w.records;
+        a.rec_cap = w.cap / DVQ_QSHARDS;
+        rc = dvq_launch_pass1_lowreg(D, routed, variant, a, np1, st);
     }
     if (rc || pass1_only) return rc;
-    double *partials3 = partials ? partials + (N + 127) / 128 + cap / RES_SLOTS : nullptr;
+    const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
+    rc = launch_resolver_d(D, img, meta, en_all, E, mask, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
+                           w, Wout, st);
+    if (rc) return rc;
+    double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
     // the list kernel is the last of the op: it also sums all partials into loss[0..1]
-    const DvqLossTail tail = {partials ? loss : nullptr, partials, counters + 4, dvq_filter_nparts(N),
-                              1.0 / ((double)N * D), beta, counters, cap / DVQ_QSHARDS};
-    return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HW, K, N, zq, codes, partials3,
-                                 exact_list, counters + 1, tail, st);
+    const DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + 4,
+                              np1 + w.cap / RES_SLOTS + list_blocks(N),
+                              1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS};
+    return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
+                                 w.exact_list, w.counters + 1, tail, rv, st);
+}
+
+// ---- routed op ---------------------------------------------------------------------------------
+// routing tables behind the filter workspace: [counts G*B ints][seg_base nseg+1 ints][cells G*B*ncell u16]
+static int routed_nseg(int G, int B) { return (B + DVQ_ROUTE_GROUP - 1) / DVQ_ROUTE_GROUP * G; }
+size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc)
+{
+    return align256((size_t)G * B * sizeof(int)) + align256((size_t)(routed_nseg(G, B) + 1) * sizeof(int)) +
+           align256((size_t)G * B * hc * wc * sizeof(unsigned short));
+}
+
+// zero counters -> prepass (indices, codebook_mask, gate_out, routing tables) -> the filter op (or, exact
+// mode, every unique token by the exact chain).  ws_extra: dvq_filter_ws_extra_bytes(N = B*HWout) bytes
+// followed by dvq_routed_tables_bytes.
+int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
+                     int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
+                     const DvqRouted *rv, hipStream_t st);
+
+int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
+                      const float *h_median, const float *h_fine, const void *prep, const float *E,
+                      int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
+                      float *loss, long long *indices, float *cmask, long long *gate_out,
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st)
+{
+    const int SC = (G == 2) ? 2 : 4;
+    const int Wout = SC * wc, HWout = SC * hc * Wout;
+    const long N = (long)B * HWout;
+    const FilterWs w = carve_ws(ws_extra, N, D);
+    char *tab = (char *)ws_extra + dvq_filter_ws_extra_bytes(D, HWout, K, N);
+    int *counts = (int *)tab;
+    int *seg_base = (int *)(tab + align256((size_t)G * B * sizeof(int)));
+    const int nseg = routed_nseg(G, B);
+    unsigned short *cells = (unsigned short *)((char *)seg_base + align256((size_t)(nseg + 1) * sizeof(int)));
+    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
+                       resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
+    int rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, counts, cells,
+                                       seg_base, nseg, w.counters + 5, st);
+    if (rc) return rc;
+    DvqRouted rv{};
+    rv.G = G; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = Wout; rv.HWout = HWout;
+    rv.counts = counts; rv.seg_base = seg_base; rv.cells = cells; rv.nseg = nseg;
+    if (G == 2) {
+        rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
+        rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 0;
+        rv.rep[0] = 2; rv.rep[1] = 1; rv.rep[2] = 0;
+        rv.mval[0] = 0.25f; rv.mval[1] = 1.0f; rv.mval[2] = 0.0f;
+    } else {
+        rv.src[0] = h_coarse; rv.src[1] = h_median; rv.src[2] = h_fine;
+        rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 4;
+        rv.rep[0] = 4; rv.rep[1] = 2; rv.rep[2] = 1;
+        rv.mval[0] = 0.0625f; rv.mval[1] = 0.25f; rv.mval[2] = 1.0f;
+    }
+    if (exact) return dvq_launch_exact(nullptr, (const float *)prep, E, cmask, D, HWout, K, N, zq, codes, partials, &rv, st);
+    return dvq_launch_filter(nullptr, prep, E, cmask, D, HWout, K, N, zq, codes, partials, ws_extra, pass1_only, false,
+                             loss, beta, &rv, st);
 }

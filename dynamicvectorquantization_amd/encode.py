@@ -17,12 +17,40 @@ asynchronously under the next batch's kernels.
 import torch
 import torch.distributed as dist
 
+from . import _lib
+from .quantize import VectorQuantize2, vq_assign_routed_dual, vq_assign_routed_triple
 from .router import DualGrainFixedEntropyRouter, route_select_dual, route_select_dual_entropy, route_select_triple
 
 
+def _can_route(quantize, quant_conv, *feats):
+    """the fused routed assign applies when nothing sits between select and quantizer and nothing needs a
+    gradient (inference / frozen stage 1): an eval-mode VectorQuantize2 on NCHW feature maps"""
+    if quant_conv is not None or not isinstance(quantize, VectorQuantize2):
+        return False
+    if quantize.training or not quantize.accept_image_fmap:
+        return False
+    if torch.is_grad_enabled() and any(t.requires_grad for t in feats):
+        return False
+    return all(t.is_cuda and t.dtype == torch.float32 for t in feats) and feats[0].shape[2] * feats[0].shape[3] <= 1024
+
+
 def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0):
-    """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode."""
-    if isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda:
+    """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode
+    (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).  Without a quant_conv (and without
+    autograd) gate + routing tail + quantizer run as ONE routed op on the unique tokens; otherwise as
+    route select -> quant_conv -> dense assign."""
+    fixed = isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda
+    if _can_route(quantize, quant_conv, h_coarse, h_fine):
+        cb = quantize.codebook
+        kw = dict(beta=quantize.beta, mode=quantize.assign_mode)
+        if fixed:
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
+                                      threshold=router.fine_grain_threshold, **kw)
+        else:
+            gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, gate=gate, **kw)
+        return r["zq"], r["loss"][1], (None, None, r["codes"]), r["indices"], r["gate"].permute(0, 3, 1, 2)
+    if fixed:
         sel = route_select_dual_entropy(entropy, router.fine_grain_threshold, h_coarse, h_fine)   # gate fused in
     else:
         gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
@@ -35,8 +63,13 @@ def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=Non
 
 
 def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None, temp=0.0):
-    """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode."""
+    """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77)."""
     gate = router(h_fine=h_fine, h_median=h_median, h_coarse=h_coarse, entropy=None)
+    if _can_route(quantize, quant_conv, h_coarse, h_median, h_fine):
+        cb = quantize.codebook
+        r = vq_assign_routed_triple(h_coarse, h_median, h_fine, cb.codes, cb._prep, gate, beta=quantize.beta,
+                                    mode=quantize.assign_mode)
+        return r["zq"], r["loss"][1], (None, None, r["codes"]), r["indices"], gate.permute(0, 3, 1, 2)
     sel = route_select_triple(gate, h_coarse, h_median, h_fine)
     h = sel["h_triple"]
     if quant_conv is not None:
@@ -134,3 +167,79 @@ def all_gather_codes(codes, grain_indices, loss_sum, numel, num_codes, global_ba
     if async_op:
         return _PendingGather(work, unpack)
     return unpack()
+
+
+class CodeExchange:
+    """The exchange step with everything preallocated: per step ONE pack kernel (`dvq_exchange_pack`), ONE
+    all-gather (RCCL when the group is "nccl"), ONE unpack kernel (`dvq_exchange_unpack`) -- no allocation,
+    no small torch ops, no host round trip.  Same wire format as all_gather_codes.
+
+        xch = CodeExchange(codes, grain, num_codes, global_batch, numel_per_image)   # shapes / device from templates
+        xch.start(codes, grain, loss)     # loss[0] = local mean; queues pack + async all-gather
+        ... next batch's kernels ...
+        g_codes, g_grain, g_mean = xch.finish()   # stream-waits for the collective, queues the unpack
+
+    CPU tensors (the gloo tests of the host logic) take the torch-op pack of all_gather_codes."""
+
+    def __init__(self, codes, grain, num_codes, global_batch, numel_per_image, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.num_codes, self.global_batch, self.numel_per_image = num_codes, global_batch, numel_per_image
+        sizes = [shard_slice(global_batch, r, self.world) for r in range(self.world)]
+        self.shard_sizes = [e - s for s, e in sizes]
+        self.b_local = self.shard_sizes[self.rank]
+        self.b_max = max(self.shard_sizes)
+        self.cshape = tuple(codes.shape[1:])
+        self.gshape = tuple(grain.shape[1:]) if grain is not None else None
+        self.cpi = int(torch.Size(self.cshape).numel())
+        self.gpi = int(torch.Size(self.gshape).numel()) if self.gshape is not None else 0
+        self.dev = codes.device
+        self.on_gpu = codes.is_cuda
+        self._pending = None
+        self._result = None
+        if self.on_gpu:
+            self.nbytes = _lib.lib.dvq_exchange_bytes(self.cpi, self.gpi, self.b_max, num_codes)
+            self.local = torch.empty(self.nbytes, dtype=torch.uint8, device=self.dev)
+            self.gathered = torch.empty(self.world * self.nbytes, dtype=torch.uint8, device=self.dev)
+            self.g_codes = torch.empty((global_batch,) + self.cshape, dtype=torch.int64, device=self.dev)
+            self.g_grain = (torch.empty((global_batch,) + self.gshape, dtype=torch.int64, device=self.dev)
+                            if self.gshape is not None else None)
+            self.g_mean = torch.empty(1, dtype=torch.float32, device=self.dev)
+
+    def start(self, codes, grain, loss):
+        """loss: tensor whose element 0 is the local mean of the loss numerator (vq_assign's loss[0]), or None"""
+        assert self._pending is None, "finish() the previous exchange first"
+        numel = float(self.b_local * self.numel_per_image)
+        if not self.on_gpu:
+            lsum = (loss.reshape(-1)[0].double() * numel) if loss is not None else torch.zeros((), dtype=torch.float64)
+            self._pending = all_gather_codes(codes, grain, lsum, numel if loss is not None else 0.0, self.num_codes,
+                                             self.global_batch, group=self.group, async_op=True)
+            return
+        assert codes.is_contiguous() and codes.dtype == torch.int64 and codes.shape[0] == self.b_local
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.lib.dvq_exchange_pack(
+                codes.data_ptr(), _lib.ptr(grain) if self.gpi else 0, _lib.ptr(loss), numel, self.b_local, self.b_max,
+                self.cpi, self.gpi, self.num_codes, self.local.data_ptr(), _lib.stream_ptr(self.dev)),
+                "dvq_exchange_pack")
+        self._pending = dist.all_gather_into_tensor(self.gathered, self.local, group=self.group, async_op=True)
+
+    def finish(self):
+        if self._pending is None:
+            return self._result
+        if not self.on_gpu:
+            self._result = self._pending.wait()
+            self._pending = None
+            return self._result
+        self._pending.wait()                       # the current stream waits for the collective
+        self._pending = None
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.lib.dvq_exchange_unpack(
+                self.gathered.data_ptr(), self.world, self.global_batch, self.cpi, self.gpi, self.num_codes,
+                self.g_codes.data_ptr(), _lib.ptr(self.g_grain), self.g_mean.data_ptr(), _lib.stream_ptr(self.dev)),
+                "dvq_exchange_unpack")
+        self._result = (self.g_codes, self.g_grain, self.g_mean[0])
+        return self._result
+
+    def result(self):
+        return self._result

@@ -26,13 +26,23 @@ _lib_handle = _lib.lib
 
 class _CodebookPrep:
     """Per-codebook device buffers of the assign kernels (tile images, exact norms), rebuilt
-    whenever the codebook tensor changes (version counter / storage / device)."""
+    whenever the codebook tensor changes: the key is (storage, autograd version, shape, device),
+    and `invalidate()` drops it.  Writes through `.data` do NOT bump the version counter
+    (`w.data.copy_(...)`, old-style optimizers): the owning modules call invalidate() from
+    `_load_from_state_dict`, `_apply`, the EMA update and at every training-mode forward; any
+    other `.data` writer must call `module.invalidate_codebook_cache()` itself.
+
+    Workspaces (queue counters, records, loss partials) are kept PER STREAM, so two streams driving
+    the same quantizer never share a queue."""
 
     def __init__(self):
         self.key = None
         self.buf = None
-        self.ws = None
-        self.ws_key = None
+        self._ws = {}            # (B, D, HW, K, mode, device, stream) -> uint8 tensor
+        self._last_ws = None
+
+    def invalidate(self):
+        self.key = None
 
     def get(self, codebook):
         K, D = codebook.shape
@@ -49,24 +59,32 @@ class _CodebookPrep:
             self.key = key
         return self.buf
 
-    def workspace(self, B, D, HW, K, mode, device):
-        key = (B, D, HW, K, mode, device)
-        if key != self.ws_key:
-            nbytes = _lib_handle.dvq_vq_assign_workspace_bytes(B, D, HW, K, mode)
-            self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self.ws_key = key
-        return self.ws
+    def workspace(self, B, D, HW, K, mode, device, nbytes=None):
+        key = (B, D, HW, K, mode, device, _lib.stream_ptr(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            if nbytes is None:
+                nbytes = _lib_handle.dvq_vq_assign_workspace_bytes(B, D, HW, K, mode)
+            if len(self._ws) >= 8:                   # shapes rarely change: keep the table small
+                self._ws.clear()
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        self._last_ws = (key, ws)
+        return ws
 
     def fallback_count(self):
         """(tokens queued for the resolver, tokens sent to the full exact pass) of the last
-        filter-mode call on this workspace (syncs)"""
-        if self.ws_key is None:
+        filter-mode call through this object (syncs)"""
+        if self._last_ws is None:
             return (0, 0)
-        B, D, HW, K, mode, _dev = self.ws_key
-        if mode not in (_lib.MODE_FILTER, _lib.MODE_FILTER_PASS1, _lib.MODE_FILTER_WIDE):
+        (B, D, HW, K, mode, _dev, _st), ws = self._last_ws
+        if mode not in _lib.FILTER_MODES:
             return (0, 0)
-        off = _lib_handle.dvq_vq_assign_fallback_count_offset(B, D, HW, K)
-        c = self.ws[off:off + 8].view(torch.int32).tolist()
+        if isinstance(HW, tuple):                   # routed workspace: ("routed2" | "routed3", hc, wc)
+            off = _lib_handle.dvq_vq_assign_routed_fallback_count_offset(int(HW[0][-1]), B, D, HW[1], HW[2], K)
+        else:
+            off = _lib_handle.dvq_vq_assign_fallback_count_offset(B, D, HW, K)
+        c = ws[off:off + 8].view(torch.int32).tolist()
         return (int(c[0]), int(c[1]))
 
 
@@ -110,6 +128,124 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
     return zq, codes, loss
 
 
+def _gate_for_routed(gate, G):
+    """-> (tensor, gate_kind) for a router output [B, hc, wc, G] (f32 logits or int64)"""
+    if not gate.is_cuda:
+        raise _lib.DvqError("gate is on %s: the dvq kernels run on the GPU only" % gate.device)
+    if gate.dim() != 4 or gate.shape[-1] != G:
+        raise ValueError("gate must be [B, h, w, %d], got %s" % (G, tuple(gate.shape)))
+    if gate.dtype == torch.int64:
+        return gate.contiguous(), _lib.GATE_I64
+    return (gate if gate.dtype == torch.float32 else gate.float()).contiguous(), _lib.GATE_F32
+
+
+def _routed_outputs(h_fine, B, hc, wc, S, want_zq, want_loss, with_gate):
+    dev = h_fine.device
+    zq = torch.empty_like(h_fine) if want_zq else None
+    codes = torch.empty((B, S * hc, S * wc), dtype=torch.int64, device=dev)
+    loss = torch.empty(2, dtype=torch.float32, device=dev) if want_loss else None
+    indices = torch.empty((B, hc, wc), dtype=torch.int64, device=dev)
+    cmask = torch.empty((B, 1, S * hc, S * wc), dtype=torch.float32, device=dev)
+    gate_out = torch.empty((B, hc, wc, 2), dtype=torch.int64, device=dev) if with_gate else None
+    return zq, codes, loss, indices, cmask, gate_out
+
+
+def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=None, threshold=None, beta=0.25,
+                          want_zq=True, want_loss=True, mode=_lib.MODE_FILTER, out=None):
+    """Routing tail of DualGrainEncoder (EncoderDual.py:134-149) + VectorQuantize2.forward
+    (quantize2_mask.py:157-191) as ONE op on the unique tokens (`dvq_vq_assign_routed_dual_f32`):
+    h_coarse [B, D, hc, wc], h_fine [B, D, 2hc, 2wc]; either `gate` [B, hc, wc, 2] (f32 logits / int64) or
+    `entropy` [B, hc, wc] + `threshold` (the fixed-entropy router fused in).
+    -> dict(zq, codes [B, 2hc, 2wc] i64, loss[2], indices [B, hc, wc] i64, codebook_mask [B, 1, 2hc, 2wc],
+            gate (entropy form: the router's int64 gate [B, hc, wc, 2], else the input gate)).
+    `out` = (zq, codes, loss, indices, codebook_mask, gate_out) preallocated (benchmark / graph capture)."""
+    h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
+    h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
+    codebook = _lib.require_cuda_f32(codebook, "codebook")
+    B, D, hc, wc = h_coarse.shape
+    K = codebook.shape[0]
+    if tuple(h_fine.shape) != (B, D, 2 * hc, 2 * wc) or codebook.shape[1] != D:
+        raise ValueError("shape mismatch: h_coarse %s h_fine %s codebook %s" %
+                         (tuple(h_coarse.shape), tuple(h_fine.shape), tuple(codebook.shape)))
+    if (gate is None) == (entropy is None):
+        raise ValueError("give exactly one of gate / entropy")
+    if entropy is not None:
+        g = _lib.require_cuda_f32(entropy, "entropy")
+        if tuple(g.shape) != (B, hc, wc) or threshold is None:
+            raise ValueError("entropy must be [B, hc, wc] and come with a threshold")
+        kind, thr = _lib.GATE_ENTROPY, float(threshold)
+    else:
+        g, kind = _gate_for_routed(gate, 2)
+        if tuple(g.shape[:3]) != (B, hc, wc):
+            raise ValueError("gate %s does not match h_coarse %s" % (tuple(gate.shape), tuple(h_coarse.shape)))
+        thr = 0.0
+    if out is not None:
+        zq, codes, loss, indices, cmask, gate_out = out
+    else:
+        zq, codes, loss, indices, cmask, gate_out = _routed_outputs(h_fine, B, hc, wc, 2, want_zq, want_loss,
+                                                                    entropy is not None)
+    res = {"zq": zq, "codes": codes, "loss": loss, "indices": indices, "codebook_mask": cmask,
+           "gate": gate_out if entropy is not None else gate}
+    if B * hc * wc == 0:
+        if loss is not None:
+            loss.fill_(float("nan"))
+        return res
+    nbytes = _lib_handle.dvq_vq_assign_routed_workspace_bytes(2, B, D, hc, wc, K, mode)
+    if nbytes == 0:
+        raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
+    ws = prep.workspace(B, D, ("routed2", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    with torch.cuda.device(h_fine.device):
+        pbuf = prep.get(codebook)
+        _lib.check(_lib_handle.dvq_vq_assign_routed_dual_f32(
+            g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(),
+            B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), indices.data_ptr(),
+            cmask.data_ptr(), _lib.ptr(gate_out), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+            "dvq_vq_assign_routed_dual_f32")
+    return res
+
+
+def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, beta=0.25, want_zq=True,
+                            want_loss=True, mode=_lib.MODE_FILTER, out=None):
+    """Routing tail of TripleGrainEncoder (EncoderTriple.py:148-176) + VectorQuantize2.forward as ONE op on the
+    unique tokens (`dvq_vq_assign_routed_triple_f32`): h_coarse [B, D, hc, wc], h_median [B, D, 2hc, 2wc],
+    h_fine [B, D, 4hc, 4wc], gate [B, hc, wc, 3].  -> dict as vq_assign_routed_dual.
+    `out` = (zq, codes, loss, indices, codebook_mask)."""
+    h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
+    h_median = _lib.require_cuda_f32(h_median, "h_median")
+    h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
+    codebook = _lib.require_cuda_f32(codebook, "codebook")
+    B, D, hc, wc = h_coarse.shape
+    K = codebook.shape[0]
+    if (tuple(h_median.shape) != (B, D, 2 * hc, 2 * wc) or tuple(h_fine.shape) != (B, D, 4 * hc, 4 * wc)
+            or codebook.shape[1] != D):
+        raise ValueError("shape mismatch: h_coarse %s h_median %s h_fine %s codebook %s" %
+                         (tuple(h_coarse.shape), tuple(h_median.shape), tuple(h_fine.shape), tuple(codebook.shape)))
+    g, kind = _gate_for_routed(gate, 3)
+    if tuple(g.shape[:3]) != (B, hc, wc):
+        raise ValueError("gate %s does not match h_coarse %s" % (tuple(gate.shape), tuple(h_coarse.shape)))
+    if out is not None:
+        zq, codes, loss, indices, cmask = out
+    else:
+        zq, codes, loss, indices, cmask, _ = _routed_outputs(h_fine, B, hc, wc, 4, want_zq, want_loss, False)
+    res = {"zq": zq, "codes": codes, "loss": loss, "indices": indices, "codebook_mask": cmask, "gate": gate}
+    if B * hc * wc == 0:
+        if loss is not None:
+            loss.fill_(float("nan"))
+        return res
+    nbytes = _lib_handle.dvq_vq_assign_routed_workspace_bytes(3, B, D, hc, wc, K, mode)
+    if nbytes == 0:
+        raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
+    ws = prep.workspace(B, D, ("routed3", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    with torch.cuda.device(h_fine.device):
+        pbuf = prep.get(codebook)
+        _lib.check(_lib_handle.dvq_vq_assign_routed_triple_f32(
+            g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(),
+            pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss),
+            indices.data_ptr(), cmask.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+            "dvq_vq_assign_routed_triple_f32")
+    return res
+
+
 def embed_gather(codebook, idx):
     """codebook[idx] (nn.Embedding forward) through dvq_embed_gather_f32."""
     codebook = _lib.require_cuda_f32(codebook, "codebook")
@@ -129,36 +265,44 @@ class _VQStraightThrough(torch.autograd.Function):
     """Forward = the fused kernel.  Backward = what autograd derives from the reference graph
     (quantize2_mask.py:172-182 / quantize_vqgan.py:290-298): identity through z + (z_q - z).detach(),
     plus the commitment-loss gradients 2 c (z - e) m / numel on z (c = coefficient of the
-    (z_q.detach() - z)^2 term) and 2 c' (e - z) m / numel scattered onto the codebook rows."""
+    (z_q.detach() - z)^2 term) and 2 c' (e - z) m / numel scattered onto the codebook rows.
+
+    The codebook is NOT saved for backward: like the reference (F.embedding on the codebook keeps
+    only the indices) the rows e chosen at forward time are what the gradient uses, so the EMA update
+    may overwrite the weight in place between forward and backward."""
 
     @staticmethod
     def forward(ctx, z, weight, mask, prep, K, coef_z, coef_e, mode):
         codebook = weight[:K]
         # beta*mean + mean is the same fp32 number whichever addend carries beta (legacy or not)
         zq, codes, loss = vq_assign(z, codebook, prep, mask, beta=(coef_z if coef_e == 1.0 else coef_e), mode=mode)
-        ctx.save_for_backward(z, weight, mask, codes)
-        ctx.K, ctx.coef_z, ctx.coef_e = K, coef_z, coef_e
+        need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_z or need_w:
+            e = embed_gather(codebook, codes.reshape(z.shape[0], -1))          # [B, HW, D], forward-time rows
+            ctx.save_for_backward(z, e, mask, codes)
+        ctx.wshape, ctx.coef_z, ctx.coef_e = tuple(weight.shape), coef_z, coef_e
         ctx.mark_non_differentiable(codes)
         return zq, loss[1], codes
 
     @staticmethod
     def backward(ctx, g_zq, g_loss, _g_codes):
-        z, weight, mask, codes = ctx.saved_tensors
+        z, e, mask, codes = ctx.saved_tensors
         B, D = z.shape[0], z.shape[1]
-        e = F.embedding(codes.reshape(B, -1), weight[:ctx.K]).permute(0, 2, 1).reshape(z.shape)
-        diff = z - e
+        diff = z - e.permute(0, 2, 1).reshape(z.shape)
         if mask is not None:
             diff = diff * mask.reshape(B, 1, *z.shape[2:])
         scale = 2.0 / z.numel()
-        gz = g_zq
+        gz = g_zq if ctx.needs_input_grad[0] else None
         gw = None
         if g_loss is not None:
             if ctx.needs_input_grad[0]:
                 gz = (g_zq if g_zq is not None else 0) + g_loss * (ctx.coef_z * scale) * diff
             if ctx.needs_input_grad[1]:
-                gw = torch.zeros_like(weight)
+                gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
                 ge = (-(g_loss * (ctx.coef_e * scale)) * diff).reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D)
                 gw.index_add_(0, codes.reshape(-1), ge)
+        elif ctx.needs_input_grad[1]:
+            gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
         return gz, gw, None, None, None, None, None, None
 
 
@@ -184,17 +328,30 @@ class VQEmbedding(nn.Embedding):
         """the K live codebook rows (weight[:-1], quantize2_mask.py:31)"""
         return self.weight[:-1, :]
 
+    def invalidate_codebook_cache(self):
+        """call after writing the codebook through `.data` (which does not bump the version counter)"""
+        self._prep.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._prep.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._prep.invalidate()
+        return out
+
     @torch.no_grad()
     def compute_distances(self, inputs):
-        """Dense [.., K] distances (quantize2_mask.py:29-48).  Only get_soft_codes needs the full
-        matrix; it is evaluated with torch ops (hipBLASLt), tolerance-level, not by the kernel."""
-        codebook_t = self.weight[:-1, :].t()
-        embed_dim = codebook_t.shape[0]
-        assert inputs.shape[-1] == embed_dim
-        flat = inputs.reshape(-1, embed_dim)
-        d = torch.addmm(flat.pow(2.).sum(dim=1, keepdim=True) + codebook_t.pow(2.).sum(dim=0, keepdim=True),
-                        flat, codebook_t, alpha=-2.0)
-        return d.reshape(*inputs.shape[:-1], -1)
+        """Dense squared distances [..., K] of channel-last inputs [..., D] to the K live rows
+        (quantize2_mask.py:29-48).  Only get_soft_codes needs the full matrix; it is a vendor GEMM
+        (torch / hipBLASLt) at tolerance level -- the assignment itself never builds it."""
+        rows = self.weight[:-1, :]
+        if inputs.shape[-1] != rows.shape[1]:
+            raise ValueError("last dim %d != codebook dim %d" % (inputs.shape[-1], rows.shape[1]))
+        x = inputs.reshape(-1, rows.shape[1])
+        norms = (x * x).sum(1, keepdim=True) + (rows * rows).sum(1).unsqueeze(0)
+        return torch.addmm(norms, x, rows.t(), alpha=-2.0).reshape(*inputs.shape[:-1], rows.shape[0])
 
     @torch.no_grad()
     def find_nearest_embedding(self, inputs):
@@ -205,11 +362,11 @@ class VQEmbedding(nn.Embedding):
 
     @torch.no_grad()
     def _tile_with_noise(self, x, target_n):
-        B, embed_dim = x.shape
-        n_repeats = (target_n + B - 1) // B
-        std = x.new_ones(embed_dim) * 0.01 / math.sqrt(embed_dim)
-        x = x.repeat(n_repeats, 1)
-        return x + torch.rand_like(x) * std
+        """at least target_n rows: x repeated, plus uniform noise of scale 0.01/sqrt(D) per element
+        (quantize2_mask.py:57-64)"""
+        n, dim = x.shape
+        tiled = x.repeat(-(-target_n // n), 1)
+        return tiled + torch.rand_like(tiled) * (0.01 / math.sqrt(dim))
 
     @torch.no_grad()
     def _cluster_sums(self, vectors, idxs, nchw=None):
@@ -251,16 +408,28 @@ class VQEmbedding(nn.Embedding):
         self.cluster_size_ema.mul_(self.decay).add_(cluster_size, alpha=1 - self.decay)
         self.embed_ema.mul_(self.decay).add_(vectors_sum_per_cluster, alpha=1 - self.decay)
         if self.restart_unused_codes:
-            if n_vectors < n_embed:
-                vectors = self._tile_with_noise(vectors, n_embed)
-            n_vectors = vectors.shape[0]
-            _vectors_random = vectors[torch.randperm(n_vectors, device=vectors.device)][:n_embed]
-            if dist.is_available() and dist.is_initialized():
-                dist.broadcast(_vectors_random, 0)
-            usage = (self.cluster_size_ema.view(-1, 1) >= 1).float()
-            self.embed_ema.mul_(usage).add_(_vectors_random * (1 - usage))
-            self.cluster_size_ema.mul_(usage.view(-1))
-            self.cluster_size_ema.add_(torch.ones_like(self.cluster_size_ema) * (1 - usage).view(-1))
+            self._restart_dead_codes(vectors, self._draw_restart_vectors(vectors))
+
+    @torch.no_grad()
+    def _draw_restart_vectors(self, vectors):
+        """n_embed input vectors in random order (tiled with noise if the batch has fewer), the same on
+        every rank (quantize2_mask.py:93-100)"""
+        n_embed = self.weight.shape[0] - 1
+        if vectors.shape[0] < n_embed:
+            vectors = self._tile_with_noise(vectors, n_embed)
+        pick = torch.randperm(vectors.shape[0], device=vectors.device)[:n_embed]
+        chosen = vectors[pick]
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast(chosen, 0)
+        return chosen
+
+    @torch.no_grad()
+    def _restart_dead_codes(self, vectors, restart_vectors):
+        """codes whose EMA count fell below 1 restart from `restart_vectors` with count 1
+        (quantize2_mask.py:102-105)"""
+        dead = self.cluster_size_ema < 1
+        self.embed_ema.copy_(torch.where(dead.unsqueeze(1), restart_vectors.to(self.embed_ema.dtype), self.embed_ema))
+        self.cluster_size_ema.masked_fill_(dead, 1.0)
 
     @torch.no_grad()
     def _update_embedding(self):
@@ -268,6 +437,7 @@ class VQEmbedding(nn.Embedding):
         n = self.cluster_size_ema.sum()
         normalized_cluster_size = n * (self.cluster_size_ema + self.eps) / (n + n_embed * self.eps)
         self.weight[:-1, :] = self.embed_ema / normalized_cluster_size.reshape(-1, 1)
+        self._prep.invalidate()
 
     def forward(self, inputs):
         """inputs [..., D] -> (embeds [..., D], idxs [...]) (quantize2_mask.py:117-128)."""
@@ -316,6 +486,8 @@ class VectorQuantize2(nn.Module):
             mask = codebook_mask
             if mask.dtype != torch.float32:
                 mask = mask.float()
+        if self.training:
+            self.codebook._prep.invalidate()             # training: optimizers / EMA may write through .data
         zq, loss, codes = _VQStraightThrough.apply(z, self.codebook.weight, mask, self.codebook._prep, K,
                                                    float(self.beta), 1.0, self.assign_mode)
         if self.training and self.codebook.ema:
@@ -338,18 +510,21 @@ class VectorQuantize2(nn.Module):
 
     @torch.no_grad()
     def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        distances = self.codebook.compute_distances(x)
-        soft_code = F.softmax(-distances / temp, dim=-1)
+        """x [..., D] channel-last -> (softmax(-d / temp) over the K codes [..., K], hard code [...]):
+        a multinomial draw per token when `stochastic`, else the nearest code (quantize2_mask.py:193-205)."""
+        d = self.codebook.compute_distances(x)
+        soft = torch.softmax(d / (-temp), dim=-1)
         if stochastic:
-            soft_code_flat = soft_code.reshape(-1, soft_code.shape[-1])
-            code = torch.multinomial(soft_code_flat, 1)
-            code = code.reshape(*soft_code.shape[:-1])
+            code = torch.multinomial(soft.reshape(-1, soft.shape[-1]), 1).reshape(soft.shape[:-1])
         else:
-            code = distances.argmin(dim=-1)
-        return soft_code, code
+            code = torch.argmin(d, dim=-1)
+        return soft, code
 
     def get_codebook_entry(self, indices, *kwargs):
         return self.codebook.embed(indices)
+
+    def invalidate_codebook_cache(self):
+        self.codebook.invalidate_codebook_cache()
 
 
 class VectorQuantizer2(nn.Module):
@@ -380,29 +555,46 @@ class VectorQuantizer2(nn.Module):
         self._prep = _CodebookPrep()
         self.assign_mode = _lib.MODE_FILTER
 
+    def invalidate_codebook_cache(self):
+        """call after writing embedding.weight through `.data` in eval mode"""
+        self._prep.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._prep.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._prep.invalidate()
+        return out
+
     def remap_to_used(self, inds):
-        ishape = inds.shape
-        assert len(ishape) > 1
-        inds = inds.reshape(ishape[0], -1)
-        used = self.used.to(inds)
-        match = (inds[:, :, None] == used[None, None, ...]).long()
-        new = match.argmax(-1)
-        unknown = match.sum(2) < 1
+        """full-codebook indices [B, ...] -> positions in the `used` list (first occurrence); indices that
+        are not in the list become `unknown_index` (an int, or the extra slot) or a random used slot
+        (quantize_vqgan.py:247-259)"""
+        if inds.dim() < 2:
+            raise ValueError("remap_to_used expects [B, ...] indices")
+        used = self.used.to(inds.device).long()
+        slot = torch.arange(used.numel(), device=inds.device)
+        first = torch.full((self.n_e,), used.numel(), dtype=torch.long, device=inds.device)
+        first.scatter_reduce_(0, used, slot, reduce="amin")              # lookup table code -> first slot
+        new = first[inds.long()]
+        unknown = new == used.numel()
         if self.unknown_index == "random":
-            new[unknown] = torch.randint(0, self.re_embed, size=new[unknown].shape).to(device=new.device)
+            new = torch.where(unknown, torch.randint(0, self.re_embed, new.shape, device=new.device), new)
         else:
-            new[unknown] = self.unknown_index
-        return new.reshape(ishape)
+            new = new.masked_fill(unknown, int(self.unknown_index))
+        return new
 
     def unmap_to_all(self, inds):
-        ishape = inds.shape
-        assert len(ishape) > 1
-        inds = inds.reshape(ishape[0], -1)
-        used = self.used.to(inds)
-        if self.re_embed > self.used.shape[0]:
-            inds[inds >= self.used.shape[0]] = 0
-        back = torch.gather(used[None, :][inds.shape[0] * [0], :], 1, inds)
-        return back.reshape(ishape)
+        """inverse of remap_to_used; the extra (unknown) slot maps to used[0] (quantize_vqgan.py:261-268)"""
+        if inds.dim() < 2:
+            raise ValueError("unmap_to_all expects [B, ...] indices")
+        used = self.used.to(inds.device).long()
+        inds = inds.long()
+        if self.re_embed > used.numel():
+            inds = inds.masked_fill(inds >= used.numel(), 0)
+        return used[inds]
 
     def forward(self, z, temp=None, rescale_logits=False, return_logits=False):
         assert temp is None or temp == 1.0, "Only for interface compatible with Gumbel"
@@ -412,6 +604,8 @@ class VectorQuantizer2(nn.Module):
             raise ValueError("VectorQuantizer2 expects z [B, C, H, W]")
         # legacy=False: beta*mean((zq.detach()-z)^2) + mean((zq-z.detach())^2); legacy=True swaps beta
         coef_z, coef_e = (1.0, float(self.beta)) if self.legacy else (float(self.beta), 1.0)
+        if self.training:
+            self._prep.invalidate()                      # the optimizer may have stepped through .data
         z_q, loss, codes = _VQStraightThrough.apply(z, self.embedding.weight, None, self._prep, self.n_e,
                                                     coef_z, coef_e, self.assign_mode)
         min_encoding_indices = codes.reshape(-1)

@@ -48,7 +48,7 @@ def _gate_arg(gate, G):
     return gate.contiguous(), _lib.GATE_F32
 
 
-def route_select_dual(gate, h_coarse, h_fine, out=None):
+def _route_select_dual_raw(gate, h_coarse, h_fine, out=None):
     """gate [B, hc, wc, 2] (router output, f32 logits or int64), h_coarse [B, C, hc, wc],
     h_fine [B, C, 2hc, 2wc] -> dict(h_dual, indices, codebook_mask, gate) exactly as
     DualGrainEncoder.forward returns it in eval mode (EncoderDual.py:151-156):
@@ -77,7 +77,7 @@ def route_select_dual(gate, h_coarse, h_fine, out=None):
     return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
 
 
-def route_select_dual_entropy(entropy, threshold, h_coarse, h_fine, out=None):
+def _route_select_dual_entropy_raw(entropy, threshold, h_coarse, h_fine, out=None):
     """DualGrainFixedEntropyRouter.forward + the routing tail of DualGrainEncoder.forward in ONE kernel
     (RouterDual.py:53-57 + EncoderDual.py:134-156): entropy [B, hc, wc] f32 -> the same dict as
     route_select_dual, "gate" being the router's int64 gate permuted to [B, 2, hc, wc].
@@ -105,7 +105,7 @@ def route_select_dual_entropy(entropy, threshold, h_coarse, h_fine, out=None):
     return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
 
 
-def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
+def _route_select_triple_raw(gate, h_coarse, h_median, h_fine, out=None):
     """gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
     -> dict(h_triple, indices, codebook_mask, gate) as TripleGrainEncoder.forward (EncoderTriple.py:178-183);
     mask values 0.0625 / 0.25 / 1.0."""
@@ -132,6 +132,81 @@ def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
             h_triple.data_ptr(), indices.data_ptr(), cmask.data_ptr(), _lib.stream_ptr(h_fine.device)),
             "dvq_route_select_triple_f32")
     return {"h_triple": h_triple, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
+
+
+
+class _RouteSelectGrad(torch.autograd.Function):
+    """The select kernels under autograd.  The reference's `torch.where(indices_repeat == g, h_g_upsampled, ...)`
+    (EncoderDual.py:137-140, EncoderTriple.py:151-159) is differentiable in every branch: the gradient of a
+    fine cell goes to h_fine, that of a coarse / median cell is the SUM over the cell's 2x2 / 4x4 output
+    positions (backward of repeat_interleave).  Forward = the HIP kernel; backward = three torch ops
+    (training only)."""
+
+    @staticmethod
+    def forward(ctx, run, h_coarse, h_median, h_fine):
+        sel = run()
+        h_out = sel["h_triple"] if h_median is not None else sel["h_dual"]
+        ctx.save_for_backward(sel["indices"])
+        ctx.triple = h_median is not None
+        ctx.mark_non_differentiable(sel["indices"], sel["codebook_mask"])
+        ctx.gate = sel["gate"]
+        return h_out, sel["indices"], sel["codebook_mask"]
+
+    @staticmethod
+    def backward(ctx, g, _gi, _gm):
+        (ind,) = ctx.saved_tensors
+        fine_id, s = (2, 4) if ctx.triple else (1, 2)
+        up = ind.repeat_interleave(s, 1).repeat_interleave(s, 2).unsqueeze(1)        # [B, 1, H, W]
+        zero = g.new_zeros(())
+        pool = torch.nn.functional.avg_pool2d
+        g_fine = torch.where(up == fine_id, g, zero) if ctx.needs_input_grad[3] else None
+        g_coarse = pool(torch.where(up == 0, g, zero), s) * float(s * s) if ctx.needs_input_grad[1] else None
+        g_median = None
+        if ctx.triple and ctx.needs_input_grad[2]:
+            g_median = pool(torch.where(up == 1, g, zero), 2) * 4.0
+        return None, g_coarse, g_median, g_fine
+
+
+def _select(run, key, h_coarse, h_median, h_fine):
+    feats = [t for t in (h_coarse, h_median, h_fine) if t is not None]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in feats):
+        h_out, indices, cmask = _RouteSelectGrad.apply(run, h_coarse, h_median, h_fine)
+        sel = run.last
+        return {key: h_out, "indices": indices, "codebook_mask": cmask, "gate": sel["gate"]}
+    return run()
+
+
+class _Run:
+    """callable that keeps the dict of its last call (the autograd wrapper returns tensors only)"""
+
+    def __init__(self, fn):
+        self.fn, self.last = fn, None
+
+    def __call__(self):
+        self.last = self.fn()
+        return self.last
+
+
+def route_select_dual(gate, h_coarse, h_fine, out=None):
+    """DualGrainEncoder.forward's eval-mode routing tail (EncoderDual.py:134-156), differentiable in
+    h_coarse / h_fine like the reference's torch.where; see _route_select_dual_raw for shapes."""
+    return _select(_Run(lambda: _route_select_dual_raw(gate, h_coarse.detach(), h_fine.detach(), out)),
+                   "h_dual", h_coarse, None, h_fine)
+
+
+def route_select_dual_entropy(entropy, threshold, h_coarse, h_fine, out=None):
+    """fixed-entropy router + routing tail in one kernel, differentiable in h_coarse / h_fine."""
+    return _select(_Run(lambda: _route_select_dual_entropy_raw(entropy, threshold, h_coarse.detach(),
+                                                               h_fine.detach(), out)),
+                   "h_dual", h_coarse, None, h_fine)
+
+
+def route_select_triple(gate, h_coarse, h_median, h_fine, out=None):
+    """TripleGrainEncoder.forward's eval-mode routing tail (EncoderTriple.py:148-183), differentiable in
+    the three branches."""
+    return _select(_Run(lambda: _route_select_triple_raw(gate, h_coarse.detach(), h_median.detach(),
+                                                         h_fine.detach(), out)),
+                   "h_triple", h_coarse, h_median, h_fine)
 
 
 class DualGrainFixedEntropyRouter(nn.Module):

@@ -38,17 +38,18 @@ extern "C" {
 #define DVQ_MODE_FILTER  1  /* fp16-MFMA filter with a rigorous error bound; every token that  */
                             /* is not provably decided is re-evaluated by the exact chain.     */
                             /* Output is identical to DVQ_MODE_EXACT.                          */
+#define DVQ_MODE_FILTER_PASS1 2  /* profiling aid: ONLY the pass-1 (fp16 filter) kernel of DVQ_MODE_FILTER, */
+                                 /* the dominant kernel; queued tokens keep their provisional code, the     */
+                                 /* loss is not finalised.  Not a production mode.                          */
+#define DVQ_MODE_FILTER_WIDE 3   /* testing aid: DVQ_MODE_FILTER with the two-blocks-per-wave pass-1 kernel */
+                                 /* forced (D = 256); normally chosen automatically for K >= 2048 and       */
+                                 /* >= 131072 tokens.  Same output.                                         */
 
-#define DVQ_MODE_FILTER_PASS1 2  /* profiling aid: ONLY the fp16 filter kernel of DVQ_MODE_FILTER (the      */
-#define DVQ_MODE_FILTER_WIDE 3   /* testing aid: DVQ_MODE_FILTER with the two-blocks-per-wave pass-1 kernel     */
-                                 /* forced (D = 256); normally chosen automatically for K >= 2048 and           */
-                                 /* >= 131072 tokens.  Same output.                                              */
-                                /* dominant kernel); queued tokens keep their provisional code, the loss   */
-                                /* is not finalised.  Not a production mode.                               */
-
-/* gate dtypes for the router select */
-#define DVQ_GATE_F32 0
-#define DVQ_GATE_I64 1
+/* gate kinds for the router select / routed assign */
+#define DVQ_GATE_F32 0      /* float32 gate logits [.., G]                                      */
+#define DVQ_GATE_I64 1      /* int64 gate [.., G] (what DualGrainFixedEntropyRouter returns)    */
+#define DVQ_GATE_ENTROPY 2  /* routed assign only: float32 entropy map [B, hc, wc] + threshold  */
+                            /* (the fixed-entropy router fused in)                              */
 
 int dvq_version(void);
 const char *dvq_last_error_string(void);
@@ -114,11 +115,6 @@ int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
                               int B, int C, int hc, int wc,
                               float *h_out, int64_t *indices, float *cmask, void *stream);
 
-/*
- * Routing tail of TripleGrainEncoder.forward in eval mode (EncoderTriple.py:148-176).
- *   gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
- *   cmask values 0.0625 / 0.25 / 1.0
- */
 /* The fixed-entropy router (RouterDual.py:46-57) fused into the dual select: entropy [B, hc, wc] f32,
  * gate = [(entropy <= threshold), (entropy > threshold)]; outputs as dvq_route_select_dual_f32 plus,
  * if gate_out != NULL, the router's int64 gate [B, hc, wc, 2] (DualGrainEncoder returns it). */
@@ -126,10 +122,59 @@ int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, con
                                       const float *h_fine, int B, int C, int hc, int wc,
                                       float *h_out, int64_t *indices, float *cmask, int64_t *gate_out,
                                       void *stream);
+
+/*
+ * Routing tail of TripleGrainEncoder.forward in eval mode (EncoderTriple.py:148-176).
+ *   gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
+ *   cmask values 0.0625 / 0.25 / 1.0
+ */
 int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 const float *h_coarse, const float *h_median,
                                 const float *h_fine, int B, int C, int hc, int wc,
                                 float *h_out, int64_t *indices, float *cmask, void *stream);
+
+/*
+ * Routed assignment: routing tail + VectorQuantize2.forward as ONE op straight from the encoder
+ * branches -- replaces dvq_route_select_{dual,triple}_f32 followed by dvq_vq_assign_nchw_f32
+ * (EncoderDual.py:134-149 / EncoderTriple.py:148-176 + quantize2_mask.py:157-191) when nothing sits
+ * between select and quantizer.  The 2x2 / 4x4 output positions of a coarse (median) cell are copies of
+ * one source vector, so each UNIQUE token is scored once and its code / z_q written to every position it
+ * covers; h_dual / h_triple is never materialised.  Same per-token arithmetic as the dense op: codes,
+ * z_q, indices, cmask identical bit for bit to select + assign, loss within 1e-5.
+ *   gate      DVQ_GATE_F32 / DVQ_GATE_I64: [B, hc, wc, G]; DVQ_GATE_ENTROPY (dual only): entropy [B, hc, wc]
+ *             with `threshold` (gate = [(e <= thr), (e > thr)], written to gate_out [B, hc, wc, 2] if non-NULL)
+ *   h_coarse  [B, D, hc, wc]; h_median [B, D, 2hc, 2wc] (triple); h_fine [B, D, S hc, S wc], S = 2 (dual) / 4 (triple)
+ *   zq        nullable [B, D, S hc, S wc]; codes [B, S hc, S wc] int64; loss nullable [2] as dvq_vq_assign_nchw_f32
+ *   indices   [B, hc, wc] int64 grain index per coarse cell; cmask [B, 1, S hc, S wc] (0.0625 / 0.25 / 1.0)
+ *   ws        >= dvq_vq_assign_routed_workspace_bytes(num_branches, ...), 256-byte aligned
+ *   mode      DVQ_MODE_EXACT / DVQ_MODE_FILTER (/ DVQ_MODE_FILTER_PASS1)
+ * hc * wc <= 1024 coarse cells per image, B <= 32768.
+ */
+size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int hc, int wc, int K, int mode);
+int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,
+                                  const float *h_coarse, const float *h_fine,
+                                  const float *codebook, const void *prep,
+                                  int B, int D, int hc, int wc, int K, float beta,
+                                  float *zq, int64_t *codes, float *loss,
+                                  int64_t *indices, float *cmask, int64_t *gate_out,
+                                  void *ws, size_t ws_bytes, int mode, void *stream);
+int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
+                                    const float *h_coarse, const float *h_median, const float *h_fine,
+                                    const float *codebook, const void *prep,
+                                    int B, int D, int hc, int wc, int K, float beta,
+                                    float *zq, int64_t *codes, float *loss,
+                                    int64_t *indices, float *cmask,
+                                    void *ws, size_t ws_bytes, int mode, void *stream);
+/* Tuning / testing aid: which pass-1 kernel DVQ_MODE_FILTER launches (process-wide; results are identical
+ * for every choice).  dense_variant: -1 = the 2-waves-per-SIMD kernel that keeps an fp32 copy of z in
+ * registers (wide form for K >= 2048), 0..3 = the low-register forms (0: 4-wave workgroups, 2-slot codebook
+ * ring, 4 per CU; 1: 4 waves, 3 slots, 3 per CU; 2: 8 waves, 4 slots, 2 per CU; 3: 8 waves, 3 slots, 2 per
+ * CU); routed_variant: 0..3 (the routed op always takes a low-register form); -2 keeps the current choice.
+ * Defaults: environment DVQ_PASS1_VARIANT / DVQ_ROUTED_VARIANT, else the built-in choice. */
+int dvq_set_pass1_variant(int dense_variant, int routed_variant);
+
+/* as dvq_vq_assign_fallback_count_offset, for a routed workspace */
+size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K);
 
 /*
  * Training-mode codebook statistics, the dense part of VQEmbedding._update_buffers
@@ -203,6 +248,27 @@ int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *
                                   int B, int Lc, int Lf, int hc, int wc,
                                   int64_t coarse_position_eos, int64_t fine_position_eos,
                                   int64_t *target, void *stream);
+
+/*
+ * Wire format of the image-parallel exchange (one all-gather per batch; the reference gathers nothing --
+ * it runs one process per GPU under Lightning DDP, train.py:230 -- this is what lets downstream consumers
+ * (permuter, stage-2 transformer) see the global code tensor).  Per rank one byte buffer of
+ * dvq_exchange_bytes(): [codes as int16 (num_codes <= 32768) / int32, b_max images][grain indices as int8]
+ * [(loss numerator, element count) as 2 x float64].
+ *   pack    codes [b_local, codes_per_image] int64, grain [b_local, grain_per_image] int64 (nullable when
+ *           grain_per_image == 0), loss nullable ([0] = local mean; numel = local element count);
+ *           rows b_local .. b_max-1 are zero padding (ragged shards)
+ *   unpack  gathered [world, bytes] -> codes [global_batch, codes_per_image] int64, grain, mean[0] = global
+ *           mean (pairs added in rank order: same bits on every rank); shard r holds the images
+ *           [r*base + min(r, extra), ...) of global_batch = world*base + extra, b_max = ceil(global_batch / world)
+ */
+size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes);
+int dvq_exchange_pack(const int64_t *codes, const int64_t *grain, const float *loss, double numel, int b_local,
+                      int b_max, int64_t codes_per_image, int64_t grain_per_image, int num_codes, void *buf,
+                      void *stream);
+int dvq_exchange_unpack(const void *gathered, int world, int global_batch, int64_t codes_per_image,
+                        int64_t grain_per_image, int num_codes, int64_t *codes, int64_t *grain, float *mean,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,19 @@ def test_vq2_oracle_matches_reference(oracle_mod, name):
     assert C.loss_close(loss, g["loss"])
 
 
+def test_vq2_oracle_matches_reference_k16384_dispatch_size(oracle_mod):
+    """the K = 16384, B = 128 fixture (the size that dispatches to the wide pass-1 kernel on the GPU): a sample of
+    8 whole images keeps the CPU suite short"""
+    g = C.load("vq2_K16384_B128_crc")
+    z, E, mask = C.vq2_inputs(g)
+    sel = np.arange(0, int(g["B"]), 16)
+    o = oracle_mod.vq_assign_nchw(z[sel], E, mask[sel])
+    codes = o["codes"].reshape(len(sel), 32, 32)
+    assert np.array_equal(codes[0], g["codes_image0"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(codes), g["codes_crc"][sel])
+    assert np.array_equal(C.per_image_crc(o["zq"]), g["zq_crc"][sel])
+
+
 @pytest.mark.parametrize("name", C.VQGAN)
 def test_vqgan_oracle_matches_reference(oracle_mod, name):
     g = C.load(name)

@@ -1,0 +1,343 @@
+"""GPU (-m gpu): the routed assign (dvq_vq_assign_routed_{dual,triple}_f32 -- routing tail + VectorQuantize2
+as one op on the unique tokens) against the CPU oracle's select + assign on the same seeded inputs, and
+the parity holes VERDICT r1 named at DISPATCH size: the exact bench step at B = 256 on all images, the
+triple encode at the per-rank size B = 128, K = 16384 through the wide pass-1 kernel + sliced resolver.
+Bar: codes, grain indices, codebook_mask, gate and z_q bit-exact; loss 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from tests import _cases as C
+
+pytestmark = pytest.mark.gpu
+
+THR = 1.6777750253677368
+
+
+def _t(dev):
+    return lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _check_dual(r, o_sel, o, B, beta=0.25, oracle_mod=None):
+    assert np.array_equal(r["indices"].cpu().numpy(), o_sel["indices"]), "grain indices"
+    assert np.array_equal(r["codebook_mask"].cpu().numpy(), o_sel["codebook_mask"]), "codebook_mask"
+    assert np.array_equal(r["codes"].cpu().numpy().reshape(B, -1), o["codes"]), "codes"
+    if r["zq"] is not None:
+        assert np.array_equal(r["zq"].cpu().numpy(), o["zq"], equal_nan=True), "z_q"
+    if r["loss"] is not None:
+        assert C.loss_close(float(r["loss"][1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], beta)), "loss"
+
+
+@pytest.fixture(params=[0, 1, 2, 3])
+def variant(request):
+    from dynamicvectorquantization_amd import _lib
+    assert _lib.lib.dvq_set_pass1_variant(-2, request.param) == 0
+    yield request.param
+    _lib.lib.dvq_set_pass1_variant(-2, 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 4, 6), (9, 16, 16), (17, 5, 8), (2, 32, 32)])
+def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode, variant):
+    """ragged batches (not a multiple of the 8-image group), grids from 1x2 to 32x32 cells, every pass-1 variant;
+    int64 gate, f32 logits (ties / NaN) and the fused entropy router"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
+    if mode == 0 and variant != 0:
+        pytest.skip("the exact mode does not use pass 1")
+    B, hc, wc = shape
+    K, D = 333, 256
+    E = synth.codebook_trained(K, D, seed=500 + hc)
+    hf, hco = synth.z_tokens(E, B, 2 * hc, 2 * wc, 510 + hc), synth.z_tokens(E, B, hc, wc, 520 + hc)
+    t = _t(dev)
+    prep = _CodebookPrep()
+    gate = synth.grain_gate_dual(530 + hc, B, hc, wc)
+    gate[0] = np.array([1, 0])                                    # image 0 all coarse
+    if B > 1:
+        gate[1] = np.array([0, 1])                                # image 1 all fine
+    logits = synth.normal(540 + hc, (B, hc, wc, 2))
+    logits[0, 0, 0] = 0.5                                         # tie -> first index (coarse)
+    logits[-1, -1, -1, 1] = np.nan                                # NaN counts as the maximum
+    ent = synth.entropy_map(550 + hc, B, hc, wc)
+    ent[0, 0, 0] = np.float32(THR)
+    ent[-1, -1, -1] = np.nan
+    for kind, g in (("gate", gate), ("gate", logits), ("entropy", ent)):
+        if kind == "entropy":
+            r = vq_assign_routed_dual(t(hco), t(hf), t(E), prep, entropy=t(g), threshold=THR, mode=mode)
+            og = oracle_mod.entropy_gate(g, THR)
+            assert np.array_equal(r["gate"].cpu().numpy(), og)
+        else:
+            r = vq_assign_routed_dual(t(hco), t(hf), t(E), prep, gate=t(g), mode=mode)
+            og = g
+        o_sel = oracle_mod.route_select_dual(og, hco, hf)
+        o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+        _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
+    # codes-only call
+    r = vq_assign_routed_dual(t(hco), t(hf), t(E), prep, gate=t(gate), mode=mode, want_zq=False, want_loss=False)
+    o_sel = oracle_mod.route_select_dual(gate, hco, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+    _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 2, 3), (10, 8, 8), (2, 16, 16)])
+def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_triple
+    if mode == 0 and variant != 0:
+        pytest.skip("the exact mode does not use pass 1")
+    B, hc, wc = shape
+    K, D = 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hm, hco = (synth.z_tokens(E, B, 4 * hc, 4 * wc, 610 + hc), synth.z_tokens(E, B, 2 * hc, 2 * wc, 620 + hc),
+                   synth.z_tokens(E, B, hc, wc, 630 + hc))
+    lg = synth.grain_logits_triple(640 + hc, B, hc, wc)
+    lg[0, 0, 0] = 0.25                                            # three-way tie -> coarse
+    if B > 1:
+        lg[1] = np.array([0.0, 0.0, 1.0])                         # image 1 all fine
+    gi = np.stack([(lg.argmax(-1) == k) for k in range(3)], -1).astype(np.int64)
+    t = _t(dev)
+    prep = _CodebookPrep()
+    for g in (lg, gi):
+        r = vq_assign_routed_triple(t(hco), t(hm), t(hf), t(E), prep, t(g), mode=mode)
+        o_sel = oracle_mod.route_select_triple(g, hco, hm, hf)
+        o = oracle_mod.vq_assign_nchw(o_sel["h_triple"], E, o_sel["codebook_mask"])
+        _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
+
+
+def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod):
+    """NaN / Inf / huge tokens in every branch go through the exact list (routed ids); a codebook with widely
+    mixed norms overflows the resolver queue; D = 64 / 128"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
+    t = _t(dev)
+    B, hc, wc, K, D = 5, 4, 4, 200, 256
+    E = synth.codebook_trained(K, D, seed=71)
+    E[7] = E[3]                                                    # duplicate code: first index wins
+    hf, hm, hco = (synth.z_tokens(E, B, 16, 16, 72), synth.z_tokens(E, B, 8, 8, 73), synth.z_tokens(E, B, 4, 4, 74))
+    for a in (hf, hm, hco):
+        a[0, 5, 0, 0] = np.nan
+        a[1, :, 1, 1] = np.inf
+        a[2, 9, 2, 2] = -np.inf
+        a[3, :, 3, 3] *= np.float32(1e6)
+        a[4, :, 0, 1] = 0.0
+    lg = synth.grain_logits_triple(75, B, hc, wc)
+    prep = _CodebookPrep()
+    r = vq_assign_routed_triple(t(hco), t(hm), t(hf), t(E), prep, t(lg))
+    o_sel = oracle_mod.route_select_triple(lg, hco, hm, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_triple"], E, o_sel["codebook_mask"])
+    assert np.array_equal(r["codes"].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(r["zq"].cpu().numpy(), o["zq"], equal_nan=True)
+    assert prep.fallback_count()[1] > 0                           # the exact list was used
+    # queue overflow (dual), the routed analogue of test_filter_queue_overflow_falls_back_to_exact
+    rng = np.random.default_rng(3)
+    K2, B2 = 1024, 24
+    E2 = synth.codebook_trained(K2, D, seed=77)
+    E2 = np.ascontiguousarray(E2 * np.exp2(rng.integers(-5, 5, size=(K2, 1))).astype(np.float32))
+    hf2, hc2 = synth.z_tokens(E2, B2, 32, 32, 4243), synth.z_tokens(E2, B2, 16, 16, 4244)
+    g2 = synth.grain_gate_dual(4245, B2, 16, 16)
+    p1, p0 = _CodebookPrep(), _CodebookPrep()
+    r1 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p1, gate=t(g2), mode=_lib.MODE_FILTER)
+    r0 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p0, gate=t(g2), mode=_lib.MODE_EXACT)
+    queued, listed = p1.fallback_count()
+    assert queued >= 4096 and listed > 500, (queued, listed)
+    assert torch.equal(r0["codes"], r1["codes"]) and torch.equal(r0["zq"], r1["zq"])
+    assert abs(float(r0["loss"][1]) - float(r1["loss"][1])) <= 1e-6 * abs(float(r0["loss"][1]))
+    o_sel = oracle_mod.route_select_dual(g2, hc2, hf2)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E2, o_sel["codebook_mask"])
+    assert np.array_equal(r1["codes"].cpu().numpy().reshape(B2, -1), o["codes"])
+    for Dd in (64, 128):
+        E3 = synth.codebook_trained(300, Dd, seed=80 + Dd)
+        hf3, hc3 = synth.z_tokens(E3, 3, 8, 8, 81 + Dd), synth.z_tokens(E3, 3, 4, 4, 82 + Dd)
+        g3 = synth.grain_gate_dual(83 + Dd, 3, 4, 4)
+        r3 = vq_assign_routed_dual(t(hc3), t(hf3), t(E3), _CodebookPrep(), gate=t(g3))
+        o_sel = oracle_mod.route_select_dual(g3, hc3, hf3)
+        o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E3, o_sel["codebook_mask"])
+        _check_dual(r3, o_sel, o, 3, oracle_mod=oracle_mod)
+
+
+def test_bench_step_full_size_all_images(dev, oracle_mod, variant):
+    """BASELINE configs[2] exactly as bench.py runs it (entropy gate + routing + masked
+    assign, B = 256, K = 1024), every one of the 256 images against the oracle, both the routed op and the
+    round-1 select + dense assign path"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
+    from dynamicvectorquantization_amd.router import route_select_dual_entropy
+    B, K, D = 256, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf = synth.z_tokens(E, B, 32, 32, 2903)
+    hco = synth.z_tokens(E, B, 16, 16, 2913)
+    ent = synth.entropy_map(5903, B, 16, 16)
+    t = _t(dev)
+    thf, thc, tent, tE = t(hf), t(hco), t(ent), t(E)
+    og = oracle_mod.entropy_gate(ent, THR)
+    o_sel = oracle_mod.route_select_dual(og, hco, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+    prep = _CodebookPrep()
+    r = vq_assign_routed_dual(thc, thf, tE, prep, entropy=tent, threshold=THR)
+    _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
+    assert np.array_equal(r["gate"].cpu().numpy(), og)
+    queued, listed = prep.fallback_count()
+    assert 0 < queued < 0.2 * B * 1024 and listed == 0, (queued, listed)
+    if variant == 0:
+        sel = route_select_dual_entropy(tent, THR, thc, thf)
+        zq, codes, loss = vq_assign(sel["h_dual"], tE, _CodebookPrep(), sel["codebook_mask"])
+        assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+        assert torch.equal(zq, r["zq"]) and torch.equal(codes, r["codes"])
+        assert C.loss_close(float(loss[1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+
+
+def test_triple_encode_per_rank_size(dev, oracle_mod):
+    """BASELINE configs[3] at the per-rank size (B = 128 of the 8-GPU job's 1024): the
+    triple encode glue (fused feature-router gate -> routed assign) against the oracle given the router's
+    logits, all images"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_triple
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import TripleGrainFeatureRouter
+    B, K, D = 128, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hm, hco = (synth.z_tokens(E, B, 32, 32, 2104), synth.z_tokens(E, B, 16, 16, 2114), synth.z_tokens(E, B, 8, 8, 2124))
+    t = _t(dev)
+    router = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu")
+    sd = {k: torch.from_numpy(synth.seeded_param(6104, i, k, tuple(v.shape)))
+          for i, (k, v) in enumerate(router.state_dict().items())}
+    router.load_state_dict(sd)
+    router = router.to(dev).eval()
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    with torch.no_grad():
+        quant, emb_loss, info, grain, gate = encode_triple(router, vq, t(hf), t(hm), t(hco))
+    lg = gate.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    assert tuple(gate.shape) == (B, 3, 8, 8)
+    o_sel = oracle_mod.route_select_triple(lg, hco, hm, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_triple"], E, o_sel["codebook_mask"])
+    assert np.array_equal(grain.cpu().numpy(), o_sel["indices"])
+    assert np.array_equal(info[2].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(quant.cpu().numpy(), o["zq"])
+    assert C.loss_close(float(emb_loss), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    counts = np.bincount(o_sel["indices"].reshape(-1), minlength=3)
+    assert counts.min() > 0.1 * counts.sum()                      # the router really mixes the three grains
+
+
+@pytest.mark.parametrize("dense_variant", [-1, 2])
+def test_k16384_dispatch_size_vs_oracle_and_golden(dev, oracle_mod, dense_variant):
+    """K = 16384, D = 256, N = 131072 tokens (B = 128, 32x32) through DVQ_MODE_FILTER: the
+    wide (two-blocks-per-wave) pass-1 kernel + 8-slice resolver (dense_variant -1) or a low-register form.
+    All images against the golden CRCs captured from the imported reference; 8 whole images against the oracle"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    g = C.load("vq2_K16384_B128_crc")
+    z, E, mask = C.vq2_inputs(g)
+    B = int(g["B"])
+    assert B * 1024 >= 131072 and int(g["K"]) == 16384
+    assert _lib.lib.dvq_set_pass1_variant(dense_variant, -2) == 0
+    try:
+        prep = _CodebookPrep()
+        t = _t(dev)
+        zq, codes, loss = vq_assign(t(z), t(E), prep, t(mask), mode=_lib.MODE_FILTER)
+        queued, listed = prep.fallback_count()
+    finally:
+        _lib.lib.dvq_set_pass1_variant(-1, -2)
+    assert queued > 0                                             # the sliced resolver had work
+    codes_np, zq_np = codes.cpu().numpy(), zq.cpu().numpy()
+    assert np.array_equal(codes_np[0], g["codes_image0"].astype(np.int64))
+    assert np.array_equal(C.per_image_crc(codes_np), g["codes_crc"])
+    assert np.array_equal(C.per_image_crc(zq_np), g["zq_crc"])
+    assert C.loss_close(float(loss[1]), g["loss"])
+    sel = np.arange(0, B, 16)                                     # 8 whole images
+    o = oracle_mod.vq_assign_nchw(z[sel], E, mask[sel])
+    assert np.array_equal(codes_np[sel].reshape(len(sel), -1), o["codes"]) and np.array_equal(zq_np[sel], o["zq"])
+
+
+@pytest.mark.parametrize("dense_variant", [0, 1, 2, 3])
+def test_low_register_pass1_dense(dev, oracle_mod, dense_variant):
+    """the low-register pass-1 forms on a dense tensor (DVQ_MODE_FILTER, D = 256): golden cfg-2 fixture,
+    ragged token counts, codes-only, vs the oracle"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    t = _t(dev)
+    assert _lib.lib.dvq_set_pass1_variant(dense_variant, -2) == 0
+    try:
+        g = C.load("vq2_cfg2_B4")
+        z, E, mask = C.vq2_inputs(g)
+        zq, codes, loss = vq_assign(t(z), t(E), _CodebookPrep(), t(mask))
+        assert np.array_equal(codes.cpu().numpy(), g["codes"].astype(np.int64))
+        assert np.array_equal(C.per_image_crc(zq.cpu().numpy()), g["zq_crc"]) and C.loss_close(float(loss[1]), g["loss"])
+        for (B, H, W, K) in ((1, 1, 33, 40), (3, 7, 11, 1000), (2, 16, 16, 2048)):
+            E2 = synth.codebook_trained(K, 256, seed=900 + K)
+            z2 = synth.z_tokens(E2, B, H, W, 910 + K)
+            o = oracle_mod.vq_assign_nchw(z2, E2, None)
+            zq2, c2, l2 = vq_assign(t(z2), t(E2), _CodebookPrep(), None)
+            assert np.array_equal(c2.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq2.cpu().numpy(), o["zq"])
+            assert C.loss_close(float(l2[1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+            _, c3, _ = vq_assign(t(z2), t(E2), _CodebookPrep(), None, want_zq=False, want_loss=False)
+            assert torch.equal(c2, c3)
+    finally:
+        _lib.lib.dvq_set_pass1_variant(-1, -2)
+
+
+def test_routed_op_is_graph_capturable(dev):
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
+    B, K, D = 4, 1024, 256
+    En = synth.codebook_trained(K, D)
+    t = _t(dev)
+    E = t(En)
+    mk = lambda seed: (t(synth.z_tokens(En, B, 32, 32, seed)), t(synth.z_tokens(En, B, 16, 16, seed + 1)),
+                       t(synth.entropy_map(seed + 2, B, 16, 16)))
+    hf, hc, ent = mk(9300)
+    prep = _CodebookPrep()
+    out = (torch.empty_like(hf), torch.empty((B, 32, 32), dtype=torch.int64, device=dev), torch.empty(2, device=dev),
+           torch.empty((B, 16, 16), dtype=torch.int64, device=dev), torch.empty((B, 1, 32, 32), device=dev),
+           torch.empty((B, 16, 16, 2), dtype=torch.int64, device=dev))
+    step = lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, out=out)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    hf2, hc2, ent2 = mk(9400)
+    hf.copy_(hf2); hc.copy_(hc2); ent.copy_(ent2)
+    g.replay()
+    torch.cuda.synchronize()
+    got = [x.clone() for x in out]
+    step()
+    torch.cuda.synchronize()
+    for a, b in zip(got, out):
+        assert torch.equal(a, b)
+
+
+def test_encode_dual_uses_routed_op_and_matches_select_path(dev, oracle_mod, golden_dir):
+    """encode glue: eval + no quant_conv -> routed op; a quant_conv (identity here) or autograd -> select + dense
+    assign; identical outputs"""
+    import os
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, DualGrainFixedEntropyRouter
+    B, K, D = 6, 1024, 256
+    E = synth.codebook_trained(K, D)
+    t = _t(dev)
+    hf, hc = t(synth.z_tokens(E, B, 32, 32, 2203)), t(synth.z_tokens(E, B, 16, 16, 2213))
+    ent = t(synth.entropy_map(5203, B, 16, 16))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    r_ent = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    torch.manual_seed(5)
+    r_feat = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
+    for router, e in ((r_ent, ent), (r_feat, None)):
+        with torch.no_grad():
+            a = encode_dual(router, vq, hf, hc, entropy=e)
+            b = encode_dual(router, vq, hf, hc, entropy=e, quant_conv=torch.nn.Identity())
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2][2], b[2][2]) and torch.equal(a[3], b[3])
+        assert torch.equal(a[4], b[4]) and a[4].shape == (B, 2, 16, 16)
+        assert abs(float(a[1]) - float(b[1])) <= 1e-6 * abs(float(b[1]))
+    hf_g = hf.clone().requires_grad_(True)
+    q, loss, _, _, _ = encode_dual(r_ent, vq, hf_g, hc, entropy=ent)          # autograd -> differentiable path
+    (q.sum() + loss).backward()
+    assert hf_g.grad is not None and float(hf_g.grad.abs().sum()) > 0
