@@ -43,6 +43,14 @@ def _worker(rank, world, port, B, q):
         b_codes, b_grain, b_mean = h2.wait()
         assert torch.equal(a_codes, g_codes) and torch.equal(a_grain, g_grain) and float(a_mean) == float(mean)
         assert torch.equal(b_codes, g_codes + 1) and b_grain is None and abs(float(b_mean) - 2 * float(mean)) < 1e-6 * float(mean)
+        # the preallocated-exchange object bench.py uses (CPU tensors: same wire format through torch ops)
+        from dynamicvectorquantization_amd.encode import CodeExchange
+        xch = CodeExchange(codes, grain, K, B, numel_per_image=8 * 8 * D)
+        assert xch.shard_sizes == [shard_slice(B, r, world)[1] - shard_slice(B, r, world)[0] for r in range(world)]
+        xch.start(codes, grain, torch.tensor([o["sqerr"] / o["numel"]], dtype=torch.float32))
+        c_codes, c_grain, c_mean = xch.finish()
+        assert torch.equal(c_codes, g_codes) and torch.equal(c_grain, g_grain)
+        assert abs(float(c_mean) - float(mean)) <= 1e-6 * abs(float(mean))
         q.put((rank, g_codes.numpy(), g_grain.numpy(), float(mean)))
     finally:
         dist.destroy_process_group()
@@ -120,3 +128,26 @@ def test_ema_update_world2_single_collective():
     assert used.sum() == 12 and np.all(cs0[~used] == 1.0)                   # dead codes restarted ...
     rows0 = {tuple(np.round(r, 5)) for r in v0}
     assert all(tuple(np.round(r, 5)) in rows0 for r in ee0[~used])          # ... with rank 0's vectors everywhere
+
+
+@pytest.mark.gpu
+def test_bench_launcher_spawns_ranks_and_exchanges_on_device():
+    """`python bench.py --gpus 2` is a launcher -- it starts 2 rank processes itself (here both
+    on the one visible GPU, gloo rendezvous), the ranks run the routed step + pack kernel + all-gather + unpack
+    kernel, rank 0's JSON line reports n_gpus == 2 with the parity check of every rank's images"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DVQ_BENCH_BACKEND="gloo")
+    env.pop("RANK", None)
+    for extra in (["--batch", "8"], ["--scaling", "strong", "--batch", "12"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                            "--spinup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == ("strong" if "strong" in extra else "weak")
+        assert d["parity_checked"] is True and d["code_mismatches"] == 0 and d["parity"]["exchange_ok"] is True
+        assert d["parity"]["images_checked"] == (12 if "strong" in extra else 16)
