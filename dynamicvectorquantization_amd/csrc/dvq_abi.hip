@@ -67,6 +67,8 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
                            int Hid, int act, float *gate, void *ws, hipStream_t st);
 
 int dvq_choose_pass1_variant(int dense, int routed);
+int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
+                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st);
 size_t dvq_xch_bytes(long cpi, long gpi, int b_max, int num_codes);
 int dvq_launch_xch_pack(const long long *codes, const long long *grain, const float *loss, double numel, int b_local,
                         int b_max, long cpi, long gpi, int num_codes, void *buf, hipStream_t st);
@@ -446,6 +448,16 @@ int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *
                                               (const long long *)coarse_position, (const long long *)fine_position,
                                               B, Lc, Lf, hc, wc, coarse_position_eos, fine_position_eos,
                                               (long long *)target, (hipStream_t)stream), "permute_backward");
+}
+
+int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,
+                                float *threshold, float *xn, float *scale, void *stream)
+{
+    if (!tokens || !prep || !scores || !threshold || !xn) { dvq_set_error("dvq_debug_filter_scores_f32: null pointer"); return DVQ_EINVAL; }
+    if (n <= 0 || K <= 0) { dvq_set_error("dvq_debug_filter_scores_f32: n, K must be positive"); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_debug_filter_scores_f32: D=%d unsupported", D); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_filter_scores_debug(tokens, n, prep, D, K, scores, threshold, xn, scale, (hipStream_t)stream),
+                  "filter_scores_debug");
 }
 
 int dvq_set_pass1_variant(int dense_variant, int routed_variant)

@@ -168,10 +168,15 @@ __global__ __launch_bounds__(256) void permute_backward_kernel(
     }
 }
 
+__global__ void permute_zero_maxes_kernel(int *__restrict__ maxes)
+{
+    if (threadIdx.x < 2) maxes[threadIdx.x] = 0;
+}
+
 int dvq_launch_permute_count(const long long *grain, int B, int ncell, int *counts, int *maxes, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(maxes, 0, 2 * sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
+    // zeroed by a kernel, not hipMemsetAsync: memset nodes misbehave under hipGraph replay on ROCm 7.2
+    hipLaunchKernelGGL(permute_zero_maxes_kernel, dim3(1), dim3(64), 0, st, maxes);
     hipLaunchKernelGGL(permute_count_kernel, dim3(B), dim3(256), 0, st, grain, ncell, counts, maxes);
     return (int)hipGetLastError();
 }

@@ -979,6 +979,108 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// audit aid (dvq_debug_filter_scores_f32, tools/bound_audit.py): pass 1's score arithmetic on a few tokens
+// given as rows [n, D] -- same fp16 conversion, same seeded accumulator, same MFMA chain in the same order,
+// same index packing, same threshold -- with every score written out instead of reduced to a top-2.
+// One wave per 32 tokens; A fragments straight from the prep image.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void filter_scores_debug_kernel(
+    const float *__restrict__ tokens, int n, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    int K, float *__restrict__ G, float *__restrict__ thr2W_out, float *__restrict__ xn_out)
+{
+    constexpr int S16 = D / 16;
+    constexpr int IMG_BYTES = S16 * 1024;
+    constexpr int TILE_STRIDE = IMG_BYTES + 256;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int tok = blockIdx.x * 32 + c;
+    const bool valid = tok < n;
+    const float *zp = tokens + (size_t)(valid ? tok : n - 1) * D + 8 * h;
+    const int T = dvq_num_tiles(K), Kpad = 32 * T;
+    const float sB = meta->scale_b;
+    f16x8 zh[S16];
+    float pa[2][8];
+    float amax = 0.0f, zeta2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S16; ++s) {
+        u32x4 packed;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            const float v0 = zp[16 * s + 2 * j2], v1 = zp[16 * s + 2 * j2 + 1];
+            const float q0 = sq_rn(v0), q1 = sq_rn(v1);
+            pa[s & 1][2 * j2] = (s < 2) ? q0 : __fadd_rn(pa[s & 1][2 * j2], q0);
+            pa[s & 1][2 * j2 + 1] = (s < 2) ? q1 : __fadd_rn(pa[s & 1][2 * j2 + 1], q1);
+            amax = vmax_abs(amax, v0);
+            amax = vmax_abs(amax, v1);
+            f32x2 vv = {v0, v1};
+            f16x2 hh = __builtin_convertvector(vv, f16x2);
+            packed[j2] = __builtin_bit_cast(unsigned, hh);
+            const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
+            zeta2 = __builtin_fmaf(r0, r0, zeta2);
+            zeta2 = __builtin_fmaf(r1, r1, zeta2);
+        }
+        zh[s] = __builtin_bit_cast(f16x8, packed);
+    }
+    float t8[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float o0 = __shfl_xor(pa[0][l], 32), o1 = __shfl_xor(pa[1][l], 32);
+        float a0_ = h == 0 ? pa[0][l] : o0, a1_ = h == 0 ? o0 : pa[0][l];
+        float a2_ = h == 0 ? pa[1][l] : o1, a3_ = h == 0 ? o1 : pa[1][l];
+        t8[l] = __fadd_rn(__fadd_rn(__fadd_rn(a0_, a1_), a2_), a3_);
+    }
+    float xn = t8[0];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
+    amax = fmaxf(amax, __shfl_xor(amax, 32));
+    zeta2 += __shfl_xor(zeta2, 32);
+    const float thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
+    if (valid && h == 0) { thr2W_out[tok] = thr2W; xn_out[tok] = xn; }
+    for (int t = 0; t < T; ++t) {
+        const char *tile = img + (size_t)t * TILE_STRIDE;
+        const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 e4 = *(const f32x4 *)(seeds + 8 * g4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g4 + q] = e4[q];
+        }
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            const f16x8 a = *(const f16x8 *)(tile + s * 1024 + lane * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                G[(size_t)tok * Kpad + code] = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+            }
+        }
+    }
+}
+
+int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
+                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st)
+{
+    char *base = (char *)prep + dvq_prep_f16_offset(K, D);
+    base = (char *)(((uintptr_t)base + 255) / 256 * 256);
+    const DvqF16Meta *meta = (const DvqF16Meta *)base;
+    const char *img = base + 256;
+    const int blocks = (n + 31) / 32;
+    switch (D) {
+    case 64:  hipLaunchKernelGGL(filter_scores_debug_kernel<64>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
+    case 128: hipLaunchKernelGGL(filter_scores_debug_kernel<128>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
+    case 256: hipLaunchKernelGGL(filter_scores_debug_kernel<256>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
+    default:  return -1000;
+    }
+    if (scale_b_out != nullptr)
+        (void)hipMemcpyAsync(scale_b_out, &meta->scale_b, sizeof(float), hipMemcpyDeviceToDevice, st);
+    return (int)hipGetLastError();
+}
+
 __global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict__ chunk_sync, int nsync)
 {
     for (int i = threadIdx.x; i < DVQ_QCOUNT0 + DVQ_QSHARDS; i += blockDim.x) counters[i] = 0;

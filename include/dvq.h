@@ -165,6 +165,14 @@ int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
                                     float *zq, int64_t *codes, float *loss,
                                     int64_t *indices, float *cmask,
                                     void *ws, size_t ws_bytes, int mode, void *stream);
+/* Audit aid (tools/bound_audit.py, tests/test_bound_audit.py): the pass-1 score arithmetic of DVQ_MODE_FILTER on
+ * n tokens given as rows [n, D] -- every fp16-MFMA score G_j ~ -2^(b-1) (d_j - xn) as pass 1 sees it (index bits
+ * packed into the low mantissa bits), the per-token decision threshold 2W, the exact norm xn and the codebook scale
+ * 2^b -- so that the bound |G_j - truth_j| <= W can be checked against the reference arithmetic in float64 on the host.
+ *   scores [n, 32*ceil(K/32)] (padding codes hold -3e38), threshold [n], xn [n], scale [1] (nullable) */
+int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,
+                                float *threshold, float *xn, float *scale, void *stream);
+
 /* Tuning / testing aid: which pass-1 kernel DVQ_MODE_FILTER launches (process-wide; results are identical
  * for every choice).  dense_variant: -1 = the 2-waves-per-SIMD kernel that keeps an fp32 copy of z in
  * registers (wide form for K >= 2048), 0..3 = the low-register forms (0: 4-wave workgroups, 2-slot codebook

@@ -1,0 +1,23 @@
+"""GPU (-m gpu): the rigorous error bound W of the fp16 filter: for sampled tokens every
+pass-1 score is compared, in float64, with the reference-arithmetic score; |G - truth| <= W must hold for
+every (token, code) pair, and no provably-decided token may disagree with the reference's argmin."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bound_holds_with_margin(dev):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bound_audit", os.path.join(root, "tools", "bound_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(64, verbose=False)
+    assert len(res) >= 8
+    for r in res:
+        assert r["max_err_over_W"] <= 1.0, r              # the theorem
+        assert r["decided_but_wrong"] == 0, r
+        assert r["decided"] + r["skipped_unscorable"] > 0 or "default-init" in r["case"] or "duplicate" in r["case"], r
+    print("max |G - truth| / W over all cases: %.4f" % max(r["max_err_over_W"] for r in res))

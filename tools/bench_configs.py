@@ -62,10 +62,11 @@ out["cfg5_filter_tflops_equiv"] = flops / (tf * 1e-3) / 1e12
 # row f3: patch-entropy map of configs[2] (B=256 images 3x256x256), fused kernel vs the reference's op sequence as torch ops
 from dynamicvectorquantization_amd.entropy import Entropy
 img = t(synth.images_flat_noise(5000, 64)[0])
-ef, et = Entropy(16, 256, 256, fused=True).to(dev), Entropy(16, 256, 256, fused=False).to(dev)
+from oracle.entropy_torch import entropy_map as entropy_torch_ops
+ef = Entropy(16, 256, 256).to(dev)
 with torch.no_grad():
     out["entropy_map_B64_fused_ms"] = timeit(lambda: ef(img), n=10, warm=3)
-    out["entropy_map_B64_torch_ops_ms"] = timeit(lambda: et(img), n=5, warm=2)
+    out["entropy_map_B64_torch_ops_ms"] = timeit(lambda: entropy_torch_ops(img), n=5, warm=2)
 # row f1: permuter forward on configs[2]-shaped codes (B=256)
 from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
 perm = DualGrainSeperatePermuter(coarse_hw=16, fine_hw=32, content_pad_code=1024, content_eos_code=1025,

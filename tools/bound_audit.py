@@ -1,0 +1,101 @@
+"""Audit of the filter path's error bound W (derivation in vq_assign_filter.hip).
+
+For sampled tokens the pass-1 scores G_j (fp16 MFMA, seeded accumulator, packed index bits), the per-token
+threshold 2W and xn come back from the GPU through dvq_debug_filter_scores_f32; the REFERENCE-arithmetic
+distances d_j = fl(fl(xn + en_j) - 2 dot_j) come from the CPU oracle; in float64
+      truth_j = -2^(b-1) (d_j - xn)
+and the claim under audit is |G_j - truth_j| <= W for every (token, code) -- which is what makes
+"best - second > 2W  =>  the reference's argmin is pass 1's best" a theorem rather than a heuristic.
+Prints the largest observed ratio |G - truth| / W (1.0 would be the edge of the bound).
+
+Usage (GPU box): python tools/bound_audit.py [n_tokens_per_case]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicvectorquantization_amd import _lib, synth                       # noqa: E402
+from dynamicvectorquantization_amd.quantize import _CodebookPrep            # noqa: E402
+
+
+def scores(tokens, E, dev):
+    """tokens [n, D], E [K, D] numpy -> (G [n, K] f32, W [n] f64, xn [n] f32, scale 2^b)"""
+    n, D = tokens.shape
+    K = E.shape[0]
+    Kpad = (K + 31) // 32 * 32
+    tt, Et = torch.from_numpy(np.ascontiguousarray(tokens)).to(dev), torch.from_numpy(E).to(dev)
+    prep = _CodebookPrep()
+    pbuf = prep.get(Et)
+    G = torch.empty((n, Kpad), dtype=torch.float32, device=dev)
+    thr = torch.empty(n, dtype=torch.float32, device=dev)
+    xn = torch.empty(n, dtype=torch.float32, device=dev)
+    sc = torch.empty(1, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.dvq_debug_filter_scores_f32(tt.data_ptr(), n, pbuf.data_ptr(), D, K, G.data_ptr(), thr.data_ptr(),
+                                                    xn.data_ptr(), sc.data_ptr(), _lib.stream_ptr(dev)),
+               "dvq_debug_filter_scores_f32")
+    torch.cuda.synchronize()
+    return G.cpu().numpy()[:, :K], thr.cpu().numpy().astype(np.float64) / 2.0, xn.cpu().numpy(), float(sc.item())
+
+
+def audit_case(name, tokens, E, dev):
+    from oracle import oracle
+    G, W, xn, sB = scores(tokens, E, dev)
+    n, K = G.shape
+    worst, decided, wrong, skipped = 0.0, 0, 0, 0
+    for i in range(n):
+        if not np.isfinite(W[i]):
+            skipped += 1                                  # the kernel sends such tokens to the exact list
+            continue
+        d = oracle.token_distances(tokens[i], E).astype(np.float64)       # reference fp32 arithmetic
+        truth = -0.5 * sB * (d - np.float64(xn[i]))
+        err = np.abs(G[i].astype(np.float64) - truth)
+        worst = max(worst, float(err.max() / W[i]))
+        order = np.argsort(-G[i], kind="stable")
+        if G[i][order[0]] - G[i][order[1]] > 2 * W[i]:
+            decided += 1
+            wrong += int(order[0] != int(np.argmin(d)))
+    return {"case": name, "tokens": n, "codes": K, "scale_b": sB, "max_err_over_W": worst, "decided": decided,
+            "decided_but_wrong": wrong, "skipped_unscorable": skipped}
+
+
+def cases(n):
+    """(name, tokens [n, D], codebook) -- trained-like data, the tie-stress default init, large / tiny magnitudes,
+    fp16-subnormal territory, near-duplicate codes, K = 16384, D = 64"""
+    out = []
+    E = synth.codebook_trained(1024, 256)
+    tok = lambda E_, seed, m=n: synth.z_tokens(E_, 1, 1, m, seed)[0, :, 0, :].T.copy()
+    out.append(("trained K=1024", tok(E, 11), E))
+    Ed = synth.codebook_default_init(1024, 256)
+    out.append(("default-init U(-1/K,1/K), tokens ~ N(0,1)", tok(Ed, 12), Ed))
+    out.append(("default-init, tokens at codebook scale", tok(Ed, 13) * np.float32(1e-3), Ed))
+    out.append(("tokens x 1e3", tok(E, 14) * np.float32(1e3), E))
+    out.append(("tokens x 1e-5 (fp16 subnormals)", tok(E, 15) * np.float32(1e-5), E))
+    Em = E * np.exp2(np.arange(1024) % 11 - 5).astype(np.float32)[:, None]
+    out.append(("codebook with norms spread over 2^10", tok(Em, 16), Em))
+    En = E.copy()
+    En[1::2] = En[0::2] * np.float32(1 + 2 ** -12)
+    out.append(("near-duplicate code pairs", tok(En, 17), En))
+    E16 = synth.codebook_trained(16384, 256)
+    out.append(("trained K=16384", tok(E16, 18, max(32, n // 4)), E16))
+    E64 = synth.codebook_trained(512, 64, seed=77)
+    out.append(("D=64", tok(E64, 19), E64))
+    return out
+
+
+def run(n=96, verbose=True):
+    dev = torch.device("cuda:0")
+    res = [audit_case(name, t, E, dev) for name, t, E in cases(n)]
+    if verbose:
+        for r in res:
+            print(json.dumps(r))
+    return res
+
+
+if __name__ == "__main__":
+    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+    print(json.dumps({"max_err_over_W": max(x["max_err_over_W"] for x in r),
+                      "decided_but_wrong": sum(x["decided_but_wrong"] for x in r)}))
