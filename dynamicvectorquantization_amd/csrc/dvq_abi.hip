@@ -179,6 +179,9 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     return DVQ_OK;
 }
 
+// token ids of a routed batch: at most one per output position
+static long routed_ids(int nb, int B, long N) { (void)nb; (void)B; return N; }
+
 static int routed_dims(int nb, int hc, int wc, int *SC)
 {
     *SC = (nb == 2) ? 2 : 4;
@@ -192,7 +195,7 @@ size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int 
     const int HWout = SC * hc * SC * wc;
     const long N = (long)B * HWout;
     (void)mode;                                          // sized for the filter path in every mode
-    return partials_bytes_for(N) + dvq_filter_ws_extra_bytes(D, HWout, K, N) +
+    return partials_bytes_for(routed_ids(num_branches, B, N)) + dvq_filter_ws_extra_bytes(D, HWout, K, N) +
            dvq_routed_tables_bytes(num_branches, B, hc, wc) + 256;
 }
 
@@ -201,7 +204,7 @@ size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D
     int SC;
     (void)D; (void)K;
     if (B <= 0 || !routed_dims(num_branches, hc, wc, &SC)) return 0;
-    return partials_bytes_for((long)B * SC * hc * SC * wc);
+    return partials_bytes_for(routed_ids(num_branches, B, (long)B * SC * hc * SC * wc));
 }
 
 static int routed_common(const char *fn, int nb, const void *gate, int gate_kind, float threshold,
@@ -233,17 +236,12 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     double *partials = loss ? (double *)ws : nullptr;
-    const size_t pbytes = partials_bytes_for(N);
+    const size_t pbytes = partials_bytes_for(routed_ids(nb, B, N));
     const int gmode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
     int rc = dvq_launch_routed(nb, gmode, gate, threshold, h_coarse, h_median, h_fine, prep, codebook, B, D, hc, wc, K,
                                beta, zq, (long long *)codes, loss, (long long *)indices, cmask, (long long *)gate_out,
                                partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st);
-    if (rc) return hip_rc(rc, fn);
-    if (mode == DVQ_MODE_EXACT && loss) {
-        rc = dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
-        if (rc) return hip_rc(rc, "vq_loss_finalize");
-    }
-    return DVQ_OK;
+    return hip_rc(rc, fn);                                   // the loss finalize is part of the op in both modes
 }
 
 int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,

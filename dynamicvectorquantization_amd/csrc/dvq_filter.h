@@ -77,87 +77,84 @@ __device__ __forceinline__ float vmax3_raw(float a, float b, float c)
 //
 // Grain type g (0 coarse, [1 median,] G-1 fine) owns a source tensor src[g] [B, D, sub_g*hc, sub_g*wc]
 // (sub = tokens per coarse-cell edge: dual 1 / 2, triple 1 / 2 / 4) and covers rep_g x rep_g output
-// positions per token (rep = SC / sub, SC = sub of the fine type).  The routing prepass
-// (routed_prepass_kernel) writes, per image and type, the list of coarse cells of that type in
-// row-major order (`cells`) and the unique-token counts; tokens of a cell are consecutive
-// (cell-major, row-major inside the cell), so the 32 tokens of a wave sit in one or two rows of coarse
-// cells: a few 128-B lines per load instruction.
+// positions per token (rep = SC / sub, SC = sub of the fine type).
 //
-// Virtual token order: images in groups of DVQ_ROUTE_GROUP; inside a group all coarse tokens, then all
-// median, then all fine ones (a group's outputs share L2 lines, its segments are processed close
-// together in time); every (group, type) segment starts at a multiple of 32 tokens (a "slot" = the 32
-// tokens of one wave), so a wave never mixes types: source stride and replication are wave-uniform.
-// seg_base[grp*G + g] = first slot of the segment, seg_base[nseg] = total number of slots.
+// Token order: inside an image, row-major by the token's TOP-LEFT output position (y0, x0); images in
+// batch order; no padding anywhere, types mix freely (source stride and replication are per lane).  So
+// the 32 tokens of a wave (a "slot") cover one or two whole rows of the output grid: a row of a fine
+// region takes its fine tokens left to right, interleaved with the coarse / median tokens whose block
+// starts in that row, and every 128-B line of z_q is written completely by one wave or by two adjacent
+// waves of one workgroup within a microsecond -- the L2 merges them.  (With the types in separate waves
+// the 8-byte pieces of a line arrived from different CUs at different times and every line went to HBM
+// as read-modify-write: measured 2.2x slower.)
+// The routing prepass (routed_prepass_kernel) writes, per image, the table rank -> token (`tok`) and the
+// image's token count; imgstart[b] = number of tokens before image b, imgstart[B] = all of them.
 // ---------------------------------------------------------------------------------------------
-#define DVQ_ROUTE_GROUP 8
 #define DVQ_ROUTE_MAX_CELLS 1024
+
+// tok entry: [15:14] grain type, [13:12] sy, [11:10] sx (position inside the coarse cell, in the type's grid),
+// [9:0] coarse cell index
+__host__ __device__ inline unsigned short dvq_tok_pack(int g, int sy, int sx, int cell)
+{
+    return (unsigned short)((g << 14) | (sy << 12) | (sx << 10) | cell);
+}
 
 struct DvqRouted {
     const float *src[3];
-    float mval[3];            // codebook_mask value of each type (1 / rep^2)
     int sub[3];               // tokens per coarse-cell edge
     int rep[3];               // output positions per token edge
     int G, B, D, hc, wc;
     int Wout, HWout;          // output grid: SC*wc, (SC*hc)*(SC*wc)
-    const int *counts;        // [G][B] unique tokens
-    const int *seg_base;      // [nseg + 1] slots
-    const unsigned short *cells;   // [G][B][hc*wc]
-    int nseg;
+    const int *imgstart;      // [B + 1]
+    const unsigned short *tok;   // [B][HWout]
 };
 
 struct DvqTok {
     const float *src;   // channel 0 of the token
     int stride;         // elements between channels
     long n;             // top-left output position (b*HWout + y0*Wout + x0); code / mask index
-    long zq0;           // element offset of channel 0 at that position in z_q [B, D, HWout]
     int rep;
     bool valid;
 };
 
-// token `c` of slot `slot` (both any value; slot beyond the end -> invalid).  g_out: the slot's type
-// (wave-uniform if slot is).
-__device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int slot, int c, int &g_out)
+// image of token t, starting the walk at image b_hint (imgstart[b_hint] <= t must hold)
+__device__ __forceinline__ int dvq_routed_image(const DvqRouted &rv, int t, int b_hint)
 {
-    DvqTok t;
-    const int nslots = rv.seg_base[rv.nseg];
-    const bool in_range = slot < nslots;
-    const int s = in_range ? slot : (nslots > 0 ? nslots - 1 : 0);
-    int lo = 0, hi = rv.nseg;                       // last seg with seg_base[seg] <= s
+    int b = b_hint;
+    while (b + 1 < rv.B && t >= rv.imgstart[b + 1]) ++b;
+    return b;
+}
+
+// last image whose first token is <= t (binary search; t < imgstart[B])
+__device__ __forceinline__ int dvq_routed_image_search(const DvqRouted &rv, int t)
+{
+    int lo = 0, hi = rv.B;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (rv.seg_base[mid] <= s) lo = mid; else hi = mid;
+        if (rv.imgstart[mid] <= t) lo = mid; else hi = mid;
     }
-    const int seg = lo, grp = seg / rv.G, g = seg - grp * rv.G;
-    g_out = g;
-    int r = 32 * (s - rv.seg_base[seg]) + c;
-    int b = grp * DVQ_ROUTE_GROUP;
-    const int bend = (b + DVQ_ROUTE_GROUP < rv.B) ? b + DVQ_ROUTE_GROUP : rv.B;
-    const int *cnt = rv.counts + (size_t)g * rv.B;
-    while (b < bend) {
-        const int cb = cnt[b];
-        if (r < cb) break;
-        r -= cb;
-        ++b;
-    }
-    t.valid = in_range && b < bend && nslots > 0;
-    if (b >= bend) { b = bend - 1; r = 0; }
-    const int sub = rv.sub[g], rep = rv.rep[g];
-    const int per = sub * sub;
-    const int k = r / per, w = r - k * per;
-    const int ncell = rv.hc * rv.wc;
-    int cell = rv.cells[((size_t)g * rv.B + b) * ncell + (t.valid ? k : 0)];
-    if (!t.valid) cell = 0;
+    return lo;
+}
+
+// token t of the batch (any value; beyond the end -> invalid, clamped to token 0's addresses)
+__device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int t, int b_hint)
+{
+    DvqTok k;
+    const int total = rv.imgstart[rv.B];
+    k.valid = t >= 0 && t < total;
+    const int tt = k.valid ? t : 0;
+    const int b = dvq_routed_image(rv, tt, k.valid ? b_hint : 0);
+    const unsigned e = (total > 0) ? rv.tok[(size_t)b * rv.HWout + (tt - rv.imgstart[b])] : 0u;
+    const int g = (int)(e >> 14), sy = (int)((e >> 12) & 3u), sx = (int)((e >> 10) & 3u), cell = (int)(e & 1023u);
     const int cy = cell / rv.wc, cx = cell - cy * rv.wc;
-    const int sy = w / sub, sx = w - sy * sub;
+    const int sub = rv.sub[g], rep = rv.rep[g];
     const int gy = cy * sub + sy, gx = cx * sub + sx;             // position in the type's own grid
     const int gwid = rv.wc * sub, plane = rv.hc * sub * gwid;
-    t.src = rv.src[g] + (size_t)b * rv.D * plane + (size_t)gy * gwid + gx;
-    t.stride = plane;
-    const long pos = (long)(gy * rep) * rv.Wout + gx * rep;
-    t.n = (long)b * rv.HWout + pos;
-    t.zq0 = (long)b * rv.D * rv.HWout + pos;
-    t.rep = rep;
-    return t;
+    k.src = rv.src[g] + (size_t)b * rv.D * plane + (size_t)gy * gwid + gx;
+    k.stride = plane;
+    k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
+    k.rep = rep;
+    return k;
 }
 
 // arguments of the low-register pass-1 kernel (vq_assign_routed.hip: vq_pass1_kernel)
@@ -178,4 +175,8 @@ struct P1Args {
     int *exact_list;
     char *records;
     int rec_cap;               // per shard
+    int stagger_ticks;         // > 0: the odd "layers" of the first generation of workgroups start this many
+                               // 100-MHz ticks late, so co-resident workgroups alternate HBM and matrix phases
+    int stagger_blocks;        // workgroups per layer (= CUs) and first-generation size
+    int stagger_first;
 };

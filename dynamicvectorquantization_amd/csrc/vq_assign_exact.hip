@@ -23,7 +23,7 @@
 #include <type_traits>
 
 // ROUTED: the tokens are the unique tokens of a routed batch (dvq_filter.h: DvqRouted), addressed in the
-// encoder branches; token ids are slot*32 + lane, a token covers rep x rep output positions.
+// encoder branches by their rank in the batch's token order; a token covers rep x rep output positions.
 template <int D, bool LIST, bool ROUTED>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *zp;                                   // channel h of the token; channel k = 2s + h at zp + 2s*stride
     int stride, rep = 1, Wout = 0, HWo = HW;
     if (ROUTED) {
-        int g;
-        const DvqTok tk = dvq_routed_lookup(rv, (int)(nn >> 5), (int)(nn & 31), g);
+        const int total = rv.imgstart[rv.B];
+        const int tid_ = (nn >= 0 && nn < total) ? (int)nn : 0;
+        const DvqTok tk = dvq_routed_lookup(rv, (nn >= 0 && nn < total) ? (int)nn : -1,
+                                            total > 0 ? dvq_routed_image_search(rv, tid_) : 0);   // token id -> branch tensor address
         valid = valid && tk.valid;
         stride = tk.stride;
         zp = tk.src + (size_t)h * stride;

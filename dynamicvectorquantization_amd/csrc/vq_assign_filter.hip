@@ -1161,8 +1161,8 @@ static int list_blocks(long N)
 int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, int nblocks, hipStream_t st);
 int dvq_pass1_tokens_per_block(int variant);
 int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
-                              long long *indices, float *cmask, long long *gate_out, int *counts,
-                              unsigned short *cells, int *seg_base, int nseg, int *ticket, hipStream_t st);
+                              long long *indices, float *cmask, long long *gate_out, int *imgcount,
+                              unsigned short *tok, int *imgstart, int *ticket, hipStream_t st);
 
 // Which pass-1 kernel: DVQ_PASS1_VARIANT = -1 legacy (fp32 copy of z in registers, 2 waves / SIMD; the wide
 // form for large codebooks), 0..3 the low-register forms of vq_assign_routed.hip.  The routed op always
@@ -1179,6 +1179,9 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 #endif
 #ifndef DVQ_ROUTED_DEFAULT
 #define DVQ_ROUTED_DEFAULT 0
+#endif
+#ifndef DVQ_STAGGER_DEFAULT_US
+#define DVQ_STAGGER_DEFAULT_US 0
 #endif
 static int g_dense_variant = -2, g_routed_variant = -2;      // -2: not chosen yet (environment / default)
 static int dense_variant()
@@ -1305,13 +1308,26 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
         }
     } else {
         const int tpb = dvq_pass1_tokens_per_block(variant);
-        np1 = (int)((N + tpb - 1) / tpb);
+        np1 = (int)((N + tpb - 1) / tpb);                      // routed: the all-fine worst case sizes the grid
         P1Args a;
         a.z = z; a.HW = HW; a.N = N;
         if (routed) a.rv = *rv; else a.rv = DvqRouted{};
         a.img = img; a.meta = meta; a.E = E; a.mask = mask; a.K = K; a.zq = zq; a.codes = codes;
         a.partials = partials; a.counters = w.counters; a.exact_list = w.exact_list; a.records = w.records;
         a.rec_cap = w.cap / DVQ_QSHARDS;
+        {
+            const int stag = env_int("DVQ_STAGGER_US", DVQ_STAGGER_DEFAULT_US, 0, 1000);   // read per launch: a tuning aid
+            static int ncu = 0;
+            if (ncu == 0) {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                ncu = n > 0 ? n : 256;
+            }
+            const int per_cu = (variant == 1) ? 3 : ((variant >= 2) ? 2 : 4);
+            a.stagger_ticks = stag * 100;
+            a.stagger_blocks = ncu;
+            a.stagger_first = ncu * per_cu;
+        }
         rc = dvq_launch_pass1_lowreg(D, routed, variant, a, np1, st);
     }
     if (rc || pass1_only) return rc;
@@ -1329,12 +1345,12 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
 }
 
 // ---- routed op ---------------------------------------------------------------------------------
-// routing tables behind the filter workspace: [counts G*B ints][seg_base nseg+1 ints][cells G*B*ncell u16]
-static int routed_nseg(int G, int B) { return (B + DVQ_ROUTE_GROUP - 1) / DVQ_ROUTE_GROUP * G; }
+// routing tables behind the filter workspace: [imgcount B ints][imgstart B+1 ints][tok B*HWout u16]
 size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc)
 {
-    return align256((size_t)G * B * sizeof(int)) + align256((size_t)(routed_nseg(G, B) + 1) * sizeof(int)) +
-           align256((size_t)G * B * hc * wc * sizeof(unsigned short));
+    const int SC = (G == 2) ? 2 : 4;
+    return align256((size_t)B * sizeof(int)) + align256((size_t)(B + 1) * sizeof(int)) +
+           align256((size_t)B * SC * hc * SC * wc * sizeof(unsigned short));
 }
 
 // zero counters -> prepass (indices, codebook_mask, gate_out, routing tables) -> the filter op (or, exact
@@ -1343,6 +1359,8 @@ size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc)
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                      const DvqRouted *rv, hipStream_t st);
+int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
+                             float *loss, hipStream_t st);
 
 int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
@@ -1355,30 +1373,31 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     const long N = (long)B * HWout;
     const FilterWs w = carve_ws(ws_extra, N, D);
     char *tab = (char *)ws_extra + dvq_filter_ws_extra_bytes(D, HWout, K, N);
-    int *counts = (int *)tab;
-    int *seg_base = (int *)(tab + align256((size_t)G * B * sizeof(int)));
-    const int nseg = routed_nseg(G, B);
-    unsigned short *cells = (unsigned short *)((char *)seg_base + align256((size_t)(nseg + 1) * sizeof(int)));
+    int *imgcount = (int *)tab;
+    int *imgstart = (int *)(tab + align256((size_t)B * sizeof(int)));
+    unsigned short *tok = (unsigned short *)((char *)imgstart + align256((size_t)(B + 1) * sizeof(int)));
     hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
                        resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-    int rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, counts, cells,
-                                       seg_base, nseg, w.counters + 5, st);
+    int rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
+                                       imgstart, w.counters + 5, st);
     if (rc) return rc;
     DvqRouted rv{};
     rv.G = G; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = Wout; rv.HWout = HWout;
-    rv.counts = counts; rv.seg_base = seg_base; rv.cells = cells; rv.nseg = nseg;
+    rv.imgstart = imgstart; rv.tok = tok;
     if (G == 2) {
         rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
-        rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 0;
-        rv.rep[0] = 2; rv.rep[1] = 1; rv.rep[2] = 0;
-        rv.mval[0] = 0.25f; rv.mval[1] = 1.0f; rv.mval[2] = 0.0f;
+        rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1;
+        rv.rep[0] = 2; rv.rep[1] = 1; rv.rep[2] = 1;
     } else {
         rv.src[0] = h_coarse; rv.src[1] = h_median; rv.src[2] = h_fine;
         rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 4;
         rv.rep[0] = 4; rv.rep[1] = 2; rv.rep[2] = 1;
-        rv.mval[0] = 0.0625f; rv.mval[1] = 0.25f; rv.mval[2] = 1.0f;
     }
-    if (exact) return dvq_launch_exact(nullptr, (const float *)prep, E, cmask, D, HWout, K, N, zq, codes, partials, &rv, st);
+    if (exact) {
+        rc = dvq_launch_exact(nullptr, (const float *)prep, E, cmask, D, HWout, K, N, zq, codes, partials, &rv, st);
+        if (rc || loss == nullptr) return rc;
+        return dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
+    }
     return dvq_launch_filter(nullptr, prep, E, cmask, D, HWout, K, N, zq, codes, partials, ws_extra, pass1_only, false,
                              loss, beta, &rv, st);
 }

@@ -11,9 +11,10 @@
 // the 2 x 268 MB of h_dual traffic (select writes it, assign reads it back) disappear.
 //
 //   routed_prepass_kernel   one workgroup per image: argmax of the gate (or entropy > threshold) per
-//                           coarse cell -> indices, codebook_mask, the router's int64 gate, per-type
-//                           cell lists + unique-token counts; the last workgroup to finish lays the
-//                           (group, type) segments out in 32-token slots (dvq_filter.h: DvqRouted)
+//                           coarse cell -> indices, codebook_mask, the router's int64 gate, and the
+//                           image's rank -> token table in row-major order of the tokens' top-left output
+//                           positions (dvq_filter.h: DvqRouted); the last workgroup to finish turns the
+//                           per-image token counts into the prefix imgstart[]
 //   vq_pass1_kernel         pass 1 with NO fp32 copy of z in registers: z is read once for the fp16
 //                           fragments (64 VGPRs) and again in the epilogue, where it is still cache
 //                           resident (L2 / Infinity Cache) -> <= 128 VGPRs, 3-4 waves per SIMD, so the
@@ -55,17 +56,21 @@ template <int G, int MODE>
 __global__ __launch_bounds__(256) void routed_prepass_kernel(
     const void *__restrict__ gate, float thr, int B, int hc, int wc,
     long long *__restrict__ indices, float *__restrict__ cmask, long long *__restrict__ gate_out,
-    int *__restrict__ counts, unsigned short *__restrict__ cells, int *__restrict__ seg_base, int nseg,
+    int *__restrict__ imgcount, unsigned short *__restrict__ tok, int *__restrict__ imgstart,
     int *__restrict__ ticket)
 {
     constexpr int SC = (G == 2) ? 2 : 4;
+    constexpr int MAXH = SC * DVQ_ROUTE_MAX_CELLS;             // hc <= ncell
     __shared__ unsigned char grain[DVQ_ROUTE_MAX_CELLS];
-    __shared__ int wtot[G][4];
+    __shared__ int rowstart[MAXH + 1];
     __shared__ int scan[256];
     __shared__ int flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int b = blockIdx.x, ncell = hc * wc;
-    const int H = SC * hc, W = SC * wc, W4 = W / 4;
+    const int H = SC * hc, W = SC * wc, W4 = W / 4, HW = H * W;
+    auto sub_of = [](int g) { return (g == G - 1) ? SC : (g == 0 ? 1 : 2); };
+    // tokens of a cell of type g whose top-left output row is the cell's sub-row ry (0 .. SC-1)
+    auto contrib = [&](int g, int ry) { const int sub = sub_of(g), rep = SC / sub; return (ry % rep == 0) ? sub : 0; };
 
     for (int cell = tid; cell < ncell; cell += 256) {
         const int g = routed_gate_argmax<G, MODE>(gate, (size_t)b * ncell + cell, thr);
@@ -88,58 +93,15 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
         }
         *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
     }
-    // per-type lists of coarse cells, row-major
-    int base[G];
-#pragma unroll
-    for (int q = 0; q < G; ++q) base[q] = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 256) {
-        const int cell = c0 + tid;
-        const int g = (cell < ncell) ? (int)grain[cell] : -1;
-        int pre[G];
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-            const unsigned long long bal = __ballot(g == q);
-            pre[q] = (int)__popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wtot[q][wave] = (int)__popcll(bal);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-            int woff = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int v = wtot[q][w];
-                woff += (w < wave) ? v : 0;
-                tot += v;
-            }
-            if (g == q) cells[((size_t)q * B + b) * ncell + base[q] + woff + pre[q]] = (unsigned short)cell;
-            base[q] += tot;
-        }
-        __syncthreads();
-    }
-    if (tid < G) {
-        const int sub = (tid == G - 1) ? SC : (tid == 0 ? 1 : 2);
-        __hip_atomic_store(&counts[(size_t)tid * B + b], base[tid] * sub * sub, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the workgroup that draws the last ticket lays out the segments
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        flag = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!flag) return;
-    __threadfence();
-    // slots per segment, then an exclusive scan: thread i owns segments [i*per, (i+1)*per)
-    const int per = (nseg + 255) / 256;
+    // tokens per output row (by top-left position), then an exclusive scan over the H rows
+    const int per = (H + 255) / 256;
     int mine = 0;
-    for (int s = tid * per; s < (tid + 1) * per && s < nseg; ++s) {
-        const int grp = s / G, g = s - grp * G;
-        int tot = 0;
-        for (int bb = grp * DVQ_ROUTE_GROUP; bb < (grp + 1) * DVQ_ROUTE_GROUP && bb < B; ++bb)
-            tot += __hip_atomic_load(&counts[(size_t)g * B + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mine += (tot + 31) / 32;
+    for (int y = tid * per; y < (tid + 1) * per && y < H; ++y) {
+        const int cy = y / SC, ry = y - cy * SC;
+        int cnt = 0;
+        for (int cx = 0; cx < wc; ++cx) cnt += contrib(grain[cy * wc + cx], ry);
+        rowstart[y + 1] = cnt;                                 // count for now
+        mine += cnt;
     }
     scan[tid] = mine;
     __syncthreads();
@@ -149,16 +111,58 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
         scan[tid] += v;
         __syncthreads();
     }
-    int run = scan[tid] - mine;                                 // exclusive prefix of this thread's chunk
-    for (int s = tid * per; s < (tid + 1) * per && s < nseg; ++s) {
-        const int grp = s / G, g = s - grp * G;
-        int tot = 0;
-        for (int bb = grp * DVQ_ROUTE_GROUP; bb < (grp + 1) * DVQ_ROUTE_GROUP && bb < B; ++bb)
-            tot += __hip_atomic_load(&counts[(size_t)g * B + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seg_base[s] = run;
-        run += (tot + 31) / 32;
+    {
+        int run = scan[tid] - mine;
+        for (int y = tid * per; y < (tid + 1) * per && y < H; ++y) {
+            const int cnt = rowstart[y + 1];
+            rowstart[y + 1] = run + cnt;                       // inclusive -> start of row y + 1
+            run += cnt;
+        }
+        if (tid == 0) rowstart[0] = 0;
     }
-    if (tid == 255) seg_base[nseg] = scan[255];
+    __syncthreads();
+    // rank -> token table
+    unsigned short *tb = tok + (size_t)b * HW;
+    for (int cell = tid; cell < ncell; cell += 256) {
+        const int g = grain[cell], sub = sub_of(g), rep = SC / sub;
+        const int cy = cell / wc, cx = cell - cy * wc;
+        for (int sy = 0; sy < sub; ++sy) {
+            const int ry = sy * rep;
+            int pre = 0;
+            for (int c2 = 0; c2 < cx; ++c2) pre += contrib(grain[cy * wc + c2], ry);
+            const int r0 = rowstart[cy * SC + ry] + pre;
+            for (int sx = 0; sx < sub; ++sx) tb[r0 + sx] = dvq_tok_pack(g, sy, sx, cell);
+        }
+    }
+    if (tid == 0)
+        __hip_atomic_store(&imgcount[b], rowstart[H], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the workgroup that draws the last ticket turns the counts into the prefix imgstart[0 .. B]
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        flag = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!flag) return;
+    __threadfence();
+    const int perb = (B + 255) / 256;
+    int sum = 0;
+    for (int i = tid * perb; i < (tid + 1) * perb && i < B; ++i)
+        sum += __hip_atomic_load(&imgcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = (tid >= off) ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int run = scan[tid] - sum;
+    for (int i = tid * perb; i < (tid + 1) * perb && i < B; ++i) {
+        imgstart[i] = run;
+        run += __hip_atomic_load(&imgcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 255) imgstart[B] = scan[255];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,8 +205,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
 
     // ---- which tokens
     int nblk = (int)gridDim.x;
+    int total = 0;
     if (ROUTED) {
-        const int nslots = a.rv.seg_base[a.rv.nseg];
+        total = a.rv.imgstart[a.rv.B];
+        const int nslots = (total + 31) / 32;
         nblk = (nslots + NW - 1) / NW;
         if ((int)blockIdx.x >= nblk) {                       // the grid is sized for the all-fine worst case
             if (a.partials != nullptr && tid == 0) a.partials[blockIdx.x] = 0.0;
@@ -210,6 +216,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
         }
     }
     const float sB = a.meta->scale_b;
+    if (a.stagger_ticks > 0 && (int)blockIdx.x < a.stagger_first && (((int)blockIdx.x / a.stagger_blocks) & 1)) {
+        // phase offset for every other layer of the first generation of resident workgroups: without it all of
+        // them run prologue (HBM) -> code loop (matrix cores) -> epilogue (HBM) in lockstep and the two
+        // resources are used one after the other instead of side by side
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
 
     auto issue_piece = [&](int t, int q) {
         const int tt = (t < T) ? t : T - 1;                  // past the end: harmless repeat, counts stay constant
@@ -231,23 +244,20 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
 
     const int tile_id = xcd_swizzle(blockIdx.x, nblk);
     const float *zsrc;                                       // channel 8h of this lane's token
-    int stride, rep = 1, Wout = 0, HWout;
+    int stride, rep = 1, Wout = 0, HWout;                    // ROUTED: stride and rep are per lane
     int n;                                                   // output position of the token, -1 = no token
     int tokid;                                               // what the exact list carries for it
-    float mval = 1.0f;
     if (ROUTED) {
-        const int slot = tile_id * NW + wave;
-        int g;
-        const DvqTok tk = dvq_routed_lookup(a.rv, slot, c, g);
-        g = __builtin_amdgcn_readfirstlane(g);
-        stride = __builtin_amdgcn_readfirstlane(tk.stride);
-        rep = __builtin_amdgcn_readfirstlane(tk.rep);
+        const int t0 = (tile_id * NW + wave) * 32;           // wave-uniform: first token of the slot
+        const int b0 = (t0 < total) ? dvq_routed_image_search(a.rv, t0) : 0;
+        tokid = t0 + c;
+        const DvqTok tk = dvq_routed_lookup(a.rv, tokid, b0);
+        stride = tk.stride;
+        rep = tk.rep;
         Wout = a.rv.Wout;
         HWout = a.rv.HWout;
         zsrc = tk.src + (size_t)8 * h * stride;
         n = tk.valid ? (int)tk.n : -1;
-        tokid = slot * 32 + c;
-        (void)g;
     } else {
         const long n_raw = ((long)tile_id * NW + wave) * 32 + c;
         n = (n_raw < a.N) ? (int)n_raw : -1;
@@ -439,9 +449,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
             char *rec = (slot >= 0) ? a.records + ((size_t)shard * a.rec_cap + slot) * rec_bytes(D) : nullptr;
             const long bimg = n / HWout;
             const size_t zq0 = ((size_t)bimg * D + 8 * h) * HWout + (size_t)(n - bimg * HWout);
-            auto finish = [&](auto store_tag, auto rep_tag) {
+            auto finish = [&](auto store_tag) {
                 constexpr bool STORE = decltype(store_tag)::value;
-                constexpr int REP = decltype(rep_tag)::value;
                 float *zqp = STORE ? a.zq + zq0 : nullptr;
                 const float *zpe = zsrc, *epe = ep;          // advance by two k-steps per batch
                 constexpr int EB = (S16 < 2) ? S16 : 2;
@@ -456,17 +465,35 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
                         eg[q][0] = *(const f32x4 *)(epe + 16 * q);
                         eg[q][1] = *(const f32x4 *)(epe + 16 * q + 4);
                     }
+                    float v[EB][8];
 #pragma unroll
                     for (int q = 0; q < EB; ++q) {
-                        const int s = s0 + q;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             float e = eg[q][j >> 2][j & 3];
                             float diff = __fsub_rn(e, zf[q][j]);
-                            if (STORE) store_rep<REP>(zqp + (size_t)(16 * s + j) * HWout, __fadd_rn(zf[q][j], diff), Wout);
+                            v[q][j] = __fadd_rn(zf[q][j], diff);
                             lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
                         }
-                        if (rec != nullptr) {
+                    }
+                    if (STORE) {
+                        // one branch per batch on the lane's replication (a wave may mix grain types)
+                        auto put = [&](auto rep_tag) {
+                            constexpr int REP = decltype(rep_tag)::value;
+#pragma unroll
+                            for (int q = 0; q < EB; ++q)
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    store_rep<REP>(zqp + (size_t)(16 * (s0 + q) + j) * HWout, v[q][j], Wout);
+                        };
+                        if (!ROUTED || rep == 1) put(std::integral_constant<int, 1>{});
+                        else if (rep == 2) put(std::integral_constant<int, 2>{});
+                        else put(std::integral_constant<int, 4>{});
+                    }
+                    if (rec != nullptr) {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q) {
+                            const int s = s0 + q;
                             f32x4 lo = {zf[q][0], zf[q][1], zf[q][2], zf[q][3]};
                             f32x4 hi = {zf[q][4], zf[q][5], zf[q][6], zf[q][7]};
                             *(f32x4 *)(rec + (16 * s + 8 * h) * 4) = lo;
@@ -478,16 +505,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
                     asm volatile("" : "+v"(zpe), "+v"(epe) : "v"(lsum));     // next batch's loads wait for this one
                 }
             };
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            using I4 = std::integral_constant<int, 4>;
-            if (a.zq != nullptr) {
-                if (!ROUTED || rep == 1) finish(std::true_type{}, I1{});
-                else if (rep == 2) finish(std::true_type{}, I2{});
-                else finish(std::true_type{}, I4{});
-            } else {
-                finish(std::false_type{}, I1{});
-            }
+            if (a.zq != nullptr) finish(std::true_type{});
+            else finish(std::false_type{});
             lsum *= (float)(rep * rep);                      // every covered position carries the same term
             if (rec != nullptr && h == 0) {
                 RecMeta rm;
@@ -557,10 +576,10 @@ int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, in
 }
 
 int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
-                              long long *indices, float *cmask, long long *gate_out, int *counts,
-                              unsigned short *cells, int *seg_base, int nseg, int *ticket, hipStream_t st)
+                              long long *indices, float *cmask, long long *gate_out, int *imgcount,
+                              unsigned short *tok, int *imgstart, int *ticket, hipStream_t st)
 {
-#define DVQ_PRE(GG, MM) hipLaunchKernelGGL((routed_prepass_kernel<GG, MM>), dim3(B), dim3(256), 0, st, gate, thr, B, hc, wc, indices, cmask, gate_out, counts, cells, seg_base, nseg, ticket)
+#define DVQ_PRE(GG, MM) hipLaunchKernelGGL((routed_prepass_kernel<GG, MM>), dim3(B), dim3(256), 0, st, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok, imgstart, ticket)
     if (G == 2 && gate_mode == 2) DVQ_PRE(2, 2);
     else if (G == 2 && gate_mode == 1) DVQ_PRE(2, 1);
     else if (G == 2) DVQ_PRE(2, 0);
