@@ -107,6 +107,8 @@ struct DvqRouted {
     int Wout, HWout;          // output grid: SC*wc, (SC*hc)*(SC*wc)
     const int *imgstart;      // [B + 1]
     const unsigned short *tok;   // [B][HWout]
+    int dense;                // 1: one token per OUTPUT POSITION (no de-duplication; rank = position, rep = 1):
+                              //    the select fused into a dense assign, every wave owns whole output rows
 };
 
 struct DvqTok {
@@ -152,8 +154,13 @@ __device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int t, 
     const int gwid = rv.wc * sub, plane = rv.hc * sub * gwid;
     k.src = rv.src[g] + (size_t)b * rv.D * plane + (size_t)gy * gwid + gx;
     k.stride = plane;
-    k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
-    k.rep = rep;
+    if (rv.dense) {
+        k.n = (long)b * rv.HWout + (tt - rv.imgstart[b]);
+        k.rep = 1;
+    } else {
+        k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
+        k.rep = rep;
+    }
     return k;
 }
 
@@ -179,4 +186,5 @@ struct P1Args {
                                // 100-MHz ticks late, so co-resident workgroups alternate HBM and matrix phases
     int stagger_blocks;        // workgroups per layer (= CUs) and first-generation size
     int stagger_first;
+    int debug;                 // timing experiments only (DVQ_P1_DEBUG): 1 no second-row store of coarse tokens, 2 no coarse stores, 4 no fine stores
 };

@@ -171,13 +171,15 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // Only two waves share a SIMD, so the code loop is written for per-wave matrix-core duty: seeds
 // read before the barrier, A fragments rotated through four register sets one k-step group ahead.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+// SEL: the router select fused in (DvqRouted with dense = 1): token n is output position n, its source vector
+// sits in the encoder branch that won its cell (per-lane source pointer and channel stride); outputs as dense.
+template <int D, bool SEL>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv)
 {
     constexpr int NW = 4;
     constexpr int S16 = D / 16;
@@ -226,7 +228,19 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         return ((size_t)bimg * D + 8 * h) * HW + hw;
     };
     float zf[S16][8];
-    {
+    if (SEL) {
+        const int t0 = (tile_id * NW + wave) * 32;                       // wave-uniform
+        const int b0 = (t0 < N) ? (int)(t0 / HW) : 0;
+        const DvqTok tk = dvq_routed_lookup(rv, (n >= 0) ? n : (int)(N - 1), b0);
+        const float *zp = tk.src + (size_t)8 * h * tk.stride;
+        const size_t st = (size_t)tk.stride;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zf[s][j] = zp[(size_t)(16 * s + j) * st];
+        __builtin_amdgcn_s_setprio(0);
+    } else {
         const float *zp = z + token_base();
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -1162,7 +1176,7 @@ int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, in
 int dvq_pass1_tokens_per_block(int variant);
 int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
                               long long *indices, float *cmask, long long *gate_out, int *imgcount,
-                              unsigned short *tok, int *imgstart, int *ticket, hipStream_t st);
+                              unsigned short *tok, int *imgstart, int *ticket, int dense, hipStream_t st);
 
 // Which pass-1 kernel: DVQ_PASS1_VARIANT = -1 legacy (fp32 copy of z in registers, 2 waves / SIMD; the wide
 // form for large codebooks), 0..3 the low-register forms of vq_assign_routed.hip.  The routed op always
@@ -1179,6 +1193,9 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 #endif
 #ifndef DVQ_ROUTED_DEFAULT
 #define DVQ_ROUTED_DEFAULT 0
+#endif
+#ifndef DVQ_ROUTED_DEDUP_DEFAULT
+#define DVQ_ROUTED_DEDUP_DEFAULT 1
 #endif
 #ifndef DVQ_STAGGER_DEFAULT_US
 #define DVQ_STAGGER_DEFAULT_US 0
@@ -1227,13 +1244,22 @@ static FilterWs carve_ws(void *ws_extra, long N, int D)
 template <int D>
 static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                                const float *mask, int HW, int K, long N, float *zq, long long *codes,
-                               double *partials, const FilterWs &w, bool force_wide, hipStream_t st)
+                               double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
+                               hipStream_t st)
 {
-    static unsigned long long done = 0;
+    static unsigned long long done = 0, done_sel = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
-    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D>, (int)shmem1, &done);
-    if (rc) return rc;
     const int nb1 = (int)((N + 127) / 128);
+    if (rv != nullptr) {                                     // select fused in (rv->dense): legacy form only
+        int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, true>, (int)shmem1, &done_sel);
+        if (rc) return rc;
+        hipLaunchKernelGGL((vq_assign_filter_kernel<D, true>), dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                           E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                           w.cap / DVQ_QSHARDS, *rv);
+        return (int)hipGetLastError();
+    }
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, false>, (int)shmem1, &done);
+    if (rc) return rc;
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
                                                              // with two 256-token workgroups: two blocks per wave
@@ -1246,8 +1272,9 @@ static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(vq_assign_filter_kernel<D>, dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                       E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records, w.cap / DVQ_QSHARDS);
+    hipLaunchKernelGGL((vq_assign_filter_kernel<D, false>), dim3(nb1), dim3(256), shmem1, st, z, img, meta,
+                       E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records, w.cap / DVQ_QSHARDS,
+                       DvqRouted{});
     return (int)hipGetLastError();
 }
 
@@ -1296,14 +1323,17 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
         hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
                            resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
     }
-    const int variant = routed ? routed_variant() : ((force_wide || D != 256) ? -1 : dense_variant());
+    // routed + de-duplicated: always a low-register form; routed without de-duplication (rv->dense): the legacy
+    // form with the select fused in unless DVQ_ROUTED_VARIANT picks a low-register one explicitly
+    int variant = routed ? routed_variant() : ((force_wide || D != 256) ? -1 : dense_variant());
+    if (routed && rv->dense && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) == 0) variant = -1;
     int rc, np1;
     if (variant < 0) {
         np1 = (int)((N + 127) / 128);
         switch (D) {
-        case 64:  rc = launch_legacy_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
-        case 128: rc = launch_legacy_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
-        case 256: rc = launch_legacy_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, st); break;
+        case 64:  rc = launch_legacy_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+        case 128: rc = launch_legacy_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+        case 256: rc = launch_legacy_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
         default:  return -1000;
         }
     } else {
@@ -1327,6 +1357,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
             a.stagger_ticks = stag * 100;
             a.stagger_blocks = ncu;
             a.stagger_first = ncu * per_cu;
+            a.debug = env_int("DVQ_P1_DEBUG", 0, 0, 7);
         }
         rc = dvq_launch_pass1_lowreg(D, routed, variant, a, np1, st);
     }
@@ -1378,12 +1409,15 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     unsigned short *tok = (unsigned short *)((char *)imgstart + align256((size_t)(B + 1) * sizeof(int)));
     hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
                        resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
+    // DVQ_ROUTED_DEDUP = 1 (default DVQ_ROUTED_DEDUP_DEFAULT): score unique tokens only; 0: one token per output
+    // position (the select fused into a dense assign)
+    const int dense = env_int("DVQ_ROUTED_DEDUP", DVQ_ROUTED_DEDUP_DEFAULT, 0, 1) ? 0 : 1;
     int rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
-                                       imgstart, w.counters + 5, st);
+                                       imgstart, w.counters + 5, dense, st);
     if (rc) return rc;
     DvqRouted rv{};
     rv.G = G; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = Wout; rv.HWout = HWout;
-    rv.imgstart = imgstart; rv.tok = tok;
+    rv.imgstart = imgstart; rv.tok = tok; rv.dense = dense;
     if (G == 2) {
         rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
         rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1;

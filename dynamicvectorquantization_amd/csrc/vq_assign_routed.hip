@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
     const void *__restrict__ gate, float thr, int B, int hc, int wc,
     long long *__restrict__ indices, float *__restrict__ cmask, long long *__restrict__ gate_out,
     int *__restrict__ imgcount, unsigned short *__restrict__ tok, int *__restrict__ imgstart,
-    int *__restrict__ ticket)
+    int *__restrict__ ticket, int dense)
 {
     constexpr int SC = (G == 2) ? 2 : 4;
     constexpr int MAXH = SC * DVQ_ROUTE_MAX_CELLS;             // hc <= ncell
@@ -92,6 +92,22 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
             m[j] = (G == 2) ? (g == 0 ? 0.25f : 1.0f) : (g == 0 ? 0.0625f : (g == 1 ? 0.25f : 1.0f));
         }
         *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
+    }
+    if (dense) {
+        // one token per output position, in plain row-major order: entry = (type, position of the source
+        // element inside the cell in the type's own grid, cell)
+        unsigned short *td = tok + (size_t)b * HW;
+        for (int i = tid; i < HW; i += 256) {
+            const int y = i / W, x = i - y * W;
+            const int cell = (y / SC) * wc + x / SC;
+            const int g = grain[cell], rep = SC / sub_of(g);
+            td[i] = dvq_tok_pack(g, (y % SC) / rep, (x % SC) / rep, cell);
+        }
+        if (tid == 0) {
+            imgstart[b] = b * HW;
+            if (b == (int)gridDim.x - 1) imgstart[B] = B * HW;
+        }
+        return;
     }
     // tokens per output row (by top-left position), then an exclusive scan over the H rows
     const int per = (H + 255) / 256;
@@ -577,9 +593,9 @@ int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, in
 
 int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
                               long long *indices, float *cmask, long long *gate_out, int *imgcount,
-                              unsigned short *tok, int *imgstart, int *ticket, hipStream_t st)
+                              unsigned short *tok, int *imgstart, int *ticket, int dense, hipStream_t st)
 {
-#define DVQ_PRE(GG, MM) hipLaunchKernelGGL((routed_prepass_kernel<GG, MM>), dim3(B), dim3(256), 0, st, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok, imgstart, ticket)
+#define DVQ_PRE(GG, MM) hipLaunchKernelGGL((routed_prepass_kernel<GG, MM>), dim3(B), dim3(256), 0, st, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok, imgstart, ticket, dense)
     if (G == 2 && gate_mode == 2) DVQ_PRE(2, 2);
     else if (G == 2 && gate_mode == 1) DVQ_PRE(2, 1);
     else if (G == 2) DVQ_PRE(2, 0);

@@ -28,12 +28,23 @@ def _check_dual(r, o_sel, o, B, beta=0.25, oracle_mod=None):
         assert C.loss_close(float(r["loss"][1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], beta)), "loss"
 
 
-@pytest.fixture(params=[0, 1, 2, 3])
+# routed-op forms: ("dedup", v) = unique tokens only, low-register pass-1 variant v; ("fused", -1) = one token per
+# output position with the select fused into the legacy pass-1 kernel; ("fused", v) = the same on a low-register form
+FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1)]
+
+
+@pytest.fixture(params=FORMS, ids=["%s%d" % f for f in FORMS])
 def variant(request):
+    import os
     from dynamicvectorquantization_amd import _lib
-    assert _lib.lib.dvq_set_pass1_variant(-2, request.param) == 0
-    yield request.param
+    kind, v = request.param
+    assert _lib.lib.dvq_set_pass1_variant(-2, max(v, 0)) == 0
+    os.environ["DVQ_ROUTED_DEDUP"] = "1" if kind == "dedup" else "0"
+    os.environ["DVQ_ROUTED_DENSE_LOWREG"] = "1" if (kind == "fused" and v >= 0) else "0"
+    yield 0 if request.param == FORMS[0] else 1 + FORMS.index(request.param)
     _lib.lib.dvq_set_pass1_variant(-2, 0)
+    os.environ.pop("DVQ_ROUTED_DEDUP", None)
+    os.environ.pop("DVQ_ROUTED_DENSE_LOWREG", None)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -43,8 +54,8 @@ def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode, variant):
     int64 gate, f32 logits (ties / NaN) and the fused entropy router"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
-    if mode == 0 and variant != 0:
-        pytest.skip("the exact mode does not use pass 1")
+    if mode == 0 and variant not in (0, 5):
+        pytest.skip("the exact mode does not use pass 1 (run once per token layout)")
     B, hc, wc = shape
     K, D = 333, 256
     E = synth.codebook_trained(K, D, seed=500 + hc)
@@ -84,8 +95,8 @@ def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode, variant):
 def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_triple
-    if mode == 0 and variant != 0:
-        pytest.skip("the exact mode does not use pass 1")
+    if mode == 0 and variant not in (0, 5):
+        pytest.skip("the exact mode does not use pass 1 (run once per token layout)")
     B, hc, wc = shape
     K, D = 1024, 256
     E = synth.codebook_trained(K, D)
@@ -105,11 +116,13 @@ def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
         _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
 
 
-def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod):
+@pytest.mark.parametrize("dedup", ["1", "0"])
+def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkeypatch):
     """NaN / Inf / huge tokens in every branch go through the exact list (routed ids); a codebook with widely
     mixed norms overflows the resolver queue; D = 64 / 128"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
+    monkeypatch.setenv("DVQ_ROUTED_DEDUP", dedup)
     t = _t(dev)
     B, hc, wc, K, D = 5, 4, 4, 200, 256
     E = synth.codebook_trained(K, D, seed=71)
@@ -140,7 +153,7 @@ def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod):
     r1 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p1, gate=t(g2), mode=_lib.MODE_FILTER)
     r0 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p0, gate=t(g2), mode=_lib.MODE_EXACT)
     queued, listed = p1.fallback_count()
-    assert queued >= 4096 and listed > 500, (queued, listed)
+    assert queued >= 4096 and listed > 500, (queued, listed)      # 64 shards full, the rest through the exact list
     assert torch.equal(r0["codes"], r1["codes"]) and torch.equal(r0["zq"], r1["zq"])
     assert abs(float(r0["loss"][1]) - float(r1["loss"][1])) <= 1e-6 * abs(float(r0["loss"][1]))
     o_sel = oracle_mod.route_select_dual(g2, hc2, hf2)
