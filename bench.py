@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
     ap.add_argument("--path", choices=["routed", "select"], default="routed",
-                    help="routed: one assign op straight from the encoder branches (unique tokens, no h_dual); "
-                         "select: route-select kernel writing h_dual, then the dense assign (round-1 path)")
+                    help="routed: ONE assign op straight from the encoder branches (the router select is fused into "
+                         "pass 1, h_dual is never written); select: route-select kernel writing h_dual, then the "
+                         "dense assign (round-1 path)")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
@@ -292,7 +293,7 @@ class WeakDual:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256>" if self.a.path == "select" else "vq_routed_pass1_kernel<256>"
+        return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
 
     def parity(self):
         """the step's outputs, still in HBM, against the oracle on ALL images of this rank"""
@@ -398,7 +399,7 @@ class StrongTriple:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256>" if self.a.path == "select" else "vq_routed_pass1_kernel<256>"
+        return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
 
     def parity(self):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
@@ -527,12 +528,10 @@ def run_rank(a):
                  "kernel_ms": dom_ms, "kernel_ms_note": "HIP events around the pass-1 launch (a 4-us counter-zero / "
                  "token-list kernel precedes it in the same op and is inside the bracket)",
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
-                 "algorithmic_note": "DENSE count (SURVEY.md 8d): every one of the B*H*W positions read + written once; "
-                                     "the routed path scores unique tokens only, see unique_tokens",
+                 "algorithmic_note": "SURVEY.md 8d count of the VQ forward: every one of the B*H*W positions read once "
+                                     "(1 KiB), z_q written once (1 KiB), int64 code, mask",
                  "hbm_gbps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_tflops_equiv": tfs,
                  "whole_op_ms": op_ms, "whole_op_hbm_gbps": alg_bytes / (op_ms * 1e-3) / 1e9})
-    if hasattr(wl, "unique_tokens"):
-        roof["unique_tokens"] = wl.unique_tokens()
     if rank == 0:
         out = {
             "metric": "images encoded/sec (VQ hot path: gate + routing + VQ assign), 256x256 inputs, K=%d" % K,

@@ -108,8 +108,50 @@ struct DvqRouted {
     const int *imgstart;      // [B + 1]
     const unsigned short *tok;   // [B][HWout]
     int dense;                // 1: one token per OUTPUT POSITION (no de-duplication; rank = position, rep = 1):
-                              //    the select fused into a dense assign, every wave owns whole output rows
+                              //    the select fused into a dense assign, every wave owns whole output rows.
+                              //    No tables: the grain of a position's cell comes from `indices` (written by the
+                              //    prepass or by pass 1 itself), or straight from the gate (dvq_gate_argmax)
+    const long long *indices; // [B, hc, wc] grain index per coarse cell (dense form)
+    const void *gate;         // router output the grain is derived from (pass 1 of the dense form)
+    int gate_mode;            // 0 f32 logits [.., G], 1 int64 [.., G], 2 f32 entropy map + thr
+    float thr;
+    long long *indices_out;   // outputs the dense pass 1 writes itself (null: the prepass wrote them)
+    float *cmask_out;
+    long long *gate_out;
 };
+
+// argmax over the G gate values of one cell with torch semantics (first maximal value wins, NaN counts as the
+// maximum); mode 2: entropy > thr (NaN compares false -> 0)
+__device__ __forceinline__ int dvq_gate_argmax(const void *gate, int mode, int G, size_t cell, float thr)
+{
+    if (mode == 2) return (((const float *)gate)[cell] > thr) ? 1 : 0;
+    int bi = 0;
+    if (mode == 1) {
+        const long long *g = (const long long *)gate + cell * G;
+        long long best = g[0];
+        for (int i = 1; i < G; ++i) {
+            const long long v = g[i];
+            if (v > best) { best = v; bi = i; }
+        }
+    } else {
+        const float *g = (const float *)gate + cell * G;
+        float best = g[0];
+        for (int i = 1; i < G; ++i) {
+            const float v = g[i];
+            if ((v > best) || (v != v && best == best)) { best = v; bi = i; }
+        }
+    }
+    return bi;
+}
+
+// dense form: source of output position (y, x) of image b whose cell has grain g
+__device__ __forceinline__ const float *dvq_dense_source(const DvqRouted &rv, int b, int y, int x, int g, int &stride)
+{
+    const int sub = rv.sub[g], rep = rv.rep[g];
+    const int gwid = rv.wc * sub, plane = rv.hc * sub * gwid;
+    stride = plane;
+    return rv.src[g] + (size_t)b * rv.D * plane + (size_t)(y / rep) * gwid + x / rep;
+}
 
 struct DvqTok {
     const float *src;   // channel 0 of the token
@@ -142,6 +184,19 @@ __device__ __forceinline__ int dvq_routed_image_search(const DvqRouted &rv, int 
 __device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int t, int b_hint)
 {
     DvqTok k;
+    if (rv.dense) {                                              // rank = output position
+        const long total = (long)rv.B * rv.HWout;
+        k.valid = t >= 0 && t < total;
+        const int tt = k.valid ? t : 0;
+        const int b = tt / rv.HWout, pos = tt - b * rv.HWout;
+        const int y = pos / rv.Wout, x = pos - y * rv.Wout;
+        const int SC = rv.sub[rv.G - 1];
+        const int g = (int)rv.indices[(size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + x / SC];
+        k.src = dvq_dense_source(rv, b, y, x, g, k.stride);
+        k.n = tt;
+        k.rep = 1;
+        return k;
+    }
     const int total = rv.imgstart[rv.B];
     k.valid = t >= 0 && t < total;
     const int tt = k.valid ? t : 0;
@@ -154,14 +209,15 @@ __device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int t, 
     const int gwid = rv.wc * sub, plane = rv.hc * sub * gwid;
     k.src = rv.src[g] + (size_t)b * rv.D * plane + (size_t)gy * gwid + gx;
     k.stride = plane;
-    if (rv.dense) {
-        k.n = (long)b * rv.HWout + (tt - rv.imgstart[b]);
-        k.rep = 1;
-    } else {
-        k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
-        k.rep = rep;
-    }
+    k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
+    k.rep = rep;
     return k;
+}
+
+// number of tokens of the batch
+__device__ __forceinline__ int dvq_routed_total(const DvqRouted &rv)
+{
+    return rv.dense ? rv.B * rv.HWout : rv.imgstart[rv.B];
 }
 
 // arguments of the low-register pass-1 kernel (vq_assign_routed.hip: vq_pass1_kernel)

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *zp;                                   // channel h of the token; channel k = 2s + h at zp + 2s*stride
     int stride, rep = 1, Wout = 0, HWo = HW;
     if (ROUTED) {
-        const int total = rv.imgstart[rv.B];
+        const int total = dvq_routed_total(rv);
         const int tid_ = (nn >= 0 && nn < total) ? (int)nn : 0;
         const DvqTok tk = dvq_routed_lookup(rv, (nn >= 0 && nn < total) ? (int)nn : -1,
-                                            total > 0 ? dvq_routed_image_search(rv, tid_) : 0);   // token id -> branch tensor address
+                                            (total > 0 && !rv.dense) ? dvq_routed_image_search(rv, tid_) : 0);   // token id -> branch tensor address
         valid = valid && tk.valid;
         stride = tk.stride;
         zp = tk.src + (size_t)h * stride;

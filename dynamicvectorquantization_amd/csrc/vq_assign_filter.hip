@@ -228,12 +228,32 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         return ((size_t)bimg * D + 8 * h) * HW + hw;
     };
     float zf[S16][8];
+    float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell
     if (SEL) {
-        const int t0 = (tile_id * NW + wave) * 32;                       // wave-uniform
-        const int b0 = (t0 < N) ? (int)(t0 / HW) : 0;
-        const DvqTok tk = dvq_routed_lookup(rv, (n >= 0) ? n : (int)(N - 1), b0);
-        const float *zp = tk.src + (size_t)8 * h * tk.stride;
-        const size_t st = (size_t)tk.stride;
+        // the router select, fused in: grain of this position's cell straight from the gate, source = the branch
+        // that won the cell; indices / codebook_mask / the int64 gate are written here as by-products
+        const int nn = (n >= 0) ? n : (int)(N - 1);
+        const int b = nn / HW, pos = nn - b * HW;
+        const int y = pos / rv.Wout, x = pos - y * rv.Wout;
+        const int SC = rv.sub[rv.G - 1];
+        const size_t cell = (size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + x / SC;
+        const int g = dvq_gate_argmax(rv.gate, rv.gate_mode, rv.G, cell, rv.thr);
+        const int rep_g = rv.rep[g];
+        sel_mask = 1.0f / (float)(rep_g * rep_g);            // 1, 0.25, 0.0625: exact
+        if (n >= 0 && h == 0 && rv.cmask_out != nullptr) {
+            rv.cmask_out[n] = sel_mask;
+            if (y % SC == 0 && x % SC == 0) {
+                rv.indices_out[cell] = g;
+                if (rv.gate_mode == 2 && rv.gate_out != nullptr) {
+                    const float e = ((const float *)rv.gate)[cell];
+                    longlong2 gg; gg.x = (e <= rv.thr) ? 1 : 0; gg.y = (e > rv.thr) ? 1 : 0;
+                    *(longlong2 *)(rv.gate_out + 2 * cell) = gg;
+                }
+            }
+        }
+        int stride_l;
+        const float *zp = dvq_dense_source(rv, b, y, x, g, stride_l) + (size_t)8 * h * stride_l;
+        const size_t st = (size_t)stride_l;
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int s = 0; s < S16; ++s)
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if (h == 0) codes[n] = (long long)code;
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
-            const float m = (mask != nullptr) ? mask[n] : 1.0f;
+            const float m = SEL ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
             constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
             // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
             // inside the loop on the per-lane pointer every one of the 128 stores became its own
@@ -1195,7 +1215,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 #define DVQ_ROUTED_DEFAULT 0
 #endif
 #ifndef DVQ_ROUTED_DEDUP_DEFAULT
-#define DVQ_ROUTED_DEDUP_DEFAULT 1
+#define DVQ_ROUTED_DEDUP_DEFAULT 0
 #endif
 #ifndef DVQ_STAGGER_DEFAULT_US
 #define DVQ_STAGGER_DEFAULT_US 0
@@ -1409,15 +1429,23 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     unsigned short *tok = (unsigned short *)((char *)imgstart + align256((size_t)(B + 1) * sizeof(int)));
     hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
                        resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-    // DVQ_ROUTED_DEDUP = 1 (default DVQ_ROUTED_DEDUP_DEFAULT): score unique tokens only; 0: one token per output
-    // position (the select fused into a dense assign)
+    // DVQ_ROUTED_DEDUP = 1: score unique tokens only (token tables from the prepass, low-register pass 1);
+    // 0 (default DVQ_ROUTED_DEDUP_DEFAULT): one token per output position -- the select fused into the legacy
+    // pass-1 kernel, which derives the grain from the gate itself: no prepass, no tables
     const int dense = env_int("DVQ_ROUTED_DEDUP", DVQ_ROUTED_DEDUP_DEFAULT, 0, 1) ? 0 : 1;
-    int rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
+    const bool lowreg_dense = dense && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) != 0;
+    const bool need_prepass = !dense || exact || lowreg_dense;
+    int rc = 0;
+    if (need_prepass) {
+        rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
                                        imgstart, w.counters + 5, dense, st);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     DvqRouted rv{};
     rv.G = G; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = Wout; rv.HWout = HWout;
     rv.imgstart = imgstart; rv.tok = tok; rv.dense = dense;
+    rv.indices = indices; rv.gate = gate; rv.gate_mode = gate_mode; rv.thr = thr;
+    if (!need_prepass) { rv.indices_out = indices; rv.cmask_out = cmask; rv.gate_out = gate_out; }
     if (G == 2) {
         rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
         rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1;

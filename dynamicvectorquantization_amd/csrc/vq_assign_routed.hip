@@ -93,22 +93,7 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
         }
         *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
     }
-    if (dense) {
-        // one token per output position, in plain row-major order: entry = (type, position of the source
-        // element inside the cell in the type's own grid, cell)
-        unsigned short *td = tok + (size_t)b * HW;
-        for (int i = tid; i < HW; i += 256) {
-            const int y = i / W, x = i - y * W;
-            const int cell = (y / SC) * wc + x / SC;
-            const int g = grain[cell], rep = SC / sub_of(g);
-            td[i] = dvq_tok_pack(g, (y % SC) / rep, (x % SC) / rep, cell);
-        }
-        if (tid == 0) {
-            imgstart[b] = b * HW;
-            if (b == (int)gridDim.x - 1) imgstart[B] = B * HW;
-        }
-        return;
-    }
+    if (dense) return;                                        // the dense form needs no token table
     // tokens per output row (by top-left position), then an exclusive scan over the H rows
     const int per = (H + 255) / 256;
     int mine = 0;
@@ -223,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
     int nblk = (int)gridDim.x;
     int total = 0;
     if (ROUTED) {
-        total = a.rv.imgstart[a.rv.B];
+        total = dvq_routed_total(a.rv);
         const int nslots = (total + 31) / 32;
         nblk = (nslots + NW - 1) / NW;
         if ((int)blockIdx.x >= nblk) {                       // the grid is sized for the all-fine worst case
@@ -265,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void vq_pass1_kernel(const P1Args a)
     int tokid;                                               // what the exact list carries for it
     if (ROUTED) {
         const int t0 = (tile_id * NW + wave) * 32;           // wave-uniform: first token of the slot
-        const int b0 = (t0 < total) ? dvq_routed_image_search(a.rv, t0) : 0;
+        const int b0 = (t0 < total && !a.rv.dense) ? dvq_routed_image_search(a.rv, t0) : 0;
         tokid = t0 + c;
         const DvqTok tk = dvq_routed_lookup(a.rv, tokid, b0);
         stride = tk.stride;
