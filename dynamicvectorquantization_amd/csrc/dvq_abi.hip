@@ -4,7 +4,7 @@
 #include <stdio.h>
 
 #include "../../include/dvq.h"
-#include "dvq_common.h"
+#include "dvq_filter.h"
 
 #define DVQ_VERSION 200   // 0.2.0
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
@@ -22,7 +22,6 @@ void dvq_set_error(const char *fmt, ...)
 // launchers implemented next to their kernels
 int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st);
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st);
-struct DvqRouted;
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                      const DvqRouted *rv, hipStream_t st);
@@ -66,6 +65,10 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
                            const float *W1, const float *b1, const float *W2, const float *b2,
                            int Hid, int act, float *gate, void *ws, hipStream_t st);
 
+size_t dvq_qconv_prep_bytes_impl(int D);
+int dvq_launch_qconv_prep(const float *Wt, const float *bias, int D, void *prep, hipStream_t st);
+int dvq_launch_qconv(const float *x, const DvqRouted *rv, const void *prep, int D, int HW, long N, float *hout,
+                     hipStream_t st);
 int dvq_choose_pass1_variant(int dense, int routed);
 int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
                                    float *thr2W, float *xn, float *scale_b_out, hipStream_t st);
@@ -446,6 +449,57 @@ int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *
                                               (const long long *)coarse_position, (const long long *)fine_position,
                                               B, Lc, Lf, hc, wc, coarse_position_eos, fine_position_eos,
                                               (long long *)target, (hipStream_t)stream), "permute_backward");
+}
+
+size_t dvq_qconv_prep_bytes(int D) { return dim_ok(D) ? dvq_qconv_prep_bytes_impl(D) : 0; }
+
+int dvq_qconv_prepare_f32(const float *weight, const float *bias, int D, void *prep, size_t prep_bytes, void *stream)
+{
+    if (!weight || !prep) { dvq_set_error("dvq_qconv_prepare_f32: null pointer"); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_prepare_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (prep_bytes < dvq_qconv_prep_bytes(D)) { dvq_set_error("dvq_qconv_prepare_f32: prep buffer %zu < %zu bytes", prep_bytes, dvq_qconv_prep_bytes(D)); return DVQ_EWORKSPACE; }
+    if (((uintptr_t)prep & 255) != 0) { dvq_set_error("dvq_qconv_prepare_f32: prep must be 256-byte aligned"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_qconv_prep(weight, bias, D, prep, (hipStream_t)stream), "qconv_prep");
+}
+
+int dvq_qconv_f32(const float *x, const void *prep, int B, int D, int HW, float *h, void *stream)
+{
+    if (!x || !prep || !h) { dvq_set_error("dvq_qconv_f32: null pointer"); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0) { dvq_set_error("dvq_qconv_f32: sizes must be positive"); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if ((long)B * HW >= (1L << 31)) { dvq_set_error("dvq_qconv_f32: tensor too large"); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_qconv(x, nullptr, prep, D, HW, (long)B * HW, h, (hipStream_t)stream), "qconv");
+}
+
+int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, float threshold,
+                         const float *h_coarse, const float *h_median, const float *h_fine, const void *prep,
+                         int B, int D, int hc, int wc, float *h, int64_t *indices, float *cmask, int64_t *gate_out,
+                         void *stream)
+{
+    const char *fn = "dvq_qconv_select_f32";
+    if (num_branches != 2 && num_branches != 3) { dvq_set_error("%s: num_branches=%d (2 or 3)", fn, num_branches); return DVQ_EINVAL; }
+    if (!gate || !h_coarse || !h_fine || !prep || !h || !indices || !cmask || (num_branches == 3 && !h_median)) {
+        dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL;
+    }
+    if (B <= 0 || hc <= 0 || wc <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    if (gate_kind != DVQ_GATE_F32 && gate_kind != DVQ_GATE_I64 && gate_kind != DVQ_GATE_ENTROPY) { dvq_set_error("%s: gate_kind %d", fn, gate_kind); return DVQ_EINVAL; }
+    if (gate_kind == DVQ_GATE_ENTROPY && num_branches != 2) { dvq_set_error("%s: the entropy gate is a dual-granularity router", fn); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    const int SC = (num_branches == 2) ? 2 : 4;
+    const long N = (long)B * SC * hc * SC * wc;
+    if (N >= (1L << 31)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
+    DvqRouted rv{};
+    rv.G = num_branches; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = SC * wc; rv.HWout = SC * hc * SC * wc;
+    rv.dense = 1; rv.gate = gate; rv.gate_mode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
+    rv.thr = threshold; rv.indices = (const long long *)indices;
+    rv.indices_out = (long long *)indices; rv.cmask_out = cmask; rv.gate_out = (long long *)gate_out;
+    if (num_branches == 2) {
+        rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1; rv.rep[0] = 2; rv.rep[1] = 1; rv.rep[2] = 1;
+    } else {
+        rv.src[0] = h_coarse; rv.src[1] = h_median; rv.src[2] = h_fine;
+        rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 4; rv.rep[0] = 4; rv.rep[1] = 2; rv.rep[2] = 1;
+    }
+    return hip_rc(dvq_launch_qconv(nullptr, &rv, prep, D, rv.HWout, N, h, (hipStream_t)stream), fn);
 }
 
 int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,

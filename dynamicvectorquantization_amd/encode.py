@@ -17,7 +17,7 @@ asynchronously under the next batch's kernels.
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, qconv
 from .quantize import VectorQuantize2, vq_assign_routed_dual, vq_assign_routed_triple
 from .router import DualGrainFixedEntropyRouter, route_select_dual, route_select_dual_entropy, route_select_triple
 
@@ -34,12 +34,32 @@ def _can_route(quantize, quant_conv, *feats):
     return all(t.is_cuda and t.dtype == torch.float32 for t in feats) and feats[0].shape[2] * feats[0].shape[3] <= 1024
 
 
+def _can_fuse_conv(quantize, quant_conv, *feats):
+    """select + 1x1 quant_conv as one kernel (qconv.quant_conv_select): inference on fp32 GPU feature maps"""
+    if quant_conv is None or not qconv.usable(quant_conv) or quant_conv.in_channels != feats[0].shape[1]:
+        return False
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in feats) or
+                                    any(p.requires_grad for p in quant_conv.parameters())):
+        return False
+    return all(t.is_cuda and t.dtype == torch.float32 for t in feats)
+
+
 def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0):
     """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode
-    (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).  Without a quant_conv (and without
-    autograd) gate + routing tail + quantizer run as ONE routed op on the unique tokens; otherwise as
-    route select -> quant_conv -> dense assign."""
+    (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).  Inference paths (no autograd):
+      * no quant_conv: gate + routing tail + quantizer as ONE routed op (the select fused into the assign);
+      * a 1x1 quant_conv: select + conv as one kernel (no h_dual), then the dense assign;
+    otherwise route select -> quant_conv -> dense assign as differentiable pieces."""
     fixed = isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda
+    if _can_fuse_conv(quantize, quant_conv, h_coarse, h_fine):
+        if fixed:
+            sel = qconv.quant_conv_select(quant_conv, h_coarse, h_fine, entropy=entropy,
+                                          threshold=router.fine_grain_threshold)
+        else:
+            sel = qconv.quant_conv_select(quant_conv, h_coarse, h_fine,
+                                          gate=router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy))
+        quant, emb_loss, info = quantize(x=sel["h"], temp=temp, codebook_mask=sel["codebook_mask"])
+        return quant, emb_loss, info, sel["indices"], sel["gate"].permute(0, 3, 1, 2)
     if _can_route(quantize, quant_conv, h_coarse, h_fine):
         cb = quantize.codebook
         kw = dict(beta=quantize.beta, mode=quantize.assign_mode)
@@ -65,6 +85,10 @@ def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=Non
 def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None, temp=0.0):
     """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77)."""
     gate = router(h_fine=h_fine, h_median=h_median, h_coarse=h_coarse, entropy=None)
+    if _can_fuse_conv(quantize, quant_conv, h_coarse, h_median, h_fine):
+        sel = qconv.quant_conv_select(quant_conv, h_coarse, h_fine, h_median=h_median, gate=gate)
+        quant, emb_loss, info = quantize(x=sel["h"], temp=temp, codebook_mask=sel["codebook_mask"])
+        return quant, emb_loss, info, sel["indices"], gate.permute(0, 3, 1, 2)
     if _can_route(quantize, quant_conv, h_coarse, h_median, h_fine):
         cb = quantize.codebook
         r = vq_assign_routed_triple(h_coarse, h_median, h_fine, cb.codes, cb._prep, gate, beta=quantize.beta,
@@ -79,9 +103,9 @@ def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None,
 
 
 def encode_fixed(quantize, h, quant_conv=None):
-    """-> (quant, emb_loss, info) as VQModel.encode (fixed granularity)."""
+    """-> (quant, emb_loss, info) as VQModel.encode (fixed granularity, models/stage1/vqgan.py:68-72)."""
     if quant_conv is not None:
-        h = quant_conv(h)
+        h = qconv.quant_conv(quant_conv, h) if _can_fuse_conv(quantize, quant_conv, h) else quant_conv(h)
     return quantize(h)
 
 

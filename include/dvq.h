@@ -165,6 +165,24 @@ int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
                                     float *zq, int64_t *codes, float *loss,
                                     int64_t *indices, float *cmask,
                                     void *ws, size_t ws_bytes, int mode, void *stream);
+/*
+ * The 1x1 quant_conv of the stage-1 models (nn.Conv2d(D, D, 1): dqvae_dual_feat.py:34,66, dqvae_triple_feat.py:39,75,
+ * vqgan.py:42,70) as a GEMM on the fp16 matrix cores at fp32 grade (both operands split hi + lo, three MFMAs,
+ * fp32 accumulation; 2^-22 products): equal to the reference's conv within 1e-5 relative to |x||w|, not bit for bit.
+ *   prepare       weight [D, D] (= conv.weight[:, :, 0, 0], row = output channel), bias nullable [D]; run once per weight
+ *   dvq_qconv_f32          x [B, D, HW] -> h [B, D, HW]
+ *   dvq_qconv_select_f32   the router select fused in (replaces dvq_route_select_* followed by the conv: h_dual / h_triple
+ *                          is never written): gate as for the routed assign, h_coarse / h_median / h_fine the encoder
+ *                          branches; outputs h [B, D, S hc, S wc] plus the select's by-products indices, cmask, gate_out
+ */
+size_t dvq_qconv_prep_bytes(int D);
+int dvq_qconv_prepare_f32(const float *weight, const float *bias, int D, void *prep, size_t prep_bytes, void *stream);
+int dvq_qconv_f32(const float *x, const void *prep, int B, int D, int HW, float *h, void *stream);
+int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, float threshold,
+                         const float *h_coarse, const float *h_median, const float *h_fine, const void *prep,
+                         int B, int D, int hc, int wc, float *h, int64_t *indices, float *cmask, int64_t *gate_out,
+                         void *stream);
+
 /* Audit aid (tools/bound_audit.py, tests/test_bound_audit.py): the pass-1 score arithmetic of DVQ_MODE_FILTER on
  * n tokens given as rows [n, D] -- every fp16-MFMA score G_j ~ -2^(b-1) (d_j - xn) as pass 1 sees it (index bits
  * packed into the low mantissa bits), the per-token decision threshold 2W, the exact norm xn and the codebook scale
