@@ -35,6 +35,17 @@ with torch.no_grad():
     out["cfg2_dual_feature_B64_ms"] = timeit(lambda: encode_dual(r, vq, hf, hc))
     out["cfg2_router_gate_fused_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc))
 out["cfg2_router_gate_torch_ops_ms"] = timeit(lambda: r(h_fine=hf, h_coarse=hc).detach())   # grad enabled -> torch ops
+# configs[1] WITH the model's 1x1 quant_conv between select and quantizer (dqvae_dual_feat.py:66): the fused
+# select + conv kernel (no h_dual) then the dense assign, vs route select + torch conv (MIOpen / hipBLASLt) + dense assign
+qc = torch.nn.Conv2d(256, 256, 1).to(dev).eval()
+with torch.no_grad():
+    out["cfg2_dual_feature_B64_with_quant_conv_fused_ms"] = timeit(lambda: encode_dual(r, vq, hf, hc, quant_conv=qc))
+    out["cfg2_dual_feature_B64_with_quant_conv_torch_ms"] = timeit(lambda: encode_dual(r, vq, hf, hc, quant_conv=torch.nn.Sequential(qc)))
+    from dynamicvectorquantization_amd.qconv import quant_conv, quant_conv_select
+    gate_ = r(h_fine=hf, h_coarse=hc)
+    out["qconv_select_kernel_B64_ms"] = timeit(lambda: quant_conv_select(qc, hc, hf, gate=gate_))
+    out["qconv_dense_kernel_B64_ms"] = timeit(lambda: quant_conv(qc, hf))
+    out["torch_conv1x1_B64_ms"] = timeit(lambda: qc(hf))
 # configs[3] per-rank share: triple F32/16/8, B=128 per GPU
 r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
 hf, hm, hc = (t(synth.z_tokens(E, 128, 32, 32, 2104)), t(synth.z_tokens(E, 128, 16, 16, 2114)),
@@ -46,17 +57,16 @@ out["cfg4_router_gate_torch_ops_ms"] = timeit(lambda: r3(h_fine=hf, h_median=hm,
 # configs[4]: large-codebook stress K=16384, B=512 (exact fp32-MFMA path vs fp16 filter path)
 E16 = synth.codebook_trained(16384, 256)
 Et = t(E16)
-zb = t(synth.z_tokens(E16, 256, 32, 32, 2005))          # half of configs[4]'s B = 512 (fills the GPU twice over)
+zb = t(synth.z_tokens(E16, 64, 32, 32, 2005)).repeat(8, 1, 1, 1)      # configs[4]'s full B = 512 (8 x 64 distinct images)
 pe, pf = _CodebookPrep(), _CodebookPrep()
 te = timeit(lambda: vq_assign(zb, Et, pe, None, mode=_lib.MODE_EXACT), n=5, warm=2)
 tf = timeit(lambda: vq_assign(zb, Et, pf, None, mode=_lib.MODE_FILTER), n=5, warm=2)
-out["cfg5_K16384_B256_exact_ms"], out["cfg5_K16384_B256_filter_ms"] = te, tf
-out["cfg5_K16384_B512_exact_ms_extrapolated"], out["cfg5_K16384_B512_filter_ms_extrapolated"] = te * 2, tf * 2
+out["cfg5_K16384_B512_exact_ms"], out["cfg5_K16384_B512_filter_ms"] = te, tf
 out["cfg5_filter_queue"] = pf.fallback_count()
 zq0, c0, _ = vq_assign(zb, Et, pe, None, mode=_lib.MODE_EXACT)
 zq1, c1, _ = vq_assign(zb, Et, pf, None, mode=_lib.MODE_FILTER)
 out["cfg5_modes_bit_identical"] = bool(torch.equal(c0, c1) and torch.equal(zq0, zq1))
-flops = 2.0 * 16384 * 256 * 256 * 1024
+flops = 2.0 * 16384 * 256 * 512 * 1024
 out["cfg5_exact_tflops"] = flops / (te * 1e-3) / 1e12
 out["cfg5_filter_tflops_equiv"] = flops / (tf * 1e-3) / 1e12
 # row f3: patch-entropy map of configs[2] (B=256 images 3x256x256), fused kernel vs the reference's op sequence as torch ops
