@@ -45,6 +45,16 @@
 #define DVQ_STORE_ZQ(p, v) (*(p) = (v))
 #endif
 
+// the select-fused prologue reads lines of h_fine / h_coarse that neighbouring waves (the other rows of a coarse cell)
+// read again: keep them in L2 (plain loads) unless DVQ_SEL_NT says otherwise
+#ifndef DVQ_SEL_NT
+#define DVQ_SEL_NT 0
+#endif
+#if DVQ_SEL_NT
+#define DVQ_LOAD_SEL(p) __builtin_nontemporal_load(p)
+#else
+#define DVQ_LOAD_SEL(p) (*(p))
+#endif
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
         for (int s = 0; s < S16; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = zp[(size_t)(16 * s + j) * st];
+            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
         __builtin_amdgcn_s_setprio(0);
     } else {
         const float *zp = z + token_base();
@@ -1152,6 +1162,10 @@ bool dvq_filter_supported(int D, int HW, int K, long N)
 // resolver slices over the code tiles: 1 up to 64 tiles (K <= 2048), then one per 64 tiles, at most 8
 static int resolver_slices(int K)
 {
+    {
+        const char *v = getenv("DVQ_RES_SLICES");           // tuning aid
+        if (v && *v) { int x = atoi(v); if (x >= 1 && x <= 8) return x; }
+    }
     int T = dvq_num_tiles(K);
     int ns = (T + 63) / 64;
     return ns < 1 ? 1 : (ns > 8 ? 8 : ns);

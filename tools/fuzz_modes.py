@@ -10,7 +10,7 @@ from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
 
 
 KS = [int(k) for k in os.environ["FUZZ_KS"].split(",")] if os.environ.get("FUZZ_KS") else \
-     [1, 7, 31, 32, 33, 100, 256, 1000, 1024, 2048, 4096, 4096, 8192]      # >= 8192 takes the wide pass-1 kernel at D = 256
+     [1, 7, 31, 32, 33, 100, 256, 1000, 1024, 1024, 2048, 4096, 4096, 8192, 16384]   # the wide pass-1 kernel (K >= 2048 and >= 131072 tokens in production) is forced on every third D = 256 case
 
 
 def run(ncases=150, seed=12345, verbose=True):
@@ -46,7 +46,12 @@ def run(ncases=150, seed=12345, verbose=True):
       pe, pf = _CodebookPrep(), _CodebookPrep()
       zq0, c0, l0 = vq_assign(zt_, Et_, pe, mt_, mode=_lib.MODE_EXACT)
       fmode = _lib.MODE_FILTER_WIDE if (D == 256 and case % 3 == 0) else _lib.MODE_FILTER     # every third D=256 case: wide pass 1
-      zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=fmode)
+      # the other D = 256 cases rotate through the legacy pass 1 (-1) and the low-register forms 0..3
+      _lib.lib.dvq_set_pass1_variant((case // 3) % 5 - 1 if D == 256 else -1, -2)
+      try:
+          zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=fmode)
+      finally:
+          _lib.lib.dvq_set_pass1_variant(-1, -2)
       torch.cuda.synchronize()
       okc = torch.equal(c0, c1)
       okz = bool(((zq0 == zq1) | (torch.isnan(zq0) & torch.isnan(zq1))).all())
