@@ -233,33 +233,12 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     const int T = (Hid + 31) / 32;
     const int S = Fp / 16;
     const f16x8 *xh = (const f16x8 *)XH + lane, *xl = (const f16x8 *)XL + lane;      // + s * 64 per k-step
-    for (int t = wave; t < T; t += 4) {
-        const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
-        const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        int s0 = 0;
-        for (; s0 + 4 <= S; s0 += 4) {                 // 8 A fragments (L2) in flight per wave
-            f16x8 vh[4], vl[4], bh[4], bl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { vh[u] = ah[(s0 + u) * 64]; vl[u] = al[(s0 + u) * 64]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { bh[u] = xh[(s0 + u) * 64]; bl[u] = xl[(s0 + u) * 64]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[u], bh[u], acc, 0, 0, 0);   // small terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bl[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bh[u], acc, 0, 0, 0);
-            }
-        }
-        for (; s0 < S; ++s0) {
-            const f16x8 vh = ah[s0 * 64], vl = al[s0 * 64], bh = xh[s0 * 64], bl = xl[s0 * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, acc, 0, 0, 0);
-        }
-        // epilogue: bias, activation, contraction with the output layer (rows of this lane)
+    // The A fragments (hidden-layer weight tiles) come straight from L2, one 16-B load per lane per MFMA triple; a
+    // workgroup has one wave per SIMD (the feature tile fills the LDS), so the L2 latency is hidden by software
+    // pipelining: the fragments of the next two groups of four k-steps (2 x 8 loads = 64 VGPRs) are in flight while
+    // the current group's twelve MFMAs run.  Groups are numbered through this wave's tiles: g -> (tile wave + 4 (g / GPT),
+    // k-steps 4 (g % GPT) ..).
+    auto epilogue = [&](int t, const f32x16 &acc) {    // bias, activation, contraction with the output layer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -270,6 +249,67 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
                 for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(PB[(1 + g) * Hid + j], hv, part[g]);
             }
         }
+    };
+    if ((S & 3) == 0) {
+        const int GPT = S >> 2;                        // groups per tile
+        const int ntile = (T - wave + 3) / 4;          // tiles of this wave
+        const int NG = ntile * GPT;
+        auto fetch = [&](int g, f16x8 (&vh)[4], f16x8 (&vl)[4]) {
+            const int gg = g < NG ? g : NG - 1;        // past the end: harmless repeat
+            const int t = wave + 4 * (gg / GPT), s0 = 4 * (gg % GPT);
+            const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
+            const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { vh[u] = ah[(s0 + u) * 64]; vl[u] = al[(s0 + u) * 64]; }
+        };
+        f32x16 acc;
+        auto step = [&](int g, const f16x8 (&vh)[4], const f16x8 (&vl)[4]) {
+            if (g >= NG) return;
+            const int t = wave + 4 * (g / GPT), s0 = 4 * (g % GPT);
+            if (s0 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            }
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { bh[u] = xh[(s0 + u) * 64]; bl[u] = xl[(s0 + u) * 64]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[u], bh[u], acc, 0, 0, 0);   // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bl[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bh[u], acc, 0, 0, 0);
+            }
+            if (s0 + 4 == S) epilogue(t, acc);
+        };
+        if (NG > 0) {
+            f16x8 h0[4], l0[4], h1[4], l1[4], h2[4], l2[4];
+            fetch(0, h0, l0);
+            fetch(1, h1, l1);
+            fetch(2, h2, l2);
+            for (int g = 0; g < NG; g += 3) {
+                step(g, h0, l0);
+                fetch(g + 3, h0, l0);
+                step(g + 1, h1, l1);
+                fetch(g + 4, h1, l1);
+                step(g + 2, h2, l2);
+                fetch(g + 5, h2, l2);
+            }
+        }
+    } else {
+    for (int t = wave; t < T; t += 4) {
+        const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
+        const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int s0 = 0; s0 < S; ++s0) {
+            const f16x8 vh = ah[s0 * 64], vl = al[s0 * 64], bh = xh[s0 * 64], bl = xl[s0 * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, acc, 0, 0, 0);
+        }
+        epilogue(t, acc);
+    }
     }
     __syncthreads();                                   // everyone is done reading X
     float *red = X;                                    // [4 waves][G][32 cells]
