@@ -448,19 +448,24 @@ def run_rank(a):
     wl.prep_dom = _CodebookPrep()
     B, K, D, H, W = wl.B, wl.K, wl.D, wl.H, wl.W
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    xch = CodeExchange(wl.codes, wl.grain, K, wl.Bglobal, numel_per_image=H * W * D) if world > 1 else None
+    # two exchange objects (two sets of wire / result buffers): the all-gather of step i is completed at step i + 2,
+    # so it has two steps' worth of kernels to hide under (a 0.6-MB all-gather is latency-bound on xGMI, and RCCL's
+    # kernel competes for CUs with a pass 1 that fills the chip)
+    xchs = [CodeExchange(wl.codes, wl.grain, K, wl.Bglobal, numel_per_image=H * W * D) for _ in range(2)] if world > 1 else []
+    nstep = [0]
 
     def step(i=None):
         codes, grain, loss = wl.step(ev[i] if i is not None else None)
-        if xch is not None:
-            # one packed all-gather per step, in flight while the next step's kernels run; the previous
-            # step's exchange is completed (stream wait + unpack kernel) first, so at most one is pending
-            xch.finish()
-            xch.start(codes, grain, loss)
+        if xchs:
+            x = xchs[nstep[0] & 1]
+            nstep[0] += 1
+            x.finish()                     # exchange of two steps ago: stream wait + unpack kernel
+            x.start(codes, grain, loss)    # pack kernel + async all-gather
 
     def fence():
-        if xch is not None:
-            xch.finish()                   # the last exchange completes inside the timed region
+        for x in xchs:
+            x.finish()                     # the last exchanges complete inside the timed region
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -490,7 +495,8 @@ def run_rank(a):
             lr = torch.tensor([parity["loss_rel_err"]], dtype=torch.float64, device=dev)
             dist.all_reduce(lr, op=dist.ReduceOp.MAX)
             parity = dict(zip(keys, (int(v) for v in tot.tolist())), loss_rel_err=float(lr.item()))
-            if xch is not None:            # the gathered global tensors agree with the local shard
+            if xchs:                       # the gathered global tensors agree with the local shard
+                xch = xchs[(nstep[0] - 1) & 1]
                 g_codes, g_grain, _ = xch.result()
                 s0 = sum(b for b in xch.shard_sizes[:rank])
                 parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], wl.codes) and
