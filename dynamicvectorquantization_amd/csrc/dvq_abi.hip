@@ -105,7 +105,7 @@ size_t dvq_codebook_prep_bytes(int K, int D)
     // f32 tile images + norms + f16 section (images of the filter kernel: 2 B per element + 16 B
     // of per-code metadata), rounded up generously so the layout can grow without an ABI change
     size_t f32 = dvq_prep_f16_offset(K, D);
-    size_t f16 = (size_t)dvq_num_tiles(K) * 32 * ((size_t)D * 2 + 16) + 4096;
+    size_t f16 = 2 * ((size_t)dvq_num_tiles(K) * 32 * ((size_t)D * 2 + 16) + 4096);   // two tile images (32x32x16 / 16x16x32 order)
     return ((f32 + f16 + 255) / 256) * 256;
 }
 

@@ -55,6 +55,11 @@
 #else
 #define DVQ_LOAD_SEL(p) (*(p))
 #endif
+#ifndef DVQ_MFMA16_DEFAULT
+#define DVQ_MFMA16_DEFAULT 1     // code loop of the legacy pass 1 on v_mfma_f32_16x16x32_f16 (same bits out; +1 % at K = 1024, +7 % at 16384)
+#endif
+static bool dvq_mfma16_enabled();
+static size_t dvq_img16_offset_of(int K, int D);
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
@@ -151,6 +156,40 @@ __global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__r
     }
 }
 
+// The same tile in v_mfma_f32_16x16x32_f16 operand order (image "16"): fragment F = c2 * (D/32) + s' (c2 < 2 code halves,
+// s' < D/32 k-steps of 32), lane l, j < 8: fp16(2^b E[32t + 16 c2 + (l & 15)][32 s' + 8 (l >> 4) + j]); same seeds tail.
+__global__ __launch_bounds__(256) void codebook_prep_f16x_kernel(const float *__restrict__ E, int K, int D,
+                                                                 const DvqF16Meta *__restrict__ meta,
+                                                                 const float *__restrict__ en_all,
+                                                                 char *__restrict__ img)
+{
+    const float sb = meta->scale_b;
+    const int S32 = D / 32;
+    const size_t img_halves = (size_t)(D / 16) * 512;
+    const size_t per_tile = img_halves + 128;
+    const size_t total = (size_t)dvq_num_tiles(K) * per_tile;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int t = (int)(i / per_tile);
+        int r = (int)(i - (size_t)t * per_tile);
+        char *tile = img + (size_t)t * per_tile * 2;
+        if (r < (int)img_halves) {
+            int F = r >> 9, lane = (r >> 3) & 63, j = r & 7;
+            int c2 = F / S32, sp = F - c2 * S32;
+            int code = t * 32 + 16 * c2 + (lane & 15);
+            int k = 32 * sp + 8 * (lane >> 4) + j;
+            float v = (code < K) ? E[(size_t)code * D + k] * sb : 0.0f;
+            ((_Float16 *)tile)[r] = (_Float16)v;
+        } else if (((r - (int)img_halves) & 1) == 0) {
+            int q = (r - (int)img_halves) >> 1;
+            int code = t * 32 + q;
+            float v = 0.0f;
+            if (q < 32) v = (code < K) ? fmaxf(-0.5f * sb * en_all[code], DVQ_SEED_PAD) : DVQ_SEED_PAD;
+            ((float *)(tile + img_halves * 2))[q] = v;
+        }
+    }
+}
+
 // etamax = max_j || 2^b e_j - fp16(2^b e_j) ||_2 (each residual is exact in fp32), rounded up
 __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restrict__ E, int K, int D,
                                                            DvqF16Meta *__restrict__ meta)
@@ -183,7 +222,9 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // ---------------------------------------------------------------------------------------------
 // SEL: the router select fused in (DvqRouted with dense = 1): token n is output position n, its source vector
 // sits in the encoder branch that won its cell (per-lane source pointer and channel stride); outputs as dense.
-template <int D, bool SEL>
+// M16: the code loop on v_mfma_f32_16x16x32_f16 (image "16"): same flops per cycle, but the part holds a higher clock
+// under this shape when power-limited; the latents' fragments are permuted into its operand order once per wave.
+template <int D, bool SEL, bool M16>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -280,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         __builtin_amdgcn_s_setprio(0);
     }
     f16x8 zh[S16];
+    f16x8 zb[2][M16 ? S16 / 2 : 1];                          // M16: B operands of the 16x16x32 loop, [token half][k-step of 32]
     float xn, thr2W;
     {
         float pa[2][8];
@@ -303,6 +345,20 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 zeta2 = __builtin_fmaf(r1, r1, zeta2);
             }
             zh[s] = __builtin_bit_cast(f16x8, packed);
+            if (M16 && (s & 1)) {
+                // tokens 16 t2 + (lane & 15), k = 32 s' + 8 (lane >> 4) + j  <-  lane (c, h) = (16 t2 + (lane & 15), (lane >> 4) & 1),
+                // k-step 2 s' + (lane >> 5) of the 32x32x16 layout: through a 2-KiB per-wave LDS scratch (a wave's LDS
+                // operations execute in order, so no barrier; 128 ds_bpermutes instead spilled 54 VGPRs)
+                const int sp = s >> 1;
+                char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;
+                *(f16x8 *)(scr + lane * 16) = zh[s - 1];
+                *(f16x8 *)(scr + 1024 + lane * 16) = zh[s];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int srcl = 16 * t2 + (lane & 15) + 32 * ((lane >> 4) & 1);
+                    zb[t2][sp] = *(const f16x8 *)(scr + (lane >> 5) * 1024 + srcl * 16);
+                }
+            }
         }
         float t8[8];
 #pragma unroll
@@ -325,86 +381,181 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
     int t1 = 0;
-    for (int t = 0; t < T; ++t) {
-        // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
-        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
-        }
-        if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-        __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
-        asm volatile("" ::: "memory");
-        if (S16 != 16) issue(t + 3);                         // D = 256: pieces ride between the MFMAs below
-        // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
-        // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
-        const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
-                                    lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
-        f16x8 a0, a1, a2, a3;
-        // make the compiler wait for the seed reads HERE (an opaque use of acc); otherwise its own
-        // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
-        asm volatile("" : "+v"(acc));
-        __builtin_amdgcn_sched_barrier(0);
-#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-#define DVQ_MM(src, S, WAIT, NEXT)                                                      \
-        asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[S], acc, 0, 0, 0);         \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
-        NEXT
-        DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
-        __builtin_amdgcn_s_setprio(1);
-        if (S16 == 16) {
-            // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
-            // then overlaps the MFMA already in the pipe instead of preceding the whole chain
-            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-            DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
-            DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
-            DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
-        } else if (S16 == 8) {
-            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-            DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
-        } else {
-            DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
-        }
-#undef DVQ_MM
-#undef DVQ_RD
-        __builtin_amdgcn_s_setprio(0);
-        const float om = m1;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            // running top-2 over the pair (g0, g1): with m2 <= m1 the new second-best is
-            // max(m2, med3(m1, g0, g1)) and the new best max3(m1, g0, g1): 2.5 VALU ops per score
-            float g0 = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-            float g1 = __uint_as_float((__float_as_uint(acc[r + 1]) & 0xFFFFFFF0u) | (unsigned)(r + 1));
-            float md = __builtin_amdgcn_fmed3f(m1, g0, g1);
-            m1 = vmax3_raw(m1, g0, g1);
-            m2 = vmax_raw(m2, md);
-        }
-        t1 = (m1 != om) ? t : t1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-
+    float best, second;
     int code;
-    float thr;
-    bool final_ok;
-    {
+    if constexpr (!M16) {
+        for (int t = 0; t < T; ++t) {
+            // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
+            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
+            f32x16 acc;
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
+            }
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
+            asm volatile("" ::: "memory");
+            if (S16 != 16) issue(t + 3);                         // D = 256: pieces ride between the MFMAs below
+            // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
+            // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
+            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+            f16x8 a0, a1, a2, a3;
+            // make the compiler wait for the seed reads HERE (an opaque use of acc); otherwise its own
+            // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
+            asm volatile("" : "+v"(acc));
+            __builtin_amdgcn_sched_barrier(0);
+    #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+    #define DVQ_MM(src, S, WAIT, NEXT)                                                      \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[S], acc, 0, 0, 0);         \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
+            NEXT
+            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+            __builtin_amdgcn_s_setprio(1);
+            if (S16 == 16) {
+                // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
+                // then overlaps the MFMA already in the pipe instead of preceding the whole chain
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
+                DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
+                DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
+            } else if (S16 == 8) {
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
+            } else {
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
+            }
+    #undef DVQ_MM
+    #undef DVQ_RD
+            __builtin_amdgcn_s_setprio(0);
+            const float om = m1;
+    #pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                // running top-2 over the pair (g0, g1): with m2 <= m1 the new second-best is
+                // max(m2, med3(m1, g0, g1)) and the new best max3(m1, g0, g1): 2.5 VALU ops per score
+                float g0 = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+                float g1 = __uint_as_float((__float_as_uint(acc[r + 1]) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+                float md = __builtin_amdgcn_fmed3f(m1, g0, g1);
+                m1 = vmax3_raw(m1, g0, g1);
+                m2 = vmax_raw(m2, md);
+            }
+            t1 = (m1 != om) ? t : t1;
+        }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
         const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
         const int ot = __shfl_xor(t1, 32);
         const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);
-        const float best = other_wins ? o1 : m1;
-        const float second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
+        best = other_wins ? o1 : m1;
+        second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
         const int wt = other_wins ? ot : t1;
         const int wh = other_wins ? (h ^ 1) : h;
         const int r = (int)(__float_as_uint(best) & 15u);
         code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-        thr = best - thr2W;
-        final_ok = (best - second) > thr2W;
+    } else {
+        // ---- 16x16x32 code loop: fragment F = c2 * S32 + s' of the tile feeds two MFMAs (token halves t2 = 0, 1);
+        // accumulator acc16[c2][t2][i] = code 16 c2 + 4 (lane >> 4) + i against token 16 t2 + (lane & 15)
+        constexpr int S32 = S16 / 2;
+        const int q16 = lane >> 4;
+        float b1[2] = {-__builtin_inff(), -__builtin_inff()}, b2[2] = {-__builtin_inff(), -__builtin_inff()};
+        int bt[2] = {0, 0};
+        for (int t = 0; t < T; ++t) {
+            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16;
+            f32x4 acc16[2][2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
+                acc16[c2][0] = e4;
+                acc16[c2][1] = e4;
+            }
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();                    // tile t (everybody's DMA) landed; t-1 consumed
+            asm volatile("" ::: "memory");
+            if (S16 != 16) issue(t + 3);
+            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+            f16x8 a0, a1, a2, a3;
+            asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][1]), "+v"(acc16[1][0]), "+v"(acc16[1][1]));
+            __builtin_amdgcn_sched_barrier(0);
+#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+#define DVQ_MM(src, F, WAIT, NEXT)                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            acc16[(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][(F) % S32], acc16[(F) / S32][0], 0, 0, 0); \
+            acc16[(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][(F) % S32], acc16[(F) / S32][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if ((F) + 4 < S16) { DVQ_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                  \
+            NEXT
+            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+            __builtin_amdgcn_s_setprio(1);
+            if (S16 == 16) {
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
+                DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
+                DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
+            } else if (S16 == 8) {
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
+            } else {
+                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
+            }
+#undef DVQ_MM
+#undef DVQ_RD
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const float om = b1[t2];
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {         // r = 4 c2 + i
+                    const float v0 = acc16[r >> 2][t2][r & 3], v1 = acc16[(r + 1) >> 2][t2][(r + 1) & 3];
+                    float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
+                    float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+                    float md = __builtin_amdgcn_fmed3f(b1[t2], g0, g1);
+                    b1[t2] = vmax3_raw(b1[t2], g0, g1);
+                    b2[t2] = vmax_raw(b2[t2], md);
+                }
+                bt[t2] = (b1[t2] != om) ? t : bt[t2];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+        // merge the four lane groups of a token column (lower lane wins ties), then hand the results to the lanes
+        // that own the token in the (c, h) layout of the prologue / epilogue
+        float rb[2], rs[2];
+        int rc[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            float mb = b1[t2], ms = b2[t2];
+            int mt = bt[t2], mq = q16;
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float o1 = __shfl_xor(mb, off), o2 = __shfl_xor(ms, off);
+                const int ot = __shfl_xor(mt, off), oq = __shfl_xor(mq, off);
+                const bool other_wins = (o1 > mb) || (o1 == mb && ((lane ^ off) < lane));
+                ms = fmaxf(other_wins ? mb : o1, fmaxf(ms, o2));
+                mb = other_wins ? o1 : mb;
+                mt = other_wins ? ot : mt;
+                mq = other_wins ? oq : mq;
+            }
+            const int r = (int)(__float_as_uint(mb) & 15u);
+            rb[t2] = mb;
+            rs[t2] = ms;
+            rc[t2] = mt * 32 + 16 * (r >> 2) + 4 * mq + (r & 3);
+        }
+        const int srcl = c & 15;
+        const float x0 = __shfl(rb[0], srcl), x1 = __shfl(rb[1], srcl);
+        const float y0 = __shfl(rs[0], srcl), y1 = __shfl(rs[1], srcl);
+        const int c0 = __shfl(rc[0], srcl), c1 = __shfl(rc[1], srcl);
+        best = (c >> 4) ? x1 : x0;
+        second = (c >> 4) ? y1 : y0;
+        code = (c >> 4) ? c1 : c0;
     }
+    const float thr = best - thr2W;
+    const bool final_ok = (best - second) > thr2W;
     const bool valid = n >= 0;
     bool hopeless = !(code < K) || !(thr == thr);
     // undecided tokens are queued for the resolver.  The slot comes from an atomic whose result is not
@@ -1029,7 +1180,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
 // same index packing, same threshold -- with every score written out instead of reduced to a top-2.
 // One wave per 32 tokens; A fragments straight from the prep image.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool M16>
 __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     const float *__restrict__ tokens, int n, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     int K, float *__restrict__ G, float *__restrict__ thr2W_out, float *__restrict__ xn_out)
@@ -1081,6 +1232,58 @@ __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     zeta2 += __shfl_xor(zeta2, 32);
     const float thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     if (valid && h == 0) { thr2W_out[tok] = thr2W; xn_out[tok] = xn; }
+    if constexpr (M16) {
+        // the 16x16x32 code loop of pass 1 (image "16" passed as img): lane (c16, q) holds tokens c16 / 16 + c16 of the
+        // block, k = 32 s' + 8 q + j -- the same fp16 values pass 1 permutes into this order
+        constexpr int S32 = D / 32;
+        const int c16 = lane & 15, q16 = lane >> 4;
+        f16x8 zb[2][S32];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int tk = blockIdx.x * 32 + 16 * t2 + c16;
+            const float *zq_ = tokens + (size_t)(tk < n ? tk : n - 1) * D + 8 * q16;
+#pragma unroll
+            for (int sp = 0; sp < S32; ++sp) {
+                u32x4 pk;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    f32x2 vv = {zq_[32 * sp + 2 * j2], zq_[32 * sp + 2 * j2 + 1]};
+                    f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    pk[j2] = __builtin_bit_cast(unsigned, hh);
+                }
+                zb[t2][sp] = __builtin_bit_cast(f16x8, pk);
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            const char *tile = img + (size_t)t * TILE_STRIDE;
+            const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * q16;
+            f32x4 acc16[2][2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
+                acc16[c2][0] = e4;
+                acc16[c2][1] = e4;
+            }
+#pragma unroll
+            for (int F = 0; F < 2 * S32; ++F) {
+                const f16x8 a = *(const f16x8 *)(tile + F * 1024 + lane * 16);
+                acc16[F / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[0][F % S32], acc16[F / S32][0], 0, 0, 0);
+                acc16[F / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[1][F % S32], acc16[F / S32][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int tk = blockIdx.x * 32 + 16 * t2 + c16;
+                if (tk < n) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int code = t * 32 + 16 * (r >> 2) + 4 * q16 + (r & 3);
+                        G[(size_t)tk * Kpad + code] = __uint_as_float((__float_as_uint(acc16[r >> 2][t2][r & 3]) & 0xFFFFFFF0u) | (unsigned)r);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int t = 0; t < T; ++t) {
         const char *tile = img + (size_t)t * TILE_STRIDE;
         const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * h;
@@ -1114,12 +1317,18 @@ int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep,
     const DvqF16Meta *meta = (const DvqF16Meta *)base;
     const char *img = base + 256;
     const int blocks = (n + 31) / 32;
+    // the arithmetic pass 1 uses: DVQ_MFMA16 (default DVQ_MFMA16_DEFAULT) picks the 16x16x32 loop and its image
+    const bool m16 = dvq_mfma16_enabled();
+    const char *im = m16 ? img + dvq_img16_offset_of(K, D) : img;
+#define DVQ_DBG(DD) do { if (m16) hipLaunchKernelGGL((filter_scores_debug_kernel<DD, true>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); \
+                         else hipLaunchKernelGGL((filter_scores_debug_kernel<DD, false>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); } while (0)
     switch (D) {
-    case 64:  hipLaunchKernelGGL(filter_scores_debug_kernel<64>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
-    case 128: hipLaunchKernelGGL(filter_scores_debug_kernel<128>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
-    case 256: hipLaunchKernelGGL(filter_scores_debug_kernel<256>, dim3(blocks), dim3(64), 0, st, tokens, n, img, meta, K, G, thr2W, xn); break;
+    case 64:  DVQ_DBG(64); break;
+    case 128: DVQ_DBG(128); break;
+    case 256: DVQ_DBG(256); break;
     default:  return -1000;
     }
+#undef DVQ_DBG
     if (scale_b_out != nullptr)
         (void)hipMemcpyAsync(scale_b_out, &meta->scale_b, sizeof(float), hipMemcpyDeviceToDevice, st);
     return (int)hipGetLastError();
@@ -1182,6 +1391,13 @@ size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
            align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
 }
 
+// the 16x16x32-order image follows the 32x32x16-order one
+static size_t dvq_img16_offset(int K, int D)
+{
+    const size_t tile = (size_t)(D / 16) * 1024 + 256;
+    return ((size_t)dvq_num_tiles(K) * tile + 255) / 256 * 256;
+}
+
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
@@ -1194,6 +1410,8 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(codebook_prep_f16_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all, img);
+    hipLaunchKernelGGL(codebook_prep_f16x_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all,
+                       img + dvq_img16_offset(K, D));
     hipLaunchKernelGGL(codebook_eta_kernel, dim3((K + 255) / 256), dim3(256), 0, st, E, K, D, meta);
     return (int)hipGetLastError();
 }
@@ -1235,6 +1453,8 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 #define DVQ_STAGGER_DEFAULT_US 0
 #endif
 static int g_dense_variant = -2, g_routed_variant = -2;      // -2: not chosen yet (environment / default)
+static bool dvq_mfma16_enabled() { return env_int("DVQ_MFMA16", DVQ_MFMA16_DEFAULT, 0, 1) != 0; }
+static size_t dvq_img16_offset_of(int K, int D) { return dvq_img16_offset(K, D); }
 static int dense_variant()
 {
     int v = __atomic_load_n(&g_dense_variant, __ATOMIC_RELAXED);
@@ -1275,30 +1495,41 @@ static FilterWs carve_ws(void *ws_extra, long N, int D)
     return w;
 }
 
+template <int D, bool SEL, bool M16>
+static int launch_legacy_form(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
+                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
+                              double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st)
+{
+    static unsigned long long done = 0;
+    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + (M16 ? 4 * 2048 : 0);
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, M16>, (int)shmem1, &done);
+    if (rc) return rc;
+    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, M16>), dim3((unsigned)((N + 127) / 128)), dim3(256), shmem1, st,
+                       z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                       w.cap / DVQ_QSHARDS, rv);
+    return (int)hipGetLastError();
+}
+
 template <int D>
 static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                                const float *mask, int HW, int K, long N, float *zq, long long *codes,
                                double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
                                hipStream_t st)
 {
-    static unsigned long long done = 0, done_sel = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
     const int nb1 = (int)((N + 127) / 128);
+    // DVQ_MFMA16 = 1: the code loop on v_mfma_f32_16x16x32_f16 (second tile image of the prep buffer)
+    const bool m16 = dvq_mfma16_enabled();
+    const char *img16 = img + dvq_img16_offset(K, D);
     if (rv != nullptr) {                                     // select fused in (rv->dense): legacy form only
-        int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, true>, (int)shmem1, &done_sel);
-        if (rc) return rc;
-        hipLaunchKernelGGL((vq_assign_filter_kernel<D, true>), dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                           E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                           w.cap / DVQ_QSHARDS, *rv);
-        return (int)hipGetLastError();
+        return m16 ? launch_legacy_form<D, true, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
+                   : launch_legacy_form<D, true, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
     }
-    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, false>, (int)shmem1, &done);
-    if (rc) return rc;
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
                                                              // with two 256-token workgroups: two blocks per wave
             static unsigned long long done_w = 0;
-            rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
+            int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
             if (rc) return rc;
             hipLaunchKernelGGL(vq_assign_filter_wide_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), shmem1, st,
                                z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
@@ -1306,10 +1537,9 @@ static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((vq_assign_filter_kernel<D, false>), dim3(nb1), dim3(256), shmem1, st, z, img, meta,
-                       E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records, w.cap / DVQ_QSHARDS,
-                       DvqRouted{});
-    return (int)hipGetLastError();
+    const DvqRouted none = {};
+    return m16 ? launch_legacy_form<D, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st)
+               : launch_legacy_form<D, false, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
 }
 
 template <int D>

@@ -29,8 +29,9 @@ def _check_dual(r, o_sel, o, B, beta=0.25, oracle_mod=None):
 
 
 # routed-op forms: ("dedup", v) = unique tokens only, low-register pass-1 variant v; ("fused", -1) = one token per
-# output position with the select fused into the legacy pass-1 kernel; ("fused", v) = the same on a low-register form
-FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1)]
+# output position with the select fused into the legacy pass-1 kernel (the default); ("fused", v) = the same on a
+# low-register form; ("fused32", -1) = the default with the 32x32x16 code loop instead of 16x16x32
+FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1), ("fused32", -1)]
 
 
 @pytest.fixture(params=FORMS, ids=["%s%d" % f for f in FORMS])
@@ -41,10 +42,12 @@ def variant(request):
     assert _lib.lib.dvq_set_pass1_variant(-2, max(v, 0)) == 0
     os.environ["DVQ_ROUTED_DEDUP"] = "1" if kind == "dedup" else "0"
     os.environ["DVQ_ROUTED_DENSE_LOWREG"] = "1" if (kind == "fused" and v >= 0) else "0"
+    os.environ["DVQ_MFMA16"] = "0" if kind == "fused32" else "1"      # code loop of the legacy pass 1: 16x16x32 (default) / 32x32x16
     yield 0 if request.param == FORMS[0] else 1 + FORMS.index(request.param)
     _lib.lib.dvq_set_pass1_variant(-2, 0)
     os.environ.pop("DVQ_ROUTED_DEDUP", None)
     os.environ.pop("DVQ_ROUTED_DENSE_LOWREG", None)
+    os.environ.pop("DVQ_MFMA16", None)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
