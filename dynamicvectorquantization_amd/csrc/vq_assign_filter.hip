@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 // >= 2 MiB of codebook every token is scored against.  Same top-2 tracking, same bound, same queue,
 // records and outputs as vq_assign_filter_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool M16>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -714,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     }
 
     // ---- prologue: per block, z in batches of four k-steps -> fp16 fragments, exact-order norm, bound
-    f16x8 zh[2][S16];
+    f16x8 zh[2][M16 ? 2 : S16];                             // M16: only the current pair of k-steps lives
+    f16x8 zb[2][2][M16 ? S16 / 2 : 1];                       // M16: [block][token half][k-step of 32] in 16x16x32 operand order
     float xn[2], thr2W[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -750,12 +751,27 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
                     zeta2 = __builtin_fmaf(r0, r0, zeta2);
                     zeta2 = __builtin_fmaf(r1, r1, zeta2);
                 }
-                zh[u][s] = __builtin_bit_cast(f16x8, packed);
+                if constexpr (!M16) {
+                    zh[u][s] = __builtin_bit_cast(f16x8, packed);
+                } else {
+                    zh[u][s & 1] = __builtin_bit_cast(f16x8, packed);
+                    if (s & 1) {                             // same permutation as vq_assign_filter_kernel, per-wave LDS scratch
+                        char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;
+                        *(f16x8 *)(scr + lane * 16) = zh[u][0];
+                        *(f16x8 *)(scr + 1024 + lane * 16) = zh[u][1];
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            const int srcl = 16 * t2 + (lane & 15) + 32 * ((lane >> 4) & 1);
+                            zb[u][t2][s >> 1] = *(const f16x8 *)(scr + (lane >> 5) * 1024 + srcl * 16);
+                        }
+                    }
+                }
             }
             // one batch of 32 loads at a time (register budget): the next batch's addresses depend,
             // opaquely, on this batch's last converted fragment
             zpb += (size_t)64 * HW;
-            asm volatile("" : "+v"(zpb) : "v"(zh[u][sb + 3]));
+            if constexpr (M16) asm volatile("" : "+v"(zpb) : "v"(zb[u][1][(sb + 3) >> 1]));
+            else asm volatile("" : "+v"(zpb) : "v"(zh[u][M16 ? 1 : sb + 3]));
         }
         float t8[8];
 #pragma unroll
@@ -777,78 +793,180 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
 
-    // ---- code loop: 32 MFMAs per tile and wave, every A fragment used for both token blocks
-    float m1[2] = {-__builtin_inff(), -__builtin_inff()}, m2[2] = {-__builtin_inff(), -__builtin_inff()};
-    int t1[2] = {0, 0};
-    for (int t = 0; t < T; ++t) {
-        const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { acc0[4 * g + q] = e4[q]; acc1[4 * g + q] = e4[q]; }
-        }
-        if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-        __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
-        asm volatile("" ::: "memory");
-        const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
-                                    lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
-        f16x8 a0, a1, a2, a3;
-        asm volatile("" : "+v"(acc0), "+v"(acc1));
-        __builtin_amdgcn_sched_barrier(0);
-#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-#define DVQ_MM2(src, S, WAIT, NEXT)                                                     \
-        asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[0][S], acc0, 0, 0, 0);    \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[1][S], acc1, 0, 0, 0);    \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
-        NEXT
-        DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
-        __builtin_amdgcn_s_setprio(1);
-        DVQ_MM2(a0, 0, 3, ) DVQ_MM2(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM2(a2, 2, 3, ) DVQ_MM2(a3, 3, 3, )
-        DVQ_MM2(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM2(a1, 5, 3, ) DVQ_MM2(a2, 6, 3, ) DVQ_MM2(a3, 7, 3, issue_piece(t + 3, 2);)
-        DVQ_MM2(a0, 8, 3, ) DVQ_MM2(a1, 9, 3, ) DVQ_MM2(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM2(a3, 11, 3, )
-        DVQ_MM2(a0, 12, 3, ) DVQ_MM2(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM2(a2, 14, 1, ) DVQ_MM2(a3, 15, 0, )
-#undef DVQ_MM2
-#undef DVQ_RD
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float om = m1[u];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float v0 = u == 0 ? acc0[r] : acc1[r], v1 = u == 0 ? acc0[r + 1] : acc1[r + 1];
-                float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
-                float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
-                float md = __builtin_amdgcn_fmed3f(m1[u], g0, g1);
-                m1[u] = vmax3_raw(m1[u], g0, g1);
-                m2[u] = vmax_raw(m2[u], md);
-            }
-            t1[u] = (m1[u] != om) ? t : t1[u];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-
-    // ---- decisions for both blocks, one queue atomic per wave
+    // ---- code loop
     int code[2];
     float thr[2];
     bool undecided[2], hopeless[2], valid[2];
+    float bestv[2], secondv[2];
+    if constexpr (!M16) {
+        // ---- code loop: 32 MFMAs per tile and wave, every A fragment used for both token blocks
+        float m1[2] = {-__builtin_inff(), -__builtin_inff()}, m2[2] = {-__builtin_inff(), -__builtin_inff()};
+        int t1[2] = {0, 0};
+        for (int t = 0; t < T; ++t) {
+            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
+            f32x16 acc0, acc1;
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) { acc0[4 * g + q] = e4[q]; acc1[4 * g + q] = e4[q]; }
+            }
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
+            asm volatile("" ::: "memory");
+            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+            f16x8 a0, a1, a2, a3;
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            __builtin_amdgcn_sched_barrier(0);
+    #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+    #define DVQ_MM2(src, S, WAIT, NEXT)                                                     \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[0][S], acc0, 0, 0, 0);    \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[1][S], acc1, 0, 0, 0);    \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
+            NEXT
+            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+            __builtin_amdgcn_s_setprio(1);
+            DVQ_MM2(a0, 0, 3, ) DVQ_MM2(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM2(a2, 2, 3, ) DVQ_MM2(a3, 3, 3, )
+            DVQ_MM2(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM2(a1, 5, 3, ) DVQ_MM2(a2, 6, 3, ) DVQ_MM2(a3, 7, 3, issue_piece(t + 3, 2);)
+            DVQ_MM2(a0, 8, 3, ) DVQ_MM2(a1, 9, 3, ) DVQ_MM2(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM2(a3, 11, 3, )
+            DVQ_MM2(a0, 12, 3, ) DVQ_MM2(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM2(a2, 14, 1, ) DVQ_MM2(a3, 15, 0, )
+    #undef DVQ_MM2
+    #undef DVQ_RD
+            __builtin_amdgcn_s_setprio(0);
+    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float om = m1[u];
+    #pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float v0 = u == 0 ? acc0[r] : acc1[r], v1 = u == 0 ? acc0[r + 1] : acc1[r + 1];
+                    float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
+                    float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+                    float md = __builtin_amdgcn_fmed3f(m1[u], g0, g1);
+                    m1[u] = vmax3_raw(m1[u], g0, g1);
+                    m2[u] = vmax_raw(m2[u], md);
+                }
+                t1[u] = (m1[u] != om) ? t : t1[u];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+
+
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float o1 = __shfl_xor(m1[u], 32), o2 = __shfl_xor(m2[u], 32);
+            const int ot = __shfl_xor(t1[u], 32);
+            const bool other_wins = (o1 > m1[u]) || (o1 == m1[u] && h == 1);
+            bestv[u] = other_wins ? o1 : m1[u];
+            secondv[u] = fmaxf(other_wins ? m1[u] : o1, fmaxf(m2[u], o2));
+            const int wt = other_wins ? ot : t1[u];
+            const int wh = other_wins ? (h ^ 1) : h;
+            const int r = (int)(__float_as_uint(bestv[u]) & 15u);
+            code[u] = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
+        }
+    } else {
+        // 16x16x32 form: every A fragment (16 codes x 32 k) feeds four MFMAs (two blocks x two token halves)
+        constexpr int S32 = S16 / 2;
+        const int q16 = lane >> 4;
+        float b1[2][2], b2[2][2];
+        int bt[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) { b1[u][t2] = -__builtin_inff(); b2[u][t2] = -__builtin_inff(); bt[u][t2] = 0; }
+        for (int t = 0; t < T; ++t) {
+            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16;
+            f32x4 acc16[2][2][2];                            // [block][code half][token half]
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
+                acc16[0][c2][0] = e4; acc16[0][c2][1] = e4; acc16[1][c2][0] = e4; acc16[1][c2][1] = e4;
+            }
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+            f16x8 a0, a1, a2, a3;
+            asm volatile("" : "+v"(acc16[0][0][0]), "+v"(acc16[0][0][1]), "+v"(acc16[0][1][0]), "+v"(acc16[0][1][1]),
+                              "+v"(acc16[1][0][0]), "+v"(acc16[1][0][1]), "+v"(acc16[1][1][0]), "+v"(acc16[1][1][1]));
+            __builtin_amdgcn_sched_barrier(0);
+#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+#define DVQ_MM4(src, F, WAIT, NEXT)                                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            acc16[0][(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][0][(F) % S32], acc16[0][(F) / S32][0], 0, 0, 0); \
+            acc16[0][(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][1][(F) % S32], acc16[0][(F) / S32][1], 0, 0, 0); \
+            acc16[1][(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][0][(F) % S32], acc16[1][(F) / S32][0], 0, 0, 0); \
+            acc16[1][(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][1][(F) % S32], acc16[1][(F) / S32][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            if ((F) + 4 < S16) { DVQ_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                             \
+            NEXT
+            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+            __builtin_amdgcn_s_setprio(1);
+            DVQ_MM4(a0, 0, 3, ) DVQ_MM4(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM4(a2, 2, 3, ) DVQ_MM4(a3, 3, 3, )
+            DVQ_MM4(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM4(a1, 5, 3, ) DVQ_MM4(a2, 6, 3, ) DVQ_MM4(a3, 7, 3, issue_piece(t + 3, 2);)
+            DVQ_MM4(a0, 8, 3, ) DVQ_MM4(a1, 9, 3, ) DVQ_MM4(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM4(a3, 11, 3, )
+            DVQ_MM4(a0, 12, 3, ) DVQ_MM4(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM4(a2, 14, 1, ) DVQ_MM4(a3, 15, 0, )
+#undef DVQ_MM4
+#undef DVQ_RD
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const float om = b1[u][t2];
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const float v0 = acc16[u][r >> 2][t2][r & 3], v1 = acc16[u][(r + 1) >> 2][t2][(r + 1) & 3];
+                        float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
+                        float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
+                        float md = __builtin_amdgcn_fmed3f(b1[u][t2], g0, g1);
+                        b1[u][t2] = vmax3_raw(b1[u][t2], g0, g1);
+                        b2[u][t2] = vmax_raw(b2[u][t2], md);
+                    }
+                    bt[u][t2] = (b1[u][t2] != om) ? t : bt[u][t2];
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float rb[2], rs[2];
+            int rc[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float mb = b1[u][t2], ms = b2[u][t2];
+                int mt = bt[u][t2], mq = q16;
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float o1 = __shfl_xor(mb, off), o2 = __shfl_xor(ms, off);
+                    const int ot = __shfl_xor(mt, off), oq = __shfl_xor(mq, off);
+                    const bool other_wins = (o1 > mb) || (o1 == mb && ((lane ^ off) < lane));
+                    ms = fmaxf(other_wins ? mb : o1, fmaxf(ms, o2));
+                    mb = other_wins ? o1 : mb;
+                    mt = other_wins ? ot : mt;
+                    mq = other_wins ? oq : mq;
+                }
+                const int r = (int)(__float_as_uint(mb) & 15u);
+                rb[t2] = mb; rs[t2] = ms;
+                rc[t2] = mt * 32 + 16 * (r >> 2) + 4 * mq + (r & 3);
+            }
+            const int srcl = c & 15;
+            const float x0 = __shfl(rb[0], srcl), x1 = __shfl(rb[1], srcl);
+            const float y0 = __shfl(rs[0], srcl), y1 = __shfl(rs[1], srcl);
+            const int c0 = __shfl(rc[0], srcl), c1 = __shfl(rc[1], srcl);
+            bestv[u] = (c >> 4) ? x1 : x0;
+            secondv[u] = (c >> 4) ? y1 : y0;
+            code[u] = (c >> 4) ? c1 : c0;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const float o1 = __shfl_xor(m1[u], 32), o2 = __shfl_xor(m2[u], 32);
-        const int ot = __shfl_xor(t1[u], 32);
-        const bool other_wins = (o1 > m1[u]) || (o1 == m1[u] && h == 1);
-        const float best = other_wins ? o1 : m1[u];
-        const float second = fmaxf(other_wins ? m1[u] : o1, fmaxf(m2[u], o2));
-        const int wt = other_wins ? ot : t1[u];
-        const int wh = other_wins ? (h ^ 1) : h;
-        const int r = (int)(__float_as_uint(best) & 15u);
-        code[u] = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-        thr[u] = best - thr2W[u];
-        const bool final_ok = (best - second) > thr2W[u];
+        thr[u] = bestv[u] - thr2W[u];
+        const bool final_ok = (bestv[u] - secondv[u]) > thr2W[u];
         valid[u] = nn[u] >= 0;
         hopeless[u] = !(code[u] < K) || !(thr[u] == thr[u]);
         undecided[u] = valid[u] && !hopeless[u] && !final_ok;
@@ -1528,12 +1646,22 @@ static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
                                                              // with two 256-token workgroups: two blocks per wave
-            static unsigned long long done_w = 0;
-            int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shmem1, &done_w);
-            if (rc) return rc;
-            hipLaunchKernelGGL(vq_assign_filter_wide_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), shmem1, st,
-                               z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                               w.cap / DVQ_QSHARDS, nb1);
+            static unsigned long long done_w = 0, done_w16 = 0;
+            const unsigned gridw = (unsigned)((N + 255) / 256);
+            if (m16) {
+                const size_t shm = shmem1 + 4 * 2048;        // + the per-wave permutation scratch
+                int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D, true>, (int)shm, &done_w16);
+                if (rc) return rc;
+                hipLaunchKernelGGL((vq_assign_filter_wide_kernel<D, true>), dim3(gridw), dim3(256), shm, st,
+                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list,
+                                   w.records, w.cap / DVQ_QSHARDS, nb1);
+            } else {
+                int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D, false>, (int)shmem1, &done_w);
+                if (rc) return rc;
+                hipLaunchKernelGGL((vq_assign_filter_wide_kernel<D, false>), dim3(gridw), dim3(256), shmem1, st,
+                                   z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list,
+                                   w.records, w.cap / DVQ_QSHARDS, nb1);
+            }
             return (int)hipGetLastError();
         }
     }
