@@ -487,6 +487,11 @@ def run_rank(a):
     parity = None
     if not a.no_parity:
         # every rank checks ITS images against the oracle, after the timed region, on the last step's outputs
+        try:
+            import ctypes
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(max(1, usable_cpus() // world))   # ranks share the host cores
+        except Exception:
+            pass
         parity = wl.parity()
         if world > 1:
             keys = sorted(k for k in parity if k != "loss_rel_err")
