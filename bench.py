@@ -302,9 +302,11 @@ class WeakDual:
         from oracle import oracle
         oracle.build()
         ent, hc, hf = (x.cpu().numpy() for x in (self.ent, self.h_coarse, self.h_fine))
+        t0 = time.perf_counter()
         og = oracle.entropy_gate(ent, THR_R05)
         osel = oracle.route_select_dual(og, hc, hf)
         o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
+        self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
         codes = self.codes.cpu().numpy().reshape(self.B, -1)
         ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
         return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
@@ -560,6 +562,8 @@ def run_rank(a):
             out["parity_checked"] = bool(bad == 0 and parity["loss_rel_err"] <= 1e-5 and parity.get("exchange_ok", True))
             out["code_mismatches"] = parity["code_mismatches"]
             out["parity"] = parity
+            if world == 1 and getattr(wl, "oracle_seconds", None):
+                out["parity"]["oracle_full_batch_images_per_s"] = wl.B / wl.oracle_seconds   # cold, fresh output arrays
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
         print(json.dumps(out), flush=True)
