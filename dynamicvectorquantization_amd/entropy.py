@@ -38,3 +38,23 @@ class Entropy(nn.Sequential):
             _lib.check(_lib.lib.dvq_entropy_map_f32(x.data_ptr(), B, H, W, 16, out.data_ptr(),
                                                     _lib.stream_ptr(x.device)), "dvq_entropy_map_f32")
         return out
+
+
+def calibrate_thresholds(batches, patch_size=16):
+    """The offline table DualGrainFixedEntropyRouter reads (reference scripts/tools/calculate_entropy_thresholds.py:
+    92-110): patch entropies of every image of an iterable of [B, 3, H, W] GPU batches, sorted; threshold "k"
+    (k = 1 .. 99) = sorted[(size * k) // 100].  Returns the dict the reference dumps as JSON (keys are strings).
+    The entropy map is the fused kernel; sorting stays on the GPU."""
+    vals = []
+    ent = None
+    for x in batches:
+        if ent is None:
+            ent = Entropy(patch_size, x.shape[-1], x.shape[-2])
+        vals.append(ent(x).reshape(-1))
+    if not vals:
+        raise ValueError("calibrate_thresholds: no images")
+    allv, _ = torch.sort(torch.cat(vals))
+    size = allv.numel()
+    idx = torch.tensor([(size * (i + 1)) // 100 for i in range(99)], device=allv.device)
+    picked = allv[idx].cpu().tolist()
+    return {str(i + 1): float(picked[i]) for i in range(99)}

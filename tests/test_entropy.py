@@ -62,3 +62,29 @@ def test_fused_entropy_full_batch(dev):
         b = entropy_map(x, chunk=8)
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
     assert np.array_equal((a > 1.6777750253677368).cpu().numpy(), noisy)
+
+
+@pytest.mark.gpu
+def test_threshold_calibration_matches_reference_procedure(dev):
+    """reference scripts/tools/calculate_entropy_thresholds.py:92-110 on synthetic images: np.sort of all patch
+    entropies, threshold k = sorted[(size * k) // 100]; a router built from the table at ratio r sends ~r of the
+    patches to the fine grain"""
+    import json
+    import os
+    import tempfile
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.entropy import Entropy, calibrate_thresholds
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    imgs = [torch.from_numpy(synth.images_flat_noise(5100 + i, 8, p_noise=0.3 + 0.1 * i)[0]).to(dev) for i in range(3)]
+    table = calibrate_thresholds(imgs)
+    ent = np.sort(np.concatenate([Entropy(16, 256, 256)(x).reshape(-1).cpu().numpy() for x in imgs]))
+    assert list(table.keys()) == [str(k) for k in range(1, 100)]
+    for k in (1, 25, 50, 75, 99):
+        assert table[str(k)] == float(ent[(ent.size * k) // 100])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "thr.json")
+        json.dump(table, open(path, "w"))
+        r = DualGrainFixedEntropyRouter(path, 0.25)                 # key "75": the top quarter of the patches is fine
+        gate = r(entropy=torch.from_numpy(ent.reshape(1, 1, -1).copy()).to(dev))
+        frac = float(gate[..., 1].float().mean())
+        assert abs(frac - 0.25) < 0.02, frac
