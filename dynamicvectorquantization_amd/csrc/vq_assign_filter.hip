@@ -1082,8 +1082,11 @@ __device__ __forceinline__ unsigned long long order_key(float d, int code)
     return ((unsigned long long)u << 32) | (unsigned)code;
 }
 
+#ifndef DVQ_RES_WAVES
+#define DVQ_RES_WAVES 4          // waves per resolver workgroup (they split the code tiles)
+#endif
 template <int D>
-__global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
+__global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
     const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
@@ -1102,7 +1105,10 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     __shared__ unsigned long long best[RES_SLOTS];
     __shared__ int misc[4];                           // [0] candidate count, [1] rewrite count
     __shared__ int rewrite[RES_SLOTS];
-    __shared__ double red[4];
+    constexpr int RW = DVQ_RES_WAVES;
+    __shared__ double red[RW];
+    constexpr int RB = D * 4 + 32;                           // bytes per record (rec_bytes(D))
+    __shared__ __attribute__((aligned(16))) char srec[RES_SLOTS * RB];   // this workgroup's records, read from HBM / L2 once
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1120,13 +1126,19 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     }
     const int T = dvq_num_tiles(K);
     int tps = (T + nslice - 1) / nslice;                        // tiles per slice, a multiple of 4
-    tps = (tps + 3) & ~3;
+    tps = (tps + RW - 1) / RW * RW;
     const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
 
+    {
+        const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
+        const f32x4 *src = (const f32x4 *)(records + (size_t)base * RB);
+        for (int i = tid; i < nlive * (RB / 16); i += RW * 64) ((f32x4 *)srec)[i] = src[i];
+    }
+    __syncthreads();
     const bool live = base + c < total;
-    const char *rec = records + (size_t)(live ? base + c : base) * rec_bytes(D);
+    const char *rec = srec + (live ? c : 0) * RB;
     f16x8 zh[S16];
 #pragma unroll
     for (int s = 0; s < S16; ++s) {                    // same RNE f32 -> f16 conversion as pass 1
@@ -1185,11 +1197,11 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         const int tw = t_begin + wave;
         if (tw < t_end) {
             fetch(tw, a0, e0);
-            for (int t = tw; t < t_end; t += 8) {
-                if (t + 4 < t_end) fetch(t + 4, a1, e1);
+            for (int t = tw; t < t_end; t += 2 * RW) {
+                if (t + RW < t_end) fetch(t + RW, a1, e1);
                 score(t, a0, e0);
-                if (t + 8 < t_end) fetch(t + 8, a0, e0);
-                if (t + 4 < t_end) score(t + 4, a1, e1);
+                if (t + 2 * RW < t_end) fetch(t + 2 * RW, a0, e0);
+                if (t + RW < t_end) score(t + RW, a1, e1);
             }
         }
     }
@@ -1199,10 +1211,10 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     const int ncand = overflow ? 0 : ncand_raw;
 
     // ---- exact chains: one thread per (token, candidate)
-    for (int i = tid; i < ncand; i += 256) {
+    for (int i = tid; i < ncand; i += RW * 64) {
         const unsigned pc = cand[i];
         const int sl = (int)(pc >> 20), code = (int)(pc & 0xFFFFFu);
-        const char *r2 = records + (size_t)(base + sl) * rec_bytes(D);
+        const char *r2 = srec + sl * RB;
         const f32x4 *zv = (const f32x4 *)r2;
         const f32x4 *ev = (const f32x4 *)(E + (size_t)code * D);
         const float xn = ((const RecMeta *)(r2 + (size_t)D * 4))->xn;
@@ -1248,7 +1260,7 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
 
     // ---- winners; slots whose winner differs from pass 1 are rewritten
     if (tid < RES_SLOTS && base + tid < total) {
-        const char *r2 = records + (size_t)(base + tid) * rec_bytes(D);
+        const char *r2 = srec + tid * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
             int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
@@ -1266,10 +1278,10 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
     __syncthreads();
     const int nrew = misc[1];
     double dsum = 0.0;
-    for (int i = wave; i < nrew; i += 4) {            // one wave per rewritten token, 4 channels per lane
+    for (int i = wave; i < nrew; i += RW) {           // one wave per rewritten token, 4 channels per lane
         const int sl = rewrite[i] >> 20, win = rewrite[i] & 0xFFFFF;
         const bool take_back_only = win == 0xFFFFF;   // token went to the exact list
-        const char *r2 = records + (size_t)(base + sl) * rec_bytes(D);
+        const char *r2 = srec + sl * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         const long n = m2.n;
         const int rep = m2.rep;
@@ -1305,7 +1317,12 @@ __global__ __launch_bounds__(256, 2) void vq_resolve_kernel(
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
-        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) tot += red[w];
+            partials[blockIdx.x] = tot;
+        }
     }
 }
 
@@ -1693,7 +1710,7 @@ static int launch_resolver(const char *img, const DvqF16Meta *meta, const float 
                            const FilterWs &w, int Wout, hipStream_t st)
 {
     const int nslice = resolver_slices(K);
-    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(w.cap / RES_SLOTS, nslice), dim3(256), 0, st, img, meta,
+    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img, meta,
                        en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
                        w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout);
     return (int)hipGetLastError();
