@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="consecutive steps (independent batches) are issued round-robin on this many HIP streams, each "
+                         "with its own outputs / workspace / exchange buffers, so a step's latency-bound tail (resolver, "
+                         "list kernel, counter zero, exchange) runs under the next batch's pass 1; 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -212,6 +216,11 @@ def tile_images(base, B):
     return torch.cat(parts, 0)[:B].contiguous()
 
 
+class Slot:
+    """one set of output tensors (and, for N > 1, exchange buffers) bound to one HIP stream"""
+    pass
+
+
 class WeakDual:
     """BASELINE configs[2]: entropy router + dual routing + VectorQuantize2 assign, B images per rank"""
     name = "dual"
@@ -236,58 +245,65 @@ class WeakDual:
         self.ent = tile_images(t(synth.entropy_map(5903, b0, H // 2, W // 2, image_offset=off)), B)
         self.E = t(self.E_np)
         self.prep = _CodebookPrep()
-        # preallocated outputs: the step allocates nothing
-        self.h_dual = torch.empty_like(self.h_fine) if a.path == "select" else None
-        self.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
-        self.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        self.zq = torch.empty_like(self.h_fine)
-        self.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-        self.loss = torch.empty(2, dtype=torch.float32, device=dev)
-        self.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+        # preallocated outputs, one set per stream slot: the step allocates nothing
+        self.slots = [self.new_slot() for _ in range(a.streams)]
+
+    def new_slot(self):
+        import torch
+        o = Slot()
+        B, H, W, dev = self.B, self.H, self.W, self.dev
+        o.h_dual = torch.empty_like(self.h_fine) if self.a.path == "select" else None
+        o.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
+        o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        o.zq = torch.empty_like(self.h_fine)
+        o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        o.loss = torch.empty(2, dtype=torch.float32, device=dev)
+        o.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+        return o
 
     def describe(self):
         return ("BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, entropy gate + "
                 "dual routing + VectorQuantize2 assign (quant_conv not in the path)" % (self.B, self.K))
 
-    def step(self, ev=None):
+    def step(self, o, ev=None):
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
         from dynamicvectorquantization_amd.router import route_select_dual_entropy
         if self.a.path == "select":
             route_select_dual_entropy(self.ent, THR_R05, self.h_coarse, self.h_fine,
-                                      out=(self.h_dual, self.grain, self.cmask, self.gate))
+                                      out=(o.h_dual, o.grain, o.cmask, o.gate))
             if ev:
                 ev[0].record()
-            vq_assign(self.h_dual, self.E, self.prep, self.cmask, beta=0.25, mode=self.mode,
-                      out=(self.zq, self.codes, self.loss))
+            vq_assign(o.h_dual, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode,
+                      out=(o.zq, o.codes, o.loss))
         else:
             if ev:
                 ev[0].record()
             vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep, entropy=self.ent, threshold=THR_R05,
                                   beta=0.25, mode=self.mode,
-                                  out=(self.zq, self.codes, self.loss, self.grain, self.cmask, self.gate))
+                                  out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate))
         if ev:
             ev[1].record()
-        return self.codes, self.grain, self.loss
+        return o.codes, o.grain, o.loss
 
-    def dominant(self, ev):
+    def dominant(self, o, ev):
         """the dominant kernel alone (pass 1 of the assign), same launch geometry"""
         from dynamicvectorquantization_amd import _lib
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
         if self.a.mode == "exact":
             ev[0].record()
-            vq_assign(self.h_dual if self.h_dual is not None else self.h_fine, self.E, self.prep_dom, self.cmask,
-                      beta=0.25, mode=_lib.MODE_EXACT, out=(self.zq, self.codes, self.loss))
+            vq_assign(o.h_dual if o.h_dual is not None else self.h_fine, self.E, self.prep_dom, o.cmask,
+                      beta=0.25, mode=_lib.MODE_EXACT, out=(o.zq, o.codes, o.loss))
             ev[1].record()
         elif self.a.path == "select":
             ev[0].record()
-            vq_assign(self.h_dual, self.E, self.prep_dom, self.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                      out=(self.zq, self.codes, None))
+            vq_assign(o.h_dual, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                      out=(o.zq, o.codes, None))
             ev[1].record()
         else:
             ev[0].record()
             vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep_dom, entropy=self.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                                  out=(self.zq, self.codes, None, self.grain, self.cmask, self.gate))
+                                  out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate))
             ev[1].record()
 
     def dominant_kernel_name(self):
@@ -295,7 +311,7 @@ class WeakDual:
             return "vq_assign_exact_kernel<256>"
         return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
 
-    def parity(self):
+    def parity(self, slot):
         """the step's outputs, still in HBM, against the oracle on ALL images of this rank"""
         import numpy as np
 
@@ -307,14 +323,14 @@ class WeakDual:
         osel = oracle.route_select_dual(og, hc, hf)
         o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
         self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
-        codes = self.codes.cpu().numpy().reshape(self.B, -1)
+        codes = slot.codes.cpu().numpy().reshape(self.B, -1)
         ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
         return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
-                "zq_mismatches": int((self.zq.cpu().numpy() != o["zq"]).sum()),
-                "grain_mismatches": int((self.grain.cpu().numpy() != osel["indices"]).sum()),
-                "mask_mismatches": int((self.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
-                "gate_mismatches": int((self.gate.cpu().numpy() != og).sum()),
-                "loss_rel_err": abs(float(self.loss[1]) - ol) / abs(ol)}
+                "zq_mismatches": int((slot.zq.cpu().numpy() != o["zq"]).sum()),
+                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
+                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
+                "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum()),
+                "loss_rel_err": abs(float(slot.loss[1]) - ol) / abs(ol)}
 
 
 class StrongTriple:
@@ -349,53 +365,60 @@ class StrongTriple:
         self.router.load_state_dict(sd)
         self.router = self.router.to(dev).eval()
         self.prep = _CodebookPrep()
-        self.h_triple = torch.empty_like(self.h_fine) if a.path == "select" else None
-        self.grain = torch.empty((B, 8, 8), dtype=torch.int64, device=dev)
-        self.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        self.zq = torch.empty_like(self.h_fine)
-        self.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-        self.loss = torch.empty(2, dtype=torch.float32, device=dev)
-        self.logits = None
+        self.slots = [self.new_slot() for _ in range(a.streams)]
+
+    def new_slot(self):
+        import torch
+        o = Slot()
+        B, H, W, dev = self.B, self.H, self.W, self.dev
+        o.h_triple = torch.empty_like(self.h_fine) if self.a.path == "select" else None
+        o.grain = torch.empty((B, 8, 8), dtype=torch.int64, device=dev)
+        o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        o.zq = torch.empty_like(self.h_fine)
+        o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        o.loss = torch.empty(2, dtype=torch.float32, device=dev)
+        o.logits = None
+        return o
 
     def describe(self):
         return ("BASELINE configs[3]: triple granularity F=32/16/8, global B=%d split image-parallel (%d on this "
                 "rank), 32x32x256 latents, K=%d, fused feature-router gate + triple routing + VectorQuantize2 assign "
                 "(quant_conv not in the path)" % (self.Bglobal, self.B, self.K))
 
-    def step(self, ev=None):
+    def step(self, o, ev=None):
         import torch
 
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
         from dynamicvectorquantization_amd.router import route_select_triple
         with torch.no_grad():
-            self.logits = self.router(h_fine=self.h_fine, h_median=self.h_median, h_coarse=self.h_coarse)
+            o.logits = self.router(h_fine=self.h_fine, h_median=self.h_median, h_coarse=self.h_coarse)
             if ev:
                 ev[0].record()
             if self.a.path == "select":
-                route_select_triple(self.logits, self.h_coarse, self.h_median, self.h_fine,
-                                    out=(self.h_triple, self.grain, self.cmask))
-                vq_assign(self.h_triple, self.E, self.prep, self.cmask, beta=0.25, mode=self.mode,
-                          out=(self.zq, self.codes, self.loss))
+                route_select_triple(o.logits, self.h_coarse, self.h_median, self.h_fine,
+                                    out=(o.h_triple, o.grain, o.cmask))
+                vq_assign(o.h_triple, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode,
+                          out=(o.zq, o.codes, o.loss))
             else:
-                vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep, self.logits,
+                vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep, o.logits,
                                         beta=0.25, mode=self.mode,
-                                        out=(self.zq, self.codes, self.loss, self.grain, self.cmask))
+                                        out=(o.zq, o.codes, o.loss, o.grain, o.cmask))
         if ev:
             ev[1].record()
-        return self.codes, self.grain, self.loss
+        return o.codes, o.grain, o.loss
 
-    def dominant(self, ev):
+    def dominant(self, o, ev):
         from dynamicvectorquantization_amd import _lib
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
         ev[0].record()
         if self.a.path == "select" or self.a.mode == "exact":
-            vq_assign(self.h_triple if self.h_triple is not None else self.h_fine, self.E, self.prep_dom, self.cmask,
+            vq_assign(o.h_triple if o.h_triple is not None else self.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT if self.a.mode == "exact" else _lib.MODE_FILTER_PASS1,
-                      out=(self.zq, self.codes, self.loss if self.a.mode == "exact" else None))
+                      out=(o.zq, o.codes, o.loss if self.a.mode == "exact" else None))
         else:
-            vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep_dom, self.logits,
+            vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep_dom, o.logits,
                                     beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                                    out=(self.zq, self.codes, None, self.grain, self.cmask))
+                                    out=(o.zq, o.codes, None, o.grain, o.cmask))
         ev[1].record()
 
     def dominant_kernel_name(self):
@@ -403,22 +426,22 @@ class StrongTriple:
             return "vq_assign_exact_kernel<256>"
         return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
 
-    def parity(self):
+    def parity(self, slot):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
         itself is a 1e-4 tolerance kernel, covered by tests/)"""
         from oracle import oracle
         oracle.build()
-        lg = self.logits.cpu().numpy()
+        lg = slot.logits.cpu().numpy()
         hc, hm, hf = (x.cpu().numpy() for x in (self.h_coarse, self.h_median, self.h_fine))
         osel = oracle.route_select_triple(lg, hc, hm, hf)
         o = oracle.vq_assign_nchw(osel["h_triple"], self.E_np, osel["codebook_mask"])
-        codes = self.codes.cpu().numpy().reshape(self.B, -1)
+        codes = slot.codes.cpu().numpy().reshape(self.B, -1)
         ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
         return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
-                "zq_mismatches": int((self.zq.cpu().numpy() != o["zq"]).sum()),
-                "grain_mismatches": int((self.grain.cpu().numpy() != osel["indices"]).sum()),
-                "mask_mismatches": int((self.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
-                "loss_rel_err": abs(float(self.loss[1]) - ol) / abs(ol)}
+                "zq_mismatches": int((slot.zq.cpu().numpy() != o["zq"]).sum()),
+                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
+                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
+                "loss_rel_err": abs(float(slot.loss[1]) - ol) / abs(ol)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -449,28 +472,36 @@ def run_rank(a):
     wl = (WeakDual if a.scaling == "weak" else StrongTriple)(a, rank, world, dev)
     wl.prep_dom = _CodebookPrep()
     B, K, D, H, W = wl.B, wl.K, wl.D, wl.H, wl.W
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    # two exchange objects (two sets of wire / result buffers): the all-gather of step i is completed at step i + 2,
-    # so it has two steps' worth of kernels to hide under (a 0.6-MB all-gather is latency-bound on xGMI, and RCCL's
-    # kernel competes for CUs with a pass 1 that fills the chip)
-    xchs = [CodeExchange(wl.codes, wl.grain, K, wl.Bglobal, numel_per_image=H * W * D) for _ in range(2)] if world > 1 else []
+    # stream slots: step i runs on slot i % S (own stream, outputs, workspace).  Exchange objects (wire / result buffers):
+    # max(2, S), so the all-gather of step i is completed when its object comes round again, two or more steps later
+    # (a 0.6-MB all-gather is latency-bound on xGMI, and RCCL's kernel competes for CUs with a pass 1 that fills the chip)
+    S = max(1, a.streams)
+    streams = [torch.cuda.current_stream(dev)] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
+    nx = max(2, S)
+    xchs = ([CodeExchange(wl.slots[0].codes, wl.slots[0].grain, K, wl.Bglobal, numel_per_image=H * W * D) for _ in range(nx)]
+            if world > 1 else [])
     nstep = [0]
 
     def step(i=None):
-        codes, grain, loss = wl.step(ev[i] if i is not None else None)
-        if xchs:
-            x = xchs[nstep[0] & 1]
-            nstep[0] += 1
-            x.finish()                     # exchange of two steps ago: stream wait + unpack kernel
-            x.start(codes, grain, loss)    # pack kernel + async all-gather
+        n = nstep[0]
+        nstep[0] += 1
+        with torch.cuda.stream(streams[n % S]):
+            codes, grain, loss = wl.step(wl.slots[n % S])
+            if xchs:
+                x = xchs[n % nx]
+                x.finish()                     # this object's previous exchange: stream wait + unpack kernel
+                x.start(codes, grain, loss)    # pack kernel + async all-gather
 
     def fence():
-        for x in xchs:
-            x.finish()                     # the last exchanges complete inside the timed region
+        for j, x in enumerate(xchs):
+            with torch.cuda.stream(streams[j % S]):
+                x.finish()                 # the last exchanges complete inside the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()
+    torch.cuda.synchronize()               # codebook image built before a second stream reads it
     for _ in range(a.spinup):              # clock / power-state ramp, see --spinup
         step()
     for _ in range(a.warmup):
@@ -494,7 +525,11 @@ def run_rank(a):
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(max(1, usable_cpus() // world))   # ranks share the host cores
         except Exception:
             pass
-        parity = wl.parity()
+        last = wl.slots[(nstep[0] - 1) % S]
+        parity = wl.parity(last)
+        # the other stream slots ran the same batch: their outputs must be the same bits
+        parity["slot_mismatches"] = int(sum(1 for o in wl.slots if o is not last and nstep[0] > S and not (
+            torch.equal(o.codes, last.codes) and torch.equal(o.zq, last.zq) and torch.equal(o.grain, last.grain))))
         if world > 1:
             keys = sorted(k for k in parity if k != "loss_rel_err")
             tot = torch.tensor([parity[k] for k in keys], dtype=torch.int64, device=dev)
@@ -503,18 +538,25 @@ def run_rank(a):
             dist.all_reduce(lr, op=dist.ReduceOp.MAX)
             parity = dict(zip(keys, (int(v) for v in tot.tolist())), loss_rel_err=float(lr.item()))
             if xchs:                       # the gathered global tensors agree with the local shard
-                xch = xchs[(nstep[0] - 1) & 1]
+                xch = xchs[(nstep[0] - 1) % nx]
                 g_codes, g_grain, _ = xch.result()
                 s0 = sum(b for b in xch.shard_sizes[:rank])
-                parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], wl.codes) and
-                                             torch.equal(g_grain[s0:s0 + B], wl.grain))
+                parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], last.codes) and
+                                             torch.equal(g_grain[s0:s0 + B], last.grain))
 
-    op_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))       # the assign op (all its kernels)
+    # the assign op (all its kernels) and, below, its dominant kernel alone: HIP events on the launch stream, serial,
+    # after the timed region (inside it the ops of consecutive steps overlap across the stream slots)
+    nev = min(a.steps, 200)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
+    for i in range(-3, nev):
+        wl.step(wl.slots[0], ev[i] if i >= 0 else None)
+    torch.cuda.synchronize()
+    op_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     # the dominant kernel alone, HIP events on the launch stream, after the timed region
-    dom_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    dom_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    for i in range(-3, a.steps):
-        wl.dominant(dom_ev[i] if i >= 0 else scratch)
+    for i in range(-3, nev):
+        wl.dominant(wl.slots[0], dom_ev[i] if i >= 0 else scratch)
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
     N = B * H * W
@@ -552,7 +594,7 @@ def run_rank(a):
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
-                       "spinup_steps": a.spinup,
+                       "spinup_steps": a.spinup, "streams": S,
                        "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
                                       "per step" % world},
             "roofline": roof,
