@@ -118,7 +118,15 @@ struct DvqRouted {
     long long *indices_out;   // outputs the dense pass 1 writes itself (null: the prepass wrote them)
     float *cmask_out;
     long long *gate_out;
+    const int *wgd;           // row-complete de-duplicated form (non-null): per workgroup slot [B][HWout / 128] four ints
+                              // {first row of cells, rows of cells, unique tokens, 0}, written by the prepass; rows = 0:
+                              // slot unused.  Downstream (resolver, list kernel) sees the dense view (dense = 1).
 };
+
+// row-complete de-duplication packs whole rows of cells into one pass-1 workgroup: at most this many unique tokens
+// (its 4 waves x 32 token lanes) and this many output positions (the z_q staging buffer in LDS)
+#define DVQ_RD_MAX_TOKENS 128
+#define DVQ_RD_MAX_POS 512
 
 // argmax over the G gate values of one cell with torch semantics (first maximal value wins, NaN counts as the
 // maximum); mode 2: entropy > thr (NaN compares false -> 0)

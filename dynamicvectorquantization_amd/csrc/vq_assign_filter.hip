@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // sits in the encoder branch that won its cell (per-lane source pointer and channel stride); outputs as dense.
 // M16: the code loop on v_mfma_f32_16x16x32_f16 (image "16"): same flops per cycle, but the part holds a higher clock
 // under this shape when power-limited; the latents' fragments are permuted into its operand order once per wave.
-template <int D, bool SEL, bool M16>
+template <int D, int SEL, bool M16>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -265,13 +265,28 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
         for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    // SEL == 2, row-complete de-duplication: this workgroup owns dd_ng whole rows of cells of ONE image (slot
+    // tile_id of the prepass's table), dd_U unique tokens in its first ceil(dd_U / 32) waves
+    int dd_g0 = 0, dd_ng = 0, dd_U = 0;
+    if (SEL == 2) {
+        const int *dsc = rv.wgd + 4 * (size_t)tile_id;
+        dd_g0 = __builtin_amdgcn_readfirstlane(dsc[0]);
+        dd_ng = __builtin_amdgcn_readfirstlane(dsc[1]);
+        dd_U = __builtin_amdgcn_readfirstlane(dsc[2]);
+        if (dd_ng == 0) {                                    // unused slot (before any DMA or barrier)
+            if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
+            return;
+        }
+    }
+    const bool wave_active = (SEL != 2) || (wave * 32 < dd_U);      // wave-uniform
     issue(0);
     issue(1);
     issue(2);
 
-    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
     const int n_raw = (tile_id * NW + wave) * 32 + c;
-    const int n = (n_raw < N) ? n_raw : -1;
+    int n = (n_raw < N) ? n_raw : -1;
+    int dd_lp = 0, dd_rep = 1;                               // SEL == 2: top-left position inside the workgroup's rows; copies per edge
     auto token_base = [&]() -> size_t {
         const long nn = (n >= 0) ? n : N - 1;
         const long bimg = nn / HW;
@@ -280,7 +295,58 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     };
     float zf[S16][8];
     float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell
-    if (SEL) {
+    if (SEL == 2) {
+        // unique tokens of the workgroup's rows of cells in row-major order of their top-left output positions (a wave's
+        // lanes then read mostly one row of one source: two or three 128-B lines per load instruction), through a token
+        // table in LDS (ring slot 3: its first DMA is issued after the loop's first barrier).  Thread t < rows * wc
+        // owns (output row t / wc, cell t % wc) and lists the tokens of that cell whose top-left corner is in that row.
+        const int wc = rv.wc, SC = rv.sub[rv.G - 1];
+        const int b = tile_id / (HW / 128);
+        const int nrc = dd_ng * SC * wc;                     // <= 256 (DVQ_RD_MAX_POS / 2)
+        int *tokl = (int *)(lds + 3 * IMG_BYTES);
+        int g = 0, cnt = 0;
+        const int yl_t = tid / wc, cx_t = tid - yl_t * wc;
+        if (tid < nrc) {
+            g = (int)rv.indices[((size_t)b * rv.hc + dd_g0 + yl_t / SC) * wc + cx_t];
+            cnt = ((yl_t % SC) % rv.rep[g] == 0) ? rv.sub[g] : 0;
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) tokl[DVQ_RD_MAX_TOKENS + wave] = inc;
+        __syncthreads();
+        {
+            int start = inc - cnt;
+            for (int w2 = 0; w2 < wave; ++w2) start += tokl[DVQ_RD_MAX_TOKENS + w2];
+            for (int q = 0; q < cnt; ++q) tokl[start + q] = (yl_t << 12) | (cx_t << 6) | (q << 2) | g;
+        }
+        __syncthreads();
+        const int u_raw = wave * 32 + c;
+        const bool has = u_raw < dd_U;
+        const int e = tokl[has ? u_raw : dd_U - 1];
+        const int yl = e >> 12, cx = (e >> 6) & 63, kx = (e >> 2) & 15, tg = e & 3;
+        const int rep = rv.rep[tg];
+        const int x = cx * SC + kx * rep, y = dd_g0 * SC + yl;
+        dd_lp = yl * rv.Wout + x;
+        dd_rep = rep;
+        n = has ? (b * HW + y * rv.Wout + x) : -1;
+        sel_mask = 1.0f / (float)(rep * rep);
+        // (a wave without tokens reads one cached line 128 times instead of branching around the loads: the straight-line
+        // prologue is what keeps this kernel free of spills)
+        int stride_l;
+        const float *zp = dvq_dense_source(rv, b, y, x, tg, stride_l) + (size_t)8 * h * stride_l;
+        if (!wave_active) { zp = E; stride_l = 0; }
+        const size_t st = (size_t)stride_l;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
+        __builtin_amdgcn_s_setprio(0);
+    } else if (SEL == 1) {
         // the router select, fused in: grain of this position's cell straight from the gate, source = the branch
         // that won the cell; indices / codebook_mask / the int64 gate are written here as by-products
         const int nn = (n >= 0) ? n : (int)(N - 1);
@@ -377,6 +443,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         zeta2 += __shfl_xor(zeta2, 32);
         thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     }
+    // SEL == 2: the two per-lane values only the epilogue needs sit out the code loop in LDS (the loop has no VGPR to spare)
+    int *dd_stash = (int *)(lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048) + lane;   // this wave's own scratch
+    if (SEL == 2) {
+        *dd_stash = dd_lp * 8 + dd_rep;
+        asm volatile("" ::: "memory");
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
@@ -385,6 +457,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     int code;
     if constexpr (!M16) {
         for (int t = 0; t < T; ++t) {
+            if (SEL == 2 && !wave_active) {                  // no tokens in this wave: keep its share of the ring DMA going
+                if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue(t + 3);
+                continue;
+            }
             // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
             const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
             f32x16 acc;
@@ -465,6 +544,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         float b1[2] = {-__builtin_inff(), -__builtin_inff()}, b2[2] = {-__builtin_inff(), -__builtin_inff()};
         int bt[2] = {0, 0};
         for (int t = 0; t < T; ++t) {
+            if (SEL == 2 && !wave_active) {                  // no tokens in this wave: keep its share of the ring DMA going
+                if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue(t + 3);
+                continue;
+            }
             const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16;
             f32x4 acc16[2][2];
 #pragma unroll
@@ -554,6 +640,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         second = (c >> 4) ? y1 : y0;
         code = (c >> 4) ? c1 : c0;
     }
+    if (SEL == 2) {
+        asm volatile("" ::: "memory");
+        const int v = *dd_stash;
+        dd_lp = v >> 3;
+        dd_rep = v & 7;
+    }
     const float thr = best - thr2W;
     const bool final_ok = (best - second) > thr2W;
     const bool valid = n >= 0;
@@ -568,15 +660,120 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     int slot_raw = 0;
     if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
     if (valid && hopeless && h == 0) {
-        int pos = atomicAdd(&counters[1], 1);
-        exact_list[pos] = n;
+        if (SEL == 2) {                                      // the list kernel sees the dense view: every covered position
+            for (int ry = 0; ry < dd_rep; ++ry)
+                for (int rx = 0; rx < dd_rep; ++rx) {
+                    int pos = atomicAdd(&counters[1], 1);
+                    exact_list[pos] = n + ry * rv.Wout + rx;
+                }
+        } else {
+            int pos = atomicAdd(&counters[1], 1);
+            exact_list[pos] = n;
+        }
     }
     float lsum = 0.0f;
+    if (SEL == 2) {
+        // row-complete writers: every value goes through LDS so that z_q and the codes leave the workgroup as whole,
+        // contiguous rows (a channel's positions of this workgroup are P consecutive floats in HBM), however the
+        // unique tokens were spread over lanes and however many positions each one covers.
+        const int Wo = rv.Wout, SC = rv.sub[rv.G - 1];
+        const int P = dd_ng * SC * Wo, P4 = P >> 2;          // P <= DVQ_RD_MAX_POS, multiple of 4
+        const int b = tile_id / (HW / 128);
+        const size_t p0 = (size_t)dd_g0 * SC * Wo;           // first position of the workgroup inside the image
+        const bool wr = valid && !hopeless;
+        const float m = sel_mask * (float)(dd_rep * dd_rep); // mask x copies = 1 (the resolver takes back mask[n] * rep^2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // every wave is out of the code loop: ring and seeds are free
+        int *cl_ = (int *)(lds + NBUF * IMG_BYTES);          // codes per local position (seed area: 4 KiB)
+        if (valid && h == 0) {
+            const int cw = hopeless ? 0 : code;              // (hopeless tokens: the list kernel rewrites their positions)
+            for (int ry = 0; ry < dd_rep; ++ry)
+                for (int rx = 0; rx < dd_rep; ++rx) cl_[dd_lp + ry * Wo + rx] = cw;
+        }
+        if (zq != nullptr) {
+            const float *ep = E + (size_t)(wr ? code : 0) * D + 8 * h;
+            // staging buffer [2][16 channels][P] floats at the start of LDS.  Addresses are carried as running values made
+            // opaque once per step: left to itself the compiler precomputes all 16 steps' pointers and spills
+            unsigned sw = (unsigned)((8 * h) * P + dd_lp);                  // float index of this lane's first staged value, buffer 0
+            unsigned sr = (unsigned)(wave * P + 4 * lane);                  // copy-out: channel `wave`, float4 `lane`
+            size_t go = (size_t)b * D * HW + p0 + (size_t)wave * HW + 4 * lane;
+            const size_t gstep = (size_t)4 * HW;
+            float *const stage = (float *)lds;
+            f32x4 eg[2], en[2];
+            eg[0] = *(const f32x4 *)(ep);
+            eg[1] = *(const f32x4 *)(ep + 4);
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                asm volatile("" : "+v"(sw), "+v"(sr), "+v"(go), "+v"(lsum));
+                if (s + 1 < S16) {
+                    en[0] = *(const f32x4 *)(ep + 16 * (s + 1));
+                    en[1] = *(const f32x4 *)(ep + 16 * (s + 1) + 4);
+                }
+                float *sb = stage + sw + ((s & 1) ? 16 * P : 0);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float e = eg[j >> 2][j & 3];
+                    const float diff = __fsub_rn(e, zf[s][j]);
+                    v[j] = __fadd_rn(zf[s][j], diff);
+                    lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                }
+                if (wr) {
+                    if (dd_rep == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sb[j * P] = v[j];
+                    } else if (dd_rep == 2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const f32x2 vv = {v[j], v[j]};
+                            *(f32x2 *)(sb + j * P) = vv;
+                            *(f32x2 *)(sb + j * P + Wo) = vv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const f32x4 vv = {v[j], v[j], v[j], v[j]};
+#pragma unroll
+                            for (int ry = 0; ry < 4; ++ry) *(f32x4 *)(sb + j * P + ry * Wo) = vv;
+                        }
+                    }
+                }
+                __syncthreads();                             // chunk s staged (the other buffer is being refilled meanwhile)
+                const float *rb = stage + sr + ((s & 1) ? 16 * P : 0);
+                float *gp = zq + go;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (lane < P4)
+                        __builtin_nontemporal_store(*(const f32x4 *)(rb + 4 * cc * P), (f32x4 *)(gp + cc * gstep));
+                    if (lane + 64 < P4)
+                        __builtin_nontemporal_store(*(const f32x4 *)(rb + 4 * cc * P + 256), (f32x4 *)(gp + cc * gstep + 256));
+                }
+                go += 4 * gstep;
+                eg[0] = en[0];
+                eg[1] = en[1];
+            }
+            if (!wr) lsum = 0.0f;
+        } else if (partials != nullptr && wr) {
+            const float *ep = E + (size_t)code * D + 8 * h;
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                const f32x4 e0 = *(const f32x4 *)(ep + 16 * s), e1 = *(const f32x4 *)(ep + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float diff = __fsub_rn(j < 4 ? e0[j & 3] : e1[j & 3], zf[s][j]);
+                    lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                }
+            }
+        }
+        __syncthreads();                                     // cl_ complete
+        long long *cb = codes + (size_t)b * HW + p0;
+        for (int i = tid; i < P; i += 256) cb[i] = (long long)cl_[i];
+    } else
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
-            const float m = SEL ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
+            const float m = (SEL != 0) ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
             constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
             // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
             // inside the loop on the per-lane pointer every one of the 128 stores became its own
@@ -615,8 +812,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         slot = undecided ? slot : -1;
         if (undecided && slot >= rec_cap) {                 // shard full: full exact evaluation instead; the
             if (h == 0) {                                   // provisional code / z_q written above are overwritten
-                int pos = atomicAdd(&counters[1], 1);       // by the exact-list kernel, the loss term is dropped here
-                exact_list[pos] = n;
+                for (int ry = 0; ry < dd_rep; ++ry)         // by the exact-list kernel, the loss term is dropped here
+                    for (int rx = 0; rx < dd_rep; ++rx) {   // (dd_rep = 1 unless SEL == 2)
+                        int pos = atomicAdd(&counters[1], 1);
+                        exact_list[pos] = n + ry * ((SEL == 2) ? rv.Wout : 0) + rx;
+                    }
             }
             lsum = 0.0f;
             slot = -1;
@@ -632,8 +832,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             }
             if (h == 0) {
                 RecMeta rm;
-                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = n; rm.prov = code;
-                rm.best = ~0ull; rm.rep = 1;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = (SEL == 2) ? (-1 - n) : n; rm.prov = code;
+                rm.best = ~0ull; rm.rep = dd_rep;
                 *(RecMeta *)(rec + (size_t)D * 4) = rm;
             }
         }
@@ -1263,9 +1463,18 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         const char *r2 = srec + tid * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
-            int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
-            exact_list[pos] = m2.tokid;               // pass 1's loss term for it is taken back below
-            pos = atomicAdd(&misc[1], 1);
+            if (m2.tokid >= 0) {
+                int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
+                exact_list[pos] = m2.tokid;               // pass 1's loss term for it is taken back below
+            } else {                                      // row-complete de-duplicated pass 1: the list kernel sees the
+                const int p0 = -1 - m2.tokid;             // dense view, so every covered position goes on the list
+                for (int ry = 0; ry < m2.rep; ++ry)
+                    for (int rx = 0; rx < m2.rep; ++rx) {
+                        int pos = atomicAdd(&counters[1], 1);
+                        exact_list[pos] = p0 + ry * Wout + rx;
+                    }
+            }
+            int pos = atomicAdd(&misc[1], 1);
             rewrite[pos] = (tid << 20) | 0xFFFFF;
         } else {
             int win = (int)(best[tid] & 0xFFFFFFFFu);
@@ -1647,13 +1856,13 @@ static FilterWs carve_ws(void *ws_extra, long N, int D)
     return w;
 }
 
-template <int D, bool SEL, bool M16>
+template <int D, int SEL, bool M16>
 static int launch_legacy_form(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                               const float *mask, int HW, int K, long N, float *zq, long long *codes,
                               double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st)
 {
     static unsigned long long done = 0;
-    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + (M16 ? 4 * 2048 : 0);
+    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + ((M16 || SEL == 2) ? 4 * 2048 : 0);
     int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, M16>, (int)shmem1, &done);
     if (rc) return rc;
     hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, M16>), dim3((unsigned)((N + 127) / 128)), dim3(256), shmem1, st,
@@ -1674,8 +1883,13 @@ static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta
     const bool m16 = dvq_mfma16_enabled();
     const char *img16 = img + dvq_img16_offset(K, D);
     if (rv != nullptr) {                                     // select fused in (rv->dense): legacy form only
-        return m16 ? launch_legacy_form<D, true, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
-                   : launch_legacy_form<D, true, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+        if constexpr (D == 256) {
+            if (rv->wgd != nullptr)                          // unique tokens only, rows of cells per workgroup
+                return m16 ? launch_legacy_form<D, 2, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
+                           : launch_legacy_form<D, 2, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+        }
+        return m16 ? launch_legacy_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
+                   : launch_legacy_form<D, 1, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
     }
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
@@ -1700,8 +1914,8 @@ static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta
         }
     }
     const DvqRouted none = {};
-    return m16 ? launch_legacy_form<D, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st)
-               : launch_legacy_form<D, false, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
+    return m16 ? launch_legacy_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st)
+               : launch_legacy_form<D, 0, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
 }
 
 template <int D>
@@ -1752,7 +1966,7 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     // routed + de-duplicated: always a low-register form; routed without de-duplication (rv->dense): the legacy
     // form with the select fused in unless DVQ_ROUTED_VARIANT picks a low-register one explicitly
     int variant = routed ? routed_variant() : ((force_wide || D != 256) ? -1 : dense_variant());
-    if (routed && rv->dense && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) == 0) variant = -1;
+    if (routed && rv->dense && (rv->wgd != nullptr || env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) == 0)) variant = -1;
     int rc, np1;
     if (variant < 0) {
         np1 = (int)((N + 127) / 128);
@@ -1838,13 +2052,18 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     // DVQ_ROUTED_DEDUP = 1: score unique tokens only (token tables from the prepass, low-register pass 1);
     // 0 (default DVQ_ROUTED_DEDUP_DEFAULT): one token per output position -- the select fused into the legacy
     // pass-1 kernel, which derives the grain from the gate itself: no prepass, no tables
-    const int dense = env_int("DVQ_ROUTED_DEDUP", DVQ_ROUTED_DEDUP_DEFAULT, 0, 1) ? 0 : 1;
-    const bool lowreg_dense = dense && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) != 0;
-    const bool need_prepass = !dense || exact || lowreg_dense;
+    // 2: unique tokens only, whole rows of cells per legacy pass-1 workgroup, z_q staged through LDS so that it leaves
+    //    as whole rows (D = 256, 32-wide output grid; anything else takes form 0)
+    int form = env_int("DVQ_ROUTED_DEDUP", DVQ_ROUTED_DEDUP_DEFAULT, 0, 2);
+    if (form == 2 && (exact || D != 256 || Wout != 32 || HWout % 128 != 0)) form = 0;
+    const bool rowdedup = form == 2;
+    const int dense = (form == 1) ? 0 : 1;
+    const bool lowreg_dense = dense && !rowdedup && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) != 0;
+    const bool need_prepass = !dense || exact || lowreg_dense || rowdedup;
     int rc = 0;
     if (need_prepass) {
         rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
-                                       imgstart, w.counters + 5, dense, st);
+                                       imgstart, w.counters + 5, rowdedup ? 2 : dense, st);
         if (rc) return rc;
     }
     DvqRouted rv{};
@@ -1852,6 +2071,7 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     rv.imgstart = imgstart; rv.tok = tok; rv.dense = dense;
     rv.indices = indices; rv.gate = gate; rv.gate_mode = gate_mode; rv.thr = thr;
     if (!need_prepass) { rv.indices_out = indices; rv.cmask_out = cmask; rv.gate_out = gate_out; }
+    rv.wgd = rowdedup ? (const int *)tok : nullptr;
     if (G == 2) {
         rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
         rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1;

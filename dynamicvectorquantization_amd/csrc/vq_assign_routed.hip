@@ -93,6 +93,35 @@ __global__ __launch_bounds__(256) void routed_prepass_kernel(
         }
         *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
     }
+    if (dense == 2) {
+        // row-complete de-duplicated form: whole rows of cells are packed greedily into pass-1 workgroups of
+        // <= DVQ_RD_MAX_TOKENS unique tokens and <= DVQ_RD_MAX_POS output positions.  A row of cells holds at most
+        // SC * W <= 128 tokens (the launcher checks W <= 128 / SC), so no workgroup is empty-handed and an image never
+        // needs more than HW / 128 of them (the dense grid); unused slots get rows = 0.
+        int *wgd = (int *)tok + (size_t)b * (HW / 128) * 4;
+        for (int cy = tid; cy < hc; cy += 256) {
+            int cnt = 0;
+            for (int cx = 0; cx < wc; ++cx) { const int sub = sub_of(grain[cy * wc + cx]); cnt += sub * sub; }
+            rowstart[cy] = cnt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int j = 0, g0 = 0;
+            const int maxwg = HW / 128;
+            while (g0 < hc && j < maxwg) {
+                int U = 0, ng = 0;
+                while (g0 + ng < hc && U + rowstart[g0 + ng] <= DVQ_RD_MAX_TOKENS && (ng + 1) * SC * W <= DVQ_RD_MAX_POS) {
+                    U += rowstart[g0 + ng];
+                    ++ng;
+                }
+                wgd[4 * j] = g0; wgd[4 * j + 1] = ng; wgd[4 * j + 2] = U; wgd[4 * j + 3] = 0;
+                ++j;
+                g0 += ng;
+            }
+            for (; j < maxwg; ++j) { wgd[4 * j] = 0; wgd[4 * j + 1] = 0; wgd[4 * j + 2] = 0; wgd[4 * j + 3] = 0; }
+        }
+        return;
+    }
     if (dense) return;                                        // the dense form needs no token table
     // tokens per output row (by top-left position), then an exclusive scan over the H rows
     const int per = (H + 255) / 256;

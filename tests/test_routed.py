@@ -31,7 +31,10 @@ def _check_dual(r, o_sel, o, B, beta=0.25, oracle_mod=None):
 # routed-op forms: ("dedup", v) = unique tokens only, low-register pass-1 variant v; ("fused", -1) = one token per
 # output position with the select fused into the legacy pass-1 kernel (the default); ("fused", v) = the same on a
 # low-register form; ("fused32", -1) = the default with the 32x32x16 code loop instead of 16x16x32
-FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1), ("fused32", -1)]
+# ("rows", -1) / ("rows32", -1) = unique tokens only, whole rows of cells per legacy pass-1 workgroup, z_q staged through
+# LDS (DVQ_ROUTED_DEDUP=2; D = 256 and a 32-wide output grid, other shapes take the fused form)
+FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1), ("fused32", -1),
+         ("rows", -1), ("rows32", -1)]
 
 
 @pytest.fixture(params=FORMS, ids=["%s%d" % f for f in FORMS])
@@ -40,9 +43,9 @@ def variant(request):
     from dynamicvectorquantization_amd import _lib
     kind, v = request.param
     assert _lib.lib.dvq_set_pass1_variant(-2, max(v, 0)) == 0
-    os.environ["DVQ_ROUTED_DEDUP"] = "1" if kind == "dedup" else "0"
+    os.environ["DVQ_ROUTED_DEDUP"] = "1" if kind == "dedup" else ("2" if kind.startswith("rows") else "0")
     os.environ["DVQ_ROUTED_DENSE_LOWREG"] = "1" if (kind == "fused" and v >= 0) else "0"
-    os.environ["DVQ_MFMA16"] = "0" if kind == "fused32" else "1"      # code loop of the legacy pass 1: 16x16x32 (default) / 32x32x16
+    os.environ["DVQ_MFMA16"] = "0" if kind.endswith("32") else "1"      # code loop of the legacy pass 1: 16x16x32 (default) / 32x32x16
     yield 0 if request.param == FORMS[0] else 1 + FORMS.index(request.param)
     _lib.lib.dvq_set_pass1_variant(-2, 0)
     os.environ.pop("DVQ_ROUTED_DEDUP", None)
@@ -119,7 +122,54 @@ def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
         _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
 
 
-@pytest.mark.parametrize("dedup", ["1", "0"])
+@pytest.mark.parametrize("m16", ["1", "0"])
+def test_rows_form_special_tokens(dev, oracle_mod, m16, monkeypatch):
+    """row-complete de-duplicated pass 1 (DVQ_ROUTED_DEDUP=2) on a 32-wide grid, dual and triple: NaN / Inf / huge
+    tokens in every branch (exact list: every covered position), zero tokens, all-coarse and all-fine images (8-row
+    and 2-row workgroups), codes-only and loss-only calls"""
+    from dynamicvectorquantization_amd import synth, _lib
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
+    monkeypatch.setenv("DVQ_ROUTED_DEDUP", "2")
+    monkeypatch.setenv("DVQ_MFMA16", m16)
+    t = _t(dev)
+    B, K, D = 6, 300, 256
+    E = synth.codebook_trained(K, D, seed=91)
+    E[7] = E[3]
+    hf, hm, hco = (synth.z_tokens(E, B, 32, 32, 92), synth.z_tokens(E, B, 16, 16, 93), synth.z_tokens(E, B, 8, 8, 94))
+    for a in (hf, hm, hco):
+        a[0, 5, 0, 0] = np.nan
+        a[1, :, 1, 1] = np.inf
+        a[2, 9, 2, 2] = -np.inf
+        a[3, :, 3, 3] *= np.float32(1e6)
+        a[4, :, 0, 1] = 0.0
+        a[5, :, 7, 7] = np.nan
+    lg = synth.grain_logits_triple(95, B, 8, 8)
+    lg[4] = np.array([1.0, 0.0, -1.0], dtype=np.float32)          # all coarse: 8 tokens per row of cells
+    lg[5] = np.array([-1.0, 0.0, 1.0], dtype=np.float32)          # all fine: 128 tokens per row of cells
+    prep = _CodebookPrep()
+    r = vq_assign_routed_triple(t(hco), t(hm), t(hf), t(E), prep, t(lg))
+    o_sel = oracle_mod.route_select_triple(lg, hco, hm, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_triple"], E, o_sel["codebook_mask"])
+    assert np.array_equal(r["indices"].cpu().numpy(), o_sel["indices"])
+    assert np.array_equal(r["codebook_mask"].cpu().numpy(), o_sel["codebook_mask"])
+    assert np.array_equal(r["codes"].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(r["zq"].cpu().numpy(), o["zq"], equal_nan=True)
+    assert prep.fallback_count()[1] > 0
+    # dual, clean data: all outputs, then codes-only and the op's loss against the oracle's
+    hf2, hc2 = synth.z_tokens(E, B, 32, 32, 96), synth.z_tokens(E, B, 16, 16, 97)
+    g2 = synth.grain_gate_dual(98, B, 16, 16)
+    g2[0] = np.array([1, 0]); g2[1] = np.array([0, 1])            # all coarse / all fine images
+    r2 = vq_assign_routed_dual(t(hc2), t(hf2), t(E), _CodebookPrep(), gate=t(g2))
+    o_sel = oracle_mod.route_select_dual(g2, hc2, hf2)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+    _check_dual(r2, o_sel, o, B, oracle_mod=oracle_mod)
+    r3 = vq_assign_routed_dual(t(hc2), t(hf2), t(E), _CodebookPrep(), gate=t(g2), want_zq=False)
+    assert np.array_equal(r3["codes"].cpu().numpy().reshape(B, -1), o["codes"])
+    ol = float(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    assert abs(float(r3["loss"][1]) - ol) <= 1e-5 * abs(ol)
+
+
+@pytest.mark.parametrize("dedup", ["1", "0", "2"])
 def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkeypatch):
     """NaN / Inf / huge tokens in every branch go through the exact list (routed ids); a codebook with widely
     mixed norms overflows the resolver queue; D = 64 / 128"""

@@ -3,6 +3,7 @@
   fused          routed op, one token per output position, select fused into the legacy pass 1
   fused-lowreg   the same on low-register pass-1 variant v
   dedup          routed op on unique tokens, low-register variant v
+  rows-dedup     routed op on unique tokens, whole rows of cells per legacy workgroup, z_q staged through LDS
 Every form's codes / z_q / grain / mask are compared with the first one's."""
 import json, os, sys
 import torch
@@ -40,7 +41,8 @@ def routed(mode):
                           out=(zq, codes, loss if mode == _lib.MODE_FILTER else None, grain, cmask, gate))
 forms = [("select+dense", None, None, None, select_dense), ("fused", "0", "0", 0, routed)]
 forms += [("fused-lowreg-v%d" % v, "0", "1", v, routed) for v in (1,)]
-forms += [("dedup-v%d" % v, "1", "0", v, routed) for v in (0, 1)]
+forms += [("dedup-v%d" % v, "1", "0", v, routed) for v in (1,)]
+forms += [("rows-dedup", "2", "0", 0, routed)]
 out, ref = {"B": B, "K": K}, None
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for name, dedup, lowreg, v, fn in forms:
