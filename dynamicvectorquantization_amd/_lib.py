@@ -35,7 +35,7 @@ EXPORTS = (
     "dvq_exchange_bytes", "dvq_exchange_pack", "dvq_exchange_unpack", "dvq_set_pass1_variant", "dvq_debug_filter_scores_f32",
     "dvq_qconv_prep_bytes", "dvq_qconv_prepare_f32", "dvq_qconv_f32", "dvq_qconv_select_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
-    "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
+    "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_prep_bytes", "dvq_router_gate_prepare_f32", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
 
 
@@ -115,10 +115,14 @@ def _load():
     lib.dvq_ema_accumulate_nchw_f32.restype = i32
     lib.dvq_ema_accumulate_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.dvq_router_gate_workspace_bytes.restype = sz
-    lib.dvq_router_gate_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.dvq_router_gate_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
+    lib.dvq_router_gate_prep_bytes.restype = sz
+    lib.dvq_router_gate_prep_bytes.argtypes = [i32, i32, i32]
+    lib.dvq_router_gate_prepare_f32.restype = i32
+    lib.dvq_router_gate_prepare_f32.argtypes = [vp, i32, i32, i32, vp, sz, vp]
     lib.dvq_router_gate_f32.restype = i32
     lib.dvq_router_gate_f32.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp,
-                                        vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+                                        vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     lib.dvq_entropy_map_f32.restype = i32
     lib.dvq_entropy_map_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.dvq_permute_dual_count_i64.restype = i32

@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 200   // 0.2.0
+#define DVQ_VERSION 201   // 0.2.1
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -59,11 +59,13 @@ int dvq_permute_max_cells(void);
 int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
                               float *cluster_size, float *vectors_sum, hipStream_t st);
 int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
-size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int groups, int Hid);
+size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid);
+size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid);
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st);
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
                            int B, int C, int hc, int wc, int groups, float eps,
                            const float *W1, const float *b1, const float *W2, const float *b2,
-                           int Hid, int act, float *gate, void *ws, hipStream_t st);
+                           int Hid, int act, const void *w1_prep, float *gate, void *ws, hipStream_t st);
 
 size_t dvq_qconv_prep_bytes_impl(int D);
 int dvq_launch_qconv_prep(const float *Wt, const float *bias, int D, void *prep, hipStream_t st);
@@ -345,10 +347,27 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
                                             (hipStream_t)stream), "ema_accumulate");
 }
 
-size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int num_groups, int hidden)
+size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden)
 {
-    if (num_branches < 2 || num_branches > 3 || B <= 0 || C <= 0 || num_groups < 0 || hidden < 0) return 0;
-    return dvq_router_gate_ws_bytes(num_branches, B, C, num_groups, hidden > 0 ? hidden : 32);
+    if (num_branches < 2 || num_branches > 3 || B <= 0 || C <= 0 || hc <= 0 || wc <= 0 || num_groups < 0 || hidden < 0) return 0;
+    return dvq_router_gate_ws_bytes(num_branches, B, C, hc, wc, num_groups, hidden > 0 ? hidden : 32);
+}
+
+size_t dvq_router_gate_prep_bytes(int num_branches, int C, int hidden)
+{
+    if (num_branches < 2 || num_branches > 3 || C <= 0 || hidden <= 0) return 0;
+    return dvq_router_gate_prep_bytes_impl(num_branches, C, hidden);
+}
+
+int dvq_router_gate_prepare_f32(const float *w1, int nb, int C, int hidden, void *w1_prep, size_t w1_prep_bytes, void *stream)
+{
+    const char *fn = "dvq_router_gate_prepare_f32";
+    if (nb != 2 && nb != 3) { dvq_set_error("%s: num_branches=%d (2 or 3)", fn, nb); return DVQ_EINVAL; }
+    if (!w1 || !w1_prep || C <= 0 || hidden <= 0) { dvq_set_error("%s: null pointer or non-positive size", fn); return DVQ_EINVAL; }
+    if (C % 8 != 0 || nb * C > 1280) { dvq_set_error("%s: C=%d unsupported (C %% 8 == 0, num_branches*C <= 1280)", fn, C); return DVQ_EUNSUPPORTED; }
+    if (w1_prep_bytes < dvq_router_gate_prep_bytes(nb, C, hidden)) { dvq_set_error("%s: buffer %zu < %zu bytes", fn, w1_prep_bytes, dvq_router_gate_prep_bytes(nb, C, hidden)); return DVQ_EWORKSPACE; }
+    if (((uintptr_t)w1_prep & 255) != 0) { dvq_set_error("%s: buffer must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_router_gate_prepare(w1, nb, C, hidden, w1_prep, (hipStream_t)stream), "router_gate_prepare");
 }
 
 int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, const float *h_fine,
@@ -357,7 +376,8 @@ int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, co
                         const float *gn_w_median, const float *gn_b_median,
                         const float *gn_w_fine, const float *gn_b_fine,
                         const float *w1, const float *b1, const float *w2, const float *b2,
-                        int hidden, int activation, float *gate, void *ws, size_t ws_bytes, void *stream)
+                        int hidden, int activation, const void *w1_prep, float *gate, void *ws, size_t ws_bytes,
+                        void *stream)
 {
     const char *fn = "dvq_router_gate_f32";
     if (nb != 2 && nb != 3) { dvq_set_error("%s: num_branches=%d (2 or 3)", fn, nb); return DVQ_EINVAL; }
@@ -372,8 +392,8 @@ int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, co
     }
     if (C % 8 != 0 || nb * C > 1280) { dvq_set_error("%s: C=%d unsupported (C %% 8 == 0, num_branches*C <= 1280)", fn, C); return DVQ_EUNSUPPORTED; }
     if (num_groups > 0 && ((size_t)(C / num_groups) * hc * wc) % 4 != 0) { dvq_set_error("%s: group size not a multiple of 4 floats", fn); return DVQ_EUNSUPPORTED; }
-    if (!ws || ws_bytes < dvq_router_gate_workspace_bytes(nb, B, C, num_groups, hidden)) {
-        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_router_gate_workspace_bytes(nb, B, C, num_groups, hidden));
+    if (!ws || ws_bytes < dvq_router_gate_workspace_bytes(nb, B, C, hc, wc, num_groups, hidden)) {
+        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_router_gate_workspace_bytes(nb, B, C, hc, wc, num_groups, hidden));
         return DVQ_EWORKSPACE;
     }
     if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
@@ -388,7 +408,7 @@ int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, co
         gb[0] = gn_b_coarse; gb[1] = gn_b_median; gb[2] = gn_b_fine;
     }
     return hip_rc(dvq_launch_router_gate(nb, h, gw, gb, B, C, hc, wc, num_groups, eps, w1, b1, w2, b2,
-                                         activation == DVQ_ACT_NONE ? 32 : hidden, activation, gate, ws,
+                                         activation == DVQ_ACT_NONE ? 32 : hidden, activation, w1_prep, gate, ws,
                                          (hipStream_t)stream), "router_gate");
 }
 

@@ -6,11 +6,16 @@
 //   modules/dynamic_modules/RouterTriple.py:46-56   GroupNorm x3, AvgPool2d(4) fine / (2) median, concat,
 //                                                   Linear [-> SiLU | ReLU -> Linear]
 // which is 8-10 launches and ~5 passes over the branch features in the reference.  Here:
-//   1. gn_stats_kernel   one pass over every branch: (mean, rstd) per (image, group).
+//   1. gate_pool_kernel  THE one pass over every branch (one workgroup per image and channel group, all
+//                        branches): (mean, rstd) per (image, group) and the raw per-cell averages
+//                        pooled[b][k = branch * C + c][cell] (the average of normalised pixels is the normalised
+//                        average, so the GroupNorm affine is applied to the averages later).  Streaming, high
+//                        occupancy: bound by the feature read.
 //   2. w1_split_kernel   hidden-layer weight -> 32-row MFMA tile images, split w = hi + lo with
-//                        hi = fp16(w), lo = fp16(w - hi) (22 significand bits between them).
-//   3. router_gate_kernel  one workgroup per 32 coarse cells: pools the raw features (the average of
-//                        normalised pixels is the normalised average), applies the GroupNorm affine,
+//                        hi = fp16(w), lo = fp16(w - hi) (22 significand bits between them); done once per
+//                        weight version when the caller keeps the images (dvq_router_gate_prepare_f32).
+//   3. router_gate_kernel  one workgroup per 32 coarse cells: reads their pooled averages (coalesced over cells),
+//                        applies the GroupNorm affine,
 //                        keeps the [32 x F] feature tile in LDS (also split hi + lo), multiplies it with
 //                        the hidden layer on the fp16 matrix cores as hi*hi + hi*lo + lo*hi with fp32
 //                        accumulation (3 MFMAs at 16x the fp32-MFMA rate; the dropped lo*lo term is
@@ -33,38 +38,76 @@ struct DvqGateArgs {
     float eps;
 };
 
-// ---- 1. GroupNorm statistics: stats[(br * B + b) * groups + g] = (mean, rstd)
-__global__ __launch_bounds__(256) void gn_stats_kernel(DvqGateArgs a, float2 *__restrict__ stats)
+// ---- 1. one pass over the branch features: the GroupNorm of every (image, group) folded with its affine into
+// ab[b * F + k] = (rstd * w, bias - mean * rstd * w), k = br * C + ch (normalised = raw * ab.x + ab.y), and
+// the raw per-cell averages pool[(b * F + br * C + ch) * ncell + cell].  Workgroup = (image b, channel group g); a
+// thread owns whole (channel, cell) pairs, so a pooled value is summed in a fixed order by one thread (deterministic,
+// and the same expression as before the split) and neighbouring threads read neighbouring cells: every load
+// instruction covers whole rows of cells.  groups == 0 (no normalisation): pseudo-groups of 8 channels, no stats.
+__global__ __launch_bounds__(256) void gate_pool_kernel(DvqGateArgs a, float2 *__restrict__ ab,
+                                                        float *__restrict__ pool)
 {
-    const int br = blockIdx.y;
-    const int bg = blockIdx.x;                              // b * groups + g
-    const int sc = a.scale[br];
-    const size_t n = (size_t)(a.C / a.groups) * (a.hc * sc) * (a.wc * sc);   // contiguous in NCHW
-    const float *p = a.h[br] + (size_t)bg * n;
-    double s = 0.0, ss = 0.0;
-    const size_t n4 = n / 4;
-    for (size_t i = threadIdx.x; i < n4; i += 256) {
-        f32x4 v = *(const f32x4 *)(p + 4 * i);
+    const int G = a.groups > 0 ? a.groups : a.C / 8;
+    const int cpg = a.C / G;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int ncell = a.hc * a.wc, F = a.nb * a.C;
+    const int npair = cpg * ncell;
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int br = 0; br < a.nb; ++br) {
+        const int sc = a.scale[br];
+        const int Wb = a.wc * sc;
+        const size_t plane = (size_t)(a.hc * sc) * Wb;
+        const float *p0 = a.h[br] + ((size_t)b * a.C + (size_t)g * cpg) * plane;
+        float *o0 = pool + ((size_t)b * F + (size_t)br * a.C + (size_t)g * cpg) * ncell;
+        double s = 0.0, ss = 0.0;
+        for (int pr = tid; pr < npair; pr += 256) {
+            const int ch = pr / ncell, cell = pr - ch * ncell;
+            const int y = cell / a.wc, x = cell - y * a.wc;
+            const float *p = p0 + (size_t)ch * plane + (size_t)sc * y * Wb + sc * x;
+            float v;
+            if (sc == 1) {
+                const float r = __builtin_nontemporal_load(p);
+                s += r; ss += (double)r * r;
+                v = r;
+            } else if (sc == 2) {
+                const f32x2 r0 = __builtin_nontemporal_load((const f32x2 *)p);
+                const f32x2 r1 = __builtin_nontemporal_load((const f32x2 *)(p + Wb));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s += v[j]; ss += (double)v[j] * v[j]; }
-    }
-    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) { s += p[i]; ss += (double)p[i] * p[i]; }
-    __shared__ double red[2][256];
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = ss;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + w];
-            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+                for (int j = 0; j < 2; ++j) { s += r0[j]; ss += (double)r0[j] * r0[j]; s += r1[j]; ss += (double)r1[j] * r1[j]; }
+                v = ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
+            } else {
+                f32x4 r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = __builtin_nontemporal_load((const f32x4 *)(p + (size_t)i * Wb));
+                float s4 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s4 += (r[i][0] + r[i][1]) + (r[i][2] + r[i][3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s += r[i][j]; ss += (double)r[i][j] * r[i][j]; }
+                }
+                v = s4 * 0.0625f;
+            }
+            o0[pr] = v;
         }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double mean = red[0][0] / (double)n;
-        double var = red[1][0] / (double)n - mean * mean;    // biased, as GroupNorm
-        if (var < 0.0) var = 0.0;
-        stats[(size_t)br * gridDim.x + bg] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)a.eps)));
+        if (a.groups > 0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ss += __shfl_xor(ss, off); }
+            __syncthreads();                                 // red[] of the previous branch consumed
+            if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+            __syncthreads();
+            if (tid < cpg) {                                 // the group's channels: normalisation folded into one affine
+                const double n = (double)cpg * (double)plane;
+                const double mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+                double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mean * mean;   // biased, as GroupNorm
+                if (var < 0.0) var = 0.0;
+                const float mf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+                const int ch = g * cpg + tid;
+                const float sc_ = rstd * a.gn_w[br][ch];
+                ab[(size_t)b * F + (size_t)br * a.C + ch] = make_float2(sc_, a.gn_b[br][ch] - mf * sc_);
+            }
+        }
     }
 }
 
@@ -90,11 +133,12 @@ __global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__
 
 // ---- 3. the gate
 // ACT: 0 = single Linear (no hidden layer), 1 = SiLU, 2 = ReLU.  G = logits per cell (2 / 3).
+#define GATE_NW 8            // waves per workgroup of the gate kernel: two per SIMD (the feature tile fills the LDS: one workgroup per CU)
 template <int G>
-__global__ __launch_bounds__(256) void router_gate_kernel(
-    DvqGateArgs a, const float2 *__restrict__ stats, const _Float16 *__restrict__ imgH,
-    const _Float16 *__restrict__ imgL, const float *__restrict__ b1, const float *__restrict__ W2,
-    const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate)
+__global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
+    DvqGateArgs a, const float2 *__restrict__ ab, const float *__restrict__ pool,
+    const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate)
 {
     // LDS: XH | XL halves [Fp/16][64 lanes = 32h + cell][8] each (B operands), then bias / output rows
     extern __shared__ __attribute__((aligned(16))) float X[];
@@ -108,67 +152,73 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     const long ncell = (long)a.B * a.hc * a.wc;
     const long cell0 = (long)blockIdx.x * 32;
 
-    // ---- feature tile: pooled + normalised, split into fp16 hi + lo, in MFMA B-operand order.  A thread
-    // keeps one cell (tid & 31) and walks channels (tid >> 5) + 8i, eight independent loads in flight.
+    // ---- feature tile: normalised averages, split into fp16 hi + lo, in MFMA B-operand order.  A thread keeps one
+    // cell (tid & 31) and walks the octets of features (tid >> 5) + 2 GATE_NW i: eight loads (one 128-B line per half wave
+    // each: the cells of a workgroup are consecutive in pool[b][k][cell]), one 16-B LDS store per image.
     auto build = [&](float xscale) -> float {
         float vmax = 0.0f;
         const int cell = tid & 31;
         const long cg = cell0 + cell;
         const bool live = cg < ncell;
         const long cgl = live ? cg : ncell - 1;
-        const int b = (int)(cgl / (a.hc * a.wc));
-        const int rem = (int)(cgl - (long)b * a.hc * a.wc);
-        const int y = rem / a.wc, x = rem - y * a.wc;
-        const int cpg = a.groups > 0 ? a.C / a.groups : 1;
-        for (int k = F + (tid >> 5); k < Fp; k += 8) {      // zero the k padding
-            const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
-            XH[idx] = (_Float16)0.0f;
-            XL[idx] = (_Float16)0.0f;
-        }
-        for (int br = 0; br < a.nb; ++br) {
-            const int sc = a.scale[br];
-            const int Wb = a.wc * sc;
-            const size_t plane = (size_t)(a.hc * sc) * Wb;
-            const float *p0 = a.h[br] + (size_t)b * a.C * plane + (size_t)sc * y * Wb + sc * x;
-            const float2 *st = stats + ((size_t)br * a.B + b) * (a.groups > 0 ? a.groups : 1);
-            const float *gw = a.gn_w[br], *gb = a.gn_b[br];
-            auto pooled = [&](int ch) -> float {
-                const float *p = p0 + (size_t)ch * plane;
-                if (sc == 1) return p[0];
-                if (sc == 2) {
-                    f32x2 r0 = *(const f32x2 *)p, r1 = *(const f32x2 *)(p + Wb);
-                    return ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
-                }
-                float s4 = 0.0f;                        // sc == 4
+        const int nci = a.hc * a.wc;
+        const int b = (int)(cgl / nci);
+        const int rem = (int)(cgl - (long)b * nci);
+        const float *pb = pool + (size_t)b * F * nci + rem;
+        const float2 *abb = ab + (size_t)b * F;
+        auto load8 = [&](int o, float (&v)[8], f32x4 (&q)[4]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 r = *(const f32x4 *)(p + (size_t)i * Wb);
-                    s4 += (r[0] + r[1]) + (r[2] + r[3]);
-                }
-                return s4 * 0.0625f;
-            };
-            auto put = [&](int ch, float v) {
-                if (a.groups > 0) {
-                    const float2 ms = st[ch / cpg];
-                    v = (v - ms.x) * ms.y * gw[ch] + gb[ch];
-                }
-                v = live ? v * xscale : 0.0f;
-                vmax = fmaxf(vmax, fabsf(v));
-                const int k = br * a.C + ch;
-                const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
-                const _Float16 hi = (_Float16)v;
-                XH[idx] = hi;
-                XL[idx] = (_Float16)(v - (float)hi);
-            };
-            int ch = tid >> 5;
-            for (; ch + 56 < a.C; ch += 64) {
-                float v[8];
+            for (int j = 0; j < 8; ++j) v[j] = (8 * o < F) ? pb[(size_t)(8 * o + j) * nci] : 0.0f;
+            if (a.groups > 0 && 8 * o < F) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = pooled(ch + 8 * u);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) put(ch + 8 * u, v[u]);
+                for (int j = 0; j < 4; ++j) q[j] = *(const f32x4 *)(abb + 8 * o + 2 * j);   // (scale, shift) of two channels
             }
-            for (; ch < a.C; ch += 8) put(ch, pooled(ch));
+        };
+        auto put8 = [&](int o, float (&v)[8], const f32x4 (&q)[4]) {
+            const int k0 = 8 * o;
+            f16x8 hi, lo;
+            if (k0 < F) {
+                if (a.groups > 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * q[j >> 1][2 * (j & 1)] + q[j >> 1][2 * (j & 1) + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = live ? v[j] * xscale : 0.0f;
+                    vmax = fmaxf(vmax, fabsf(x));
+                    const _Float16 hh = (_Float16)x;
+                    hi[j] = hh;
+                    lo[j] = (_Float16)(x - (float)hh);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.0f; lo[j] = (_Float16)0.0f; }
+            }
+            const int slot = (o >> 1) * 64 + (o & 1) * 32 + cell;          // f16x8 index: k-step o / 2, half o & 1
+            ((f16x8 *)XH)[slot] = hi;
+            ((f16x8 *)XL)[slot] = lo;
+        };
+        const int NO = Fp / 8;
+        constexpr int OL = GATE_NW * 2;                      // octet lanes (threads per cell)
+        int o = tid >> 5;
+        for (; o + 3 * OL < NO; o += 4 * OL) {               // four octets (32 loads) in flight per thread
+            float v0[8], v1[8], v2[8], v3[8];
+            f32x4 q0[4], q1[4], q2[4], q3[4];
+            load8(o, v0, q0); load8(o + OL, v1, q1); load8(o + 2 * OL, v2, q2); load8(o + 3 * OL, v3, q3);
+            put8(o, v0, q0); put8(o + OL, v1, q1); put8(o + 2 * OL, v2, q2); put8(o + 3 * OL, v3, q3);
+        }
+        if (o + OL < NO) {                                   // two octets left (triple at GATE_NW = 8: 6 per thread)
+            float v0[8], v1[8];
+            f32x4 q0[4], q1[4];
+            load8(o, v0, q0); load8(o + OL, v1, q1);
+            put8(o, v0, q0); put8(o + OL, v1, q1);
+            o += 2 * OL;
+        }
+        for (; o < NO; o += OL) {
+            float v0[8];
+            f32x4 q0[4];
+            load8(o, v0, q0);
+            put8(o, v0, q0);
         }
         return vmax;
     };
@@ -177,6 +227,9 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     if (tid == 0) s_amax = 0u;
     __syncthreads();
     float inv_scale = 1.0f;
+#ifdef GATE_PROBE_NO_BUILD
+    if (false)
+#endif
     {
         float vmax = build(1.0f);
         atomicMax(&s_amax, __float_as_uint(vmax));          // non-negative floats order like their bits
@@ -198,7 +251,7 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     for (int g = 0; g < G; ++g) part[g] = 0.0f;
     float *PB = X + 32 * Fp;                           // hidden bias + output-layer rows: [1 + G][Hid]
     if (act != 0) {
-        for (int i = tid; i < Hid; i += 256) {
+        for (int i = tid; i < Hid; i += GATE_NW * 64) {
             PB[i] = b1[i];
 #pragma unroll
             for (int g = 0; g < G; ++g) PB[(1 + g) * Hid + i] = W2[(size_t)g * Hid + i];
@@ -206,9 +259,10 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     }
 
     if (act == 0) {
-        // single Linear: gate[cell][g] = W2[g][:] . x + b2[g]; 8 threads per cell split k
-        const int cell = tid >> 3, sub = tid & 7;
-        for (int k = sub; k < F; k += 8) {
+        // single Linear: gate[cell][g] = W2[g][:] . x + b2[g]; 2 GATE_NW threads per cell split k
+        constexpr int SUB = GATE_NW * 2;
+        const int cell = tid / SUB, sub = tid % SUB;
+        for (int k = sub; k < F; k += SUB) {
             const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
             const float xv = ((float)XH[idx] + (float)XL[idx]) * inv_scale;
 #pragma unroll
@@ -216,9 +270,8 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            part[g] += __shfl_xor(part[g], 1);
-            part[g] += __shfl_xor(part[g], 2);
-            part[g] += __shfl_xor(part[g], 4);
+#pragma unroll
+            for (int off = 1; off < SUB; off <<= 1) part[g] += __shfl_xor(part[g], off);
         }
         const long cg = cell0 + cell;
         if (sub == 0 && cg < ncell) {
@@ -229,15 +282,18 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     }
 
     __syncthreads();
-    // ---- hidden layer on the fp16 matrix cores (split operands): wave w takes hidden-row tiles w, w + 4, ...
+#ifdef GATE_PROBE_NO_MFMA
+    if (gate != nullptr) return;
+#endif
+    // ---- hidden layer on the fp16 matrix cores (split operands): wave w takes hidden-row tiles w, w + GATE_NW, ...
     const int T = (Hid + 31) / 32;
     const int S = Fp / 16;
     const f16x8 *xh = (const f16x8 *)XH + lane, *xl = (const f16x8 *)XL + lane;      // + s * 64 per k-step
-    // The A fragments (hidden-layer weight tiles) come straight from L2, one 16-B load per lane per MFMA triple; a
-    // workgroup has one wave per SIMD (the feature tile fills the LDS), so the L2 latency is hidden by software
-    // pipelining: the fragments of the next two groups of four k-steps (2 x 8 loads = 64 VGPRs) are in flight while
-    // the current group's twelve MFMAs run.  Groups are numbered through this wave's tiles: g -> (tile wave + 4 (g / GPT),
-    // k-steps 4 (g % GPT) ..).
+    // The A fragments (hidden-layer weight tiles) come straight from L2, one 16-B load per lane per MFMA triple; the
+    // feature tile fills the LDS, so there is one workgroup per CU and the L2 latency is hidden by its own two waves per
+    // SIMD plus software pipelining: the fragments of the next three groups of four k-steps (3 x 8 loads = 96 VGPRs) are
+    // in flight while the current group's twelve MFMAs run.  Groups are numbered through this wave's tiles:
+    // g -> (tile wave + GATE_NW (g / GPT), k-steps 4 (g % GPT) ..).
     auto epilogue = [&](int t, const f32x16 &acc) {    // bias, activation, contraction with the output layer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -252,11 +308,11 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     };
     if ((S & 3) == 0) {
         const int GPT = S >> 2;                        // groups per tile
-        const int ntile = (T - wave + 3) / 4;          // tiles of this wave
+        const int ntile = (T - wave + GATE_NW - 1) / GATE_NW;   // tiles of this wave
         const int NG = ntile * GPT;
         auto fetch = [&](int g, f16x8 (&vh)[4], f16x8 (&vl)[4]) {
             const int gg = g < NG ? g : NG - 1;        // past the end: harmless repeat
-            const int t = wave + 4 * (gg / GPT), s0 = 4 * (gg % GPT);
+            const int t = wave + GATE_NW * (gg / GPT), s0 = 4 * (gg % GPT);
             const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
             const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
 #pragma unroll
@@ -265,7 +321,7 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
         f32x16 acc;
         auto step = [&](int g, const f16x8 (&vh)[4], const f16x8 (&vl)[4]) {
             if (g >= NG) return;
-            const int t = wave + 4 * (g / GPT), s0 = 4 * (g % GPT);
+            const int t = wave + GATE_NW * (g / GPT), s0 = 4 * (g % GPT);
             if (s0 == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -282,21 +338,24 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
             if (s0 + 4 == S) epilogue(t, acc);
         };
         if (NG > 0) {
-            f16x8 h0[4], l0[4], h1[4], l1[4], h2[4], l2[4];
+            f16x8 h0[4], l0[4], h1[4], l1[4], h2[4], l2[4], h3[4], l3[4];
             fetch(0, h0, l0);
             fetch(1, h1, l1);
             fetch(2, h2, l2);
-            for (int g = 0; g < NG; g += 3) {
+            fetch(3, h3, l3);
+            for (int g = 0; g < NG; g += 4) {
                 step(g, h0, l0);
-                fetch(g + 3, h0, l0);
+                fetch(g + 4, h0, l0);
                 step(g + 1, h1, l1);
-                fetch(g + 4, h1, l1);
+                fetch(g + 5, h1, l1);
                 step(g + 2, h2, l2);
-                fetch(g + 5, h2, l2);
+                fetch(g + 6, h2, l2);
+                step(g + 3, h3, l3);
+                fetch(g + 7, h3, l3);
             }
         }
     } else {
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += GATE_NW) {
         const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
         const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
         f32x16 acc;
@@ -312,7 +371,7 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
     }
     }
     __syncthreads();                                   // everyone is done reading X
-    float *red = X;                                    // [4 waves][G][32 cells]
+    float *red = X;                                    // [GATE_NW waves][G][32 cells]
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float v = part[g] + __shfl_xor(part[g], 32);
@@ -323,8 +382,9 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
         const int cell = tid / G, g = tid - cell * G;
         const long cg = cell0 + cell;
         if (cg < ncell) {
-            float v = (red[(0 * G + g) * 32 + cell] + red[(1 * G + g) * 32 + cell]) +
-                      (red[(2 * G + g) * 32 + cell] + red[(3 * G + g) * 32 + cell]);
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < GATE_NW; w += 2) v += red[(w * G + g) * 32 + cell] + red[((w + 1) * G + g) * 32 + cell];
             gate[cg * G + g] = v + b2[g];
         }
     }
@@ -335,18 +395,38 @@ __global__ __launch_bounds__(256) void router_gate_kernel(
 // ---------------------------------------------------------------------------------------------
 static size_t align256r(size_t x) { return (x + 255) / 256 * 256; }
 
-// ws: [stats nb*B*groups float2][W1 hi image | W1 lo image: ceil(Hid/32)*32*Fp halves each]
-size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int groups, int Hid)
+// ws: [folded GroupNorm affine B*F float2][pooled averages B*F*hc*wc floats][W1 hi image | W1 lo image: ceil(Hid/32)*32*Fp halves
+// each -- used only when the caller passes no prepared images]
+static size_t gate_img_bytes(int nb, int C, int Hid)
 {
     const size_t Fp = ((size_t)nb * C + 15) / 16 * 16;
-    return align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)) +
-           align256r((size_t)((Hid + 31) / 32) * 32 * Fp * 2 * sizeof(_Float16)) + 256;
+    return align256r((size_t)((Hid + 31) / 32) * 32 * Fp * 2 * sizeof(_Float16));
+}
+size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid) { return gate_img_bytes(nb, C, Hid) + 256; }
+size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid)
+{
+    (void)groups;
+    return align256r((size_t)B * nb * C * sizeof(float2)) +
+           align256r((size_t)B * nb * C * hc * wc * sizeof(float)) + gate_img_bytes(nb, C, Hid) + 256;
+}
+
+// hidden-layer weight -> split fp16 tile images (kept by the caller across calls while the weight is unchanged)
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st)
+{
+    const int F = nb * C, Fp = (F + 15) & ~15;
+    _Float16 *imgH = (_Float16 *)prep;
+    _Float16 *imgL = imgH + (size_t)((Hid + 31) / 32) * 32 * Fp;
+    size_t total = (size_t)((Hid + 31) / 32) * 32 * Fp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL);
+    return (int)hipGetLastError();
 }
 
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
                            int B, int C, int hc, int wc, int groups, float eps,
                            const float *W1, const float *b1, const float *W2, const float *b2,
-                           int Hid, int act, float *gate, void *ws, hipStream_t st)
+                           int Hid, int act, const void *w1_prep, float *gate, void *ws, hipStream_t st)
 {
     DvqGateArgs a;
     for (int i = 0; i < 3; ++i) {
@@ -357,28 +437,28 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     }
     a.nb = nb; a.B = B; a.C = C; a.hc = hc; a.wc = wc; a.groups = groups; a.eps = eps;
     const int F = nb * C, Fp = (F + 15) & ~15;
-    float2 *stats = (float2 *)ws;
-    _Float16 *imgH = (_Float16 *)((char *)ws + align256r((size_t)nb * B * (groups > 0 ? groups : 1) * sizeof(float2)));
-    _Float16 *imgL = imgH + (size_t)((Hid + 31) / 32) * 32 * Fp;
-    if (groups > 0)
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups, nb), dim3(256), 0, st, a, stats);
-    if (act != 0) {
-        size_t total = (size_t)((Hid + 31) / 32) * 32 * Fp;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL);
+    float2 *stats = (float2 *)ws;                            // (scale, shift) per (image, feature)
+    float *pool = (float *)((char *)ws + align256r((size_t)B * F * sizeof(float2)));
+    const _Float16 *imgH = (const _Float16 *)w1_prep;
+    if (act != 0 && imgH == nullptr) {
+        void *own = (char *)pool + align256r((size_t)B * F * hc * wc * sizeof(float));
+        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, own, st);
+        if (rc) return rc;
+        imgH = (const _Float16 *)own;
     }
+    const _Float16 *imgL = imgH ? imgH + (size_t)((Hid + 31) / 32) * 32 * Fp : nullptr;
+    hipLaunchKernelGGL(gate_pool_kernel, dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool);
     const long ncell = (long)B * hc * wc;
     const unsigned grid = (unsigned)((ncell + 31) / 32);
     const size_t shmem = ((size_t)32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
     if (nb == 2) {
         static unsigned long long done2 = 0;
         { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<2>, 160 * 1024 - 256, &done2); if (rc) return rc; }
-        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
+        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool, imgH, imgL, b1, W2, b2, Hid, act, gate);
     } else {
         static unsigned long long done3 = 0;
         { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<3>, 160 * 1024 - 256, &done3); if (rc) return rc; }
-        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(256), shmem, st, a, stats, imgH, imgL, b1, W2, b2, Hid, act, gate);
+        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool, imgH, imgL, b1, W2, b2, Hid, act, gate);
     }
     return (int)hipGetLastError();
 }

@@ -231,10 +231,42 @@ def _needs_autograd(module, *tensors):
     return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
 
 
-def fused_router_gate(gate, gate_type, norms, branches):
+class _GateWeightPrep:
+    """The hidden-layer weight of a router's gate MLP as split fp16 matrix-core tile images
+    (`dvq_router_gate_prepare_f32`), rebuilt only when the weight changes: keyed on (data_ptr, _version, shape,
+    device) like quantize._CodebookPrep, with the same caveat -- writes through `.data` do not bump the version, so
+    the router modules call invalidate() from `_load_from_state_dict`, `_apply` and every training-mode forward."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def invalidate(self):
+        self.key = None
+
+    def get(self, w1, nb, C):
+        hidden = w1.shape[0]
+        key = (w1.data_ptr(), w1._version, tuple(w1.shape), w1.device)
+        if key != self.key:
+            nbytes = _lib_handle.dvq_router_gate_prep_bytes(nb, C, hidden)
+            if nbytes == 0:
+                raise _lib.DvqError("unsupported gate shape nb=%d C=%d hidden=%d" % (nb, C, hidden))
+            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != w1.device:
+                self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+            with torch.cuda.device(w1.device):
+                _lib.check(_lib_handle.dvq_router_gate_prepare_f32(
+                    w1.data_ptr(), nb, C, hidden, self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
+                    "dvq_router_gate_prepare_f32")
+            self.key = key
+        return self.buf
+
+
+def fused_router_gate(gate, gate_type, norms, branches, weight_prep=None):
     """gate: the router's nn.Linear / nn.Sequential; norms / branches: coarse -> fine lists of the
     GroupNorm (or Identity) modules and of the [B, C, rows, cols] feature maps.
-    -> logits [B, hc, wc, len(branches)] f32 from one fused kernel (RouterDual.py:35-43, RouterTriple.py:46-56)."""
+    -> logits [B, hc, wc, len(branches)] f32 (RouterDual.py:35-43, RouterTriple.py:46-56): one pass over the features
+    (statistics + per-cell averages), then the gate MLP on the averages.  weight_prep: a _GateWeightPrep kept by the
+    module (None: the weight images are rebuilt inside the call)."""
     nb = len(branches)
     hs = [_lib.require_cuda_f32(h, "router input") for h in branches]
     B, C, hc, wc = hs[0].shape
@@ -253,20 +285,44 @@ def fused_router_gate(gate, gate_type, norms, branches):
     else:
         w1, b1, w2, b2 = gate[0].weight, gate[0].bias, gate[2].weight, gate[2].bias
         hidden = w1.shape[0]
-    w1, b1, w2, b2 = [None if t is None else t.detach().float().contiguous() for t in (w1, b1, w2, b2)]
+    w1, b1, w2, b2 = [None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous())
+                                               else t.detach().float().contiguous()) for t in (w1, b1, w2, b2)]
     dev = hs[0].device
     out = torch.empty((B, hc, wc, nb), dtype=torch.float32, device=dev)
-    ws_bytes = _lib_handle.dvq_router_gate_workspace_bytes(nb, B, C, groups, hidden)
+    ws_bytes = _lib_handle.dvq_router_gate_workspace_bytes(nb, B, C, hc, wc, groups, hidden)
+    if ws_bytes == 0:
+        raise _lib.DvqError("unsupported router shape")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()
     med = hs[1] if nb == 3 else None
+    prep = weight_prep.get(w1, nb, C) if (weight_prep is not None and w1 is not None) else None
     with torch.cuda.device(dev):
         _lib.check(_lib_handle.dvq_router_gate_f32(
             nb, hs[0].data_ptr(), ptr(med), hs[-1].data_ptr(), B, C, hc, wc, groups, float(eps),
             ptr(gw[0]), ptr(gb[0]), ptr(gw[1]) if nb == 3 else None, ptr(gb[1]) if nb == 3 else None,
-            ptr(gw[-1]), ptr(gb[-1]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), hidden, act,
+            ptr(gw[-1]), ptr(gb[-1]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), hidden, act, ptr(prep),
             out.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "dvq_router_gate_f32")
     return out
+
+
+class _GateCacheMixin:
+    """invalidation hooks of the cached gate-weight images (see _GateWeightPrep)"""
+
+    def _gate_prep(self):
+        if self.training:
+            self._gate_weight_prep.invalidate()
+        return self._gate_weight_prep
+
+    def invalidate_gate_cache(self):
+        self._gate_weight_prep.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._gate_weight_prep.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._gate_weight_prep.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
 
 def _make_gate(gate_type, width, splits, allow_relu):
@@ -288,7 +344,7 @@ def _make_norm(normalization_type, num_channels):
     raise NotImplementedError()
 
 
-class DualGrainFeatureRouter(nn.Module):
+class DualGrainFeatureRouter(_GateCacheMixin, nn.Module):
     """RouterDual.py:6-43: GroupNorm both branches, 2x2 average-pool the fine one, concat channels,
     NHWC, gate MLP -> logits [B, hc, wc, 2]."""
 
@@ -301,11 +357,12 @@ class DualGrainFeatureRouter(nn.Module):
         self.normalization_type = normalization_type
         self.feature_norm_fine = _make_norm(normalization_type, num_channels)
         self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
+        self._gate_weight_prep = _GateWeightPrep()
 
     def forward(self, h_fine, h_coarse, entropy=None):
         if h_fine.is_cuda and not _needs_autograd(self, h_fine, h_coarse):
             return fused_router_gate(self.gate, self.gate_type, [self.feature_norm_coarse, self.feature_norm_fine],
-                                     [h_coarse, h_fine])
+                                     [h_coarse, h_fine], weight_prep=self._gate_prep())
         h_fine = self.feature_norm_fine(h_fine)
         h_coarse = self.feature_norm_coarse(h_coarse)
         avg_h_fine = self.gate_pool(h_fine)
@@ -313,7 +370,7 @@ class DualGrainFeatureRouter(nn.Module):
         return self.gate(h_logistic)
 
 
-class TripleGrainFeatureRouter(nn.Module):
+class TripleGrainFeatureRouter(_GateCacheMixin, nn.Module):
     """RouterTriple.py:6-56: three GroupNorms, 4x4 / 2x2 pools, concat -> MLP -> logits [B, hc, wc, 3]."""
 
     def __init__(self, num_channels, normalization_type="none", gate_type="1layer-fc"):
@@ -327,12 +384,13 @@ class TripleGrainFeatureRouter(nn.Module):
         self.feature_norm_fine = _make_norm(normalization_type, num_channels)
         self.feature_norm_median = _make_norm(normalization_type, num_channels)
         self.feature_norm_coarse = _make_norm(normalization_type, num_channels)
+        self._gate_weight_prep = _GateWeightPrep()
 
     def forward(self, h_fine, h_median, h_coarse, entropy=None):
         if h_fine.is_cuda and not _needs_autograd(self, h_fine, h_median, h_coarse):
             return fused_router_gate(self.gate, self.gate_type,
                                      [self.feature_norm_coarse, self.feature_norm_median, self.feature_norm_fine],
-                                     [h_coarse, h_median, h_fine])
+                                     [h_coarse, h_median, h_fine], weight_prep=self._gate_prep())
         h_fine = self.feature_norm_fine(h_fine)
         h_median = self.feature_norm_median(h_median)
         h_coarse = self.feature_norm_coarse(h_coarse)

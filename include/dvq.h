@@ -231,14 +231,22 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
 #define DVQ_ACT_NONE 0
 #define DVQ_ACT_SILU 1
 #define DVQ_ACT_RELU 2
-size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int num_groups, int hidden);
+/* The workspace holds the GroupNorm statistics and the per-cell averages of every branch (B * nb*C * hc*wc floats): the
+ * features are read from HBM once.  w1_prep (nullable): the split fp16 tile images of w1 made by
+ * dvq_router_gate_prepare_f32 into a caller-kept buffer of dvq_router_gate_prep_bytes -- valid while w1 is unchanged;
+ * NULL: they are rebuilt inside the call. */
+size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden);
+size_t dvq_router_gate_prep_bytes(int num_branches, int C, int hidden);
+int dvq_router_gate_prepare_f32(const float *w1, int num_branches, int C, int hidden, void *w1_prep,
+                                size_t w1_prep_bytes, void *stream);
 int dvq_router_gate_f32(int num_branches, const float *h_coarse, const float *h_median, const float *h_fine,
                         int B, int C, int hc, int wc, int num_groups, float eps,
                         const float *gn_w_coarse, const float *gn_b_coarse,
                         const float *gn_w_median, const float *gn_b_median,
                         const float *gn_w_fine, const float *gn_b_fine,
                         const float *w1, const float *b1, const float *w2, const float *b2,
-                        int hidden, int activation, float *gate, void *ws, size_t ws_bytes, void *stream);
+                        int hidden, int activation, const void *w1_prep, float *gate, void *ws, size_t ws_bytes,
+                        void *stream);
 
 /*
  * Patch-entropy map, Entropy.forward (models/stage1_dynamic/dqvae_dual_entropy.py:13-63) with

@@ -49,9 +49,12 @@ def test_size_queries_and_validation_without_gpu():
     assert L.dvq_route_select_dual_entropy_f32(1, 1.0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 0, 0) == -2    # odd wc
     assert L.dvq_ema_accumulate_nchw_f32(0, 0, 1, 64, 1, 8, 0, 0, 0) == -1
     assert L.dvq_entropy_map_f32(1, 1, 250, 256, 16, 1, 0) == -2                               # H % 16
-    assert L.dvq_router_gate_workspace_bytes(2, 64, 256, 32, 512) >= 512 * 512 * 4
-    assert L.dvq_router_gate_workspace_bytes(4, 64, 256, 32, 512) == 0                         # 2 or 3 branches
-    args = [2, 1, 0, 1, 1, 256, 16, 16, 32, 1e-6, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 512, 1, 1, 0, 0, 0]
+    assert L.dvq_router_gate_workspace_bytes(2, 64, 256, 16, 16, 32, 512) >= 512 * 512 * 4 + 64 * 512 * 256 * 4
+    assert L.dvq_router_gate_workspace_bytes(4, 64, 256, 16, 16, 32, 512) == 0                 # 2 or 3 branches
+    assert L.dvq_router_gate_prep_bytes(2, 256, 512) >= 512 * 512 * 4
+    assert L.dvq_router_gate_prepare_f32(1, 2, 256, 512, 256, 16, 0) == -3                     # buffer too small
+    assert L.dvq_router_gate_prepare_f32(0, 2, 256, 512, 256, 1 << 30, 0) == -1                # null weight
+    args = [2, 1, 0, 1, 1, 256, 16, 16, 32, 1e-6, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 512, 1, 0, 1, 0, 0, 0]
     assert L.dvq_router_gate_f32(*args) == -3 and b"workspace" in L.dvq_last_error_string()
     args[5] = 100                                                                               # C % 8
     assert L.dvq_router_gate_f32(*args) == -1 or L.dvq_router_gate_f32(*args) == -2

@@ -206,7 +206,9 @@ def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkey
     r1 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p1, gate=t(g2), mode=_lib.MODE_FILTER)
     r0 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p0, gate=t(g2), mode=_lib.MODE_EXACT)
     queued, listed = p1.fallback_count()
-    assert queued >= 4096 and listed > 500, (queued, listed)      # 64 shards full, the rest through the exact list
+    # 64 shards full, the rest through the exact list (form 2 leaves a quarter of the workgroup slots, hence some
+    # shards, unused)
+    assert queued >= (2048 if dedup == "2" else 4096) and listed > 500, (queued, listed)
     assert torch.equal(r0["codes"], r1["codes"]) and torch.equal(r0["zq"], r1["zq"])
     assert abs(float(r0["loss"][1]) - float(r1["loss"][1])) <= 1e-6 * abs(float(r0["loss"][1]))
     o_sel = oracle_mod.route_select_dual(g2, hc2, hf2)
