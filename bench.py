@@ -580,8 +580,11 @@ def run_rank(a):
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
     roof.update({"kernel": wl.dominant_kernel_name(), "traffic_source": tsrc,
-                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events around the pass-1 launch (a 4-us counter-zero / "
-                 "token-list kernel precedes it in the same op and is inside the bracket)",
+                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events on the launch stream around the pass-1 launch (a 4-us "
+                 "counter-zero kernel precedes it in the same op and is inside the bracket), one launch at a time after "
+                 "the timed region. Inside the timed region consecutive steps overlap on config.streams HIP streams, so a "
+                 "kernel trace of THIS command shows stretched, overlapping per-kernel durations; the trace of the same "
+                 "command with --streams 1 (profiles/r02_bench_kernel_stats.csv) is the one this figure agrees with",
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                  "algorithmic_note": "SURVEY.md 8d count of the VQ forward: every one of the B*H*W positions read once "
                                      "(1 KiB), z_q written once (1 KiB), int64 code, mask",

@@ -26,7 +26,7 @@ kernels = {}
 def find(per, prefix):
     ks = [k for k in per if k.startswith(prefix)]
     return ks[0] if ks else None
-for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, false"), ("fused_pass1", "vq_assign_filter_kernel<256, true"),
+for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0"), ("fused_pass1", "vq_assign_filter_kernel<256, 1"),
                       ("resolver", "vq_resolve_kernel<256>")):
     kf, kw = find(fetch, prefix), find(write, prefix)
     if kf is None or kw is None:
