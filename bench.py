@@ -453,11 +453,21 @@ def run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line (rank 0's JSON): until then file descriptor 1 points at stderr, so that native
+    # libraries that print there (RCCL's version banner at the first collective) cannot add lines to it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local = local % torch.cuda.device_count()      # (a 1-GPU box can still exercise the N > 1 code path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    force_xch = world == 1 and os.environ.get("DVQ_BENCH_FORCE_EXCHANGE") == "1"   # 1-rank RCCL group: exchange overhead probe
+    if force_xch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DVQ_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for tests
@@ -479,7 +489,7 @@ def run_rank(a):
     streams = [torch.cuda.current_stream(dev)] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
     nx = max(2, S)
     xchs = ([CodeExchange(wl.slots[0].codes, wl.slots[0].grain, K, wl.Bglobal, numel_per_image=H * W * D) for _ in range(nx)]
-            if world > 1 else [])
+            if (world > 1 or force_xch) else [])
     nstep = [0]
 
     def step(i=None):
@@ -510,6 +520,7 @@ def run_rank(a):
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
+    t_issue = time.perf_counter() - t0        # host time to queue the K steps (launch-bound if close to dt)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -597,7 +608,7 @@ def run_rank(a):
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
-                       "spinup_steps": a.spinup, "streams": S,
+                       "spinup_steps": a.spinup, "streams": S, "host_issue_ms_per_step": t_issue / a.steps * 1e3,
                        "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
                                       "per step" % world},
             "roofline": roof,
@@ -611,9 +622,13 @@ def run_rank(a):
                 out["parity"]["oracle_full_batch_images_per_s"] = wl.B / wl.oracle_seconds   # cold, fresh output arrays
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
+    if world > 1 or force_xch:
         dist.destroy_process_group()
 
 
