@@ -26,6 +26,7 @@
 // A different summation order than ATen/MKL and 2^-22 instead of 2^-24 products: tolerance parity
 // (logits within 1e-4 of the reference, ~1e-6 in practice), by design.
 #include "dvq_common.h"
+#include <cstdlib>
 
 struct DvqGateArgs {
     const float *h[3];        // branches, coarse -> fine
@@ -36,6 +37,7 @@ struct DvqGateArgs {
     int B, C, hc, wc;
     int groups;               // 0 = no normalisation
     float eps;
+    int vec;                  // pooling pass: 16-B loads where the rows allow (0: tuning aid DVQ_GATE_POOL_SCALAR=1)
 };
 
 // ---- 1. one pass over the branch features: the GroupNorm of every (image, group) folded with its affine into
@@ -61,6 +63,48 @@ __global__ __launch_bounds__(256) void gate_pool_kernel(DvqGateArgs a, float2 *_
         const float *p0 = a.h[br] + ((size_t)b * a.C + (size_t)g * cpg) * plane;
         float *o0 = pool + ((size_t)b * F + (size_t)br * a.C + (size_t)g * cpg) * ncell;
         double s = 0.0, ss = 0.0;
+        if (a.vec && (Wb & 3) == 0) {
+            // rows are whole float4s: a thread takes 4 consecutive source columns = 4 / sc cells of one row of cells
+            // (16-B loads for every branch), sc source rows deep
+            const int cu = 4 / sc;                           // cells per unit (sc = 1, 2, 4 -> 4, 2, 1)
+            const int upr = a.wc / cu;                       // units per row of cells
+            const int upc = a.hc * upr;                      // units per channel
+            const int nunit = cpg * upc;
+            for (int u = tid; u < nunit; u += 256) {
+                const int ch = u / upc, r = u - ch * upc;
+                const int y = r / upr, xu = r - y * upr;
+                const float *p = p0 + (size_t)ch * plane + (size_t)sc * y * Wb + 4 * xu;
+                float *o = o0 + (size_t)ch * ncell + y * a.wc + xu * cu;
+                auto acc4 = [&](const f32x4 &r) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s += r[j]; ss += (double)r[j] * r[j]; }
+                };
+                if (sc == 1) {
+                    const f32x4 r0 = __builtin_nontemporal_load((const f32x4 *)p);
+                    acc4(r0);
+                    *(f32x4 *)o = r0;
+                } else if (sc == 2) {
+                    const f32x4 r0 = __builtin_nontemporal_load((const f32x4 *)p);
+                    const f32x4 r1 = __builtin_nontemporal_load((const f32x4 *)(p + Wb));
+                    acc4(r0); acc4(r1);
+                    f32x2 v;
+                    v[0] = ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
+                    v[1] = ((r0[2] + r0[3]) + (r1[2] + r1[3])) * 0.25f;
+                    *(f32x2 *)o = v;
+                } else {
+                    f32x4 rw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rw[i] = __builtin_nontemporal_load((const f32x4 *)(p + (size_t)i * Wb));
+                    float s4 = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s4 += (rw[i][0] + rw[i][1]) + (rw[i][2] + rw[i][3]);
+                        acc4(rw[i]);
+                    }
+                    *o = s4 * 0.0625f;
+                }
+            }
+        } else
         for (int pr = tid; pr < npair; pr += 256) {
             const int ch = pr / ncell, cell = pr - ch * ncell;
             const int y = cell / a.wc, x = cell - y * a.wc;
@@ -134,31 +178,34 @@ __global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__
 // ---- 3. the gate
 // ACT: 0 = single Linear (no hidden layer), 1 = SiLU, 2 = ReLU.  G = logits per cell (2 / 3).
 #define GATE_NW 8            // waves per workgroup of the gate kernel: two per SIMD (the feature tile fills the LDS: one workgroup per CU)
-template <int G>
+// CB = blocks of 32 cells per workgroup: every weight fragment fetched from L2 feeds CB x 3 MFMAs (the stream of
+// weight fragments through one CU's vector-memory path is what bounds the matrix phase); CB = 2 needs the split tile of
+// 64 cells in LDS: F <= 512 (the dual routers).
+template <int G, int CB>
 __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     DvqGateArgs a, const float2 *__restrict__ ab, const float *__restrict__ pool,
     const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL, const float *__restrict__ b1,
     const float *__restrict__ W2, const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate)
 {
-    // LDS: XH | XL halves [Fp/16][64 lanes = 32h + cell][8] each (B operands), then bias / output rows
+    // LDS: per cell block XH | XL halves [Fp/16][64 lanes = 32h + cell][8] each (B operands), then bias / output rows
     extern __shared__ __attribute__((aligned(16))) float X[];
     const int F = a.nb * a.C;
     const int Fp = (F + 15) & ~15;
-    _Float16 *XH = (_Float16 *)X, *XL = XH + 32 * Fp;
     __shared__ unsigned s_amax;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const long ncell = (long)a.B * a.hc * a.wc;
-    const long cell0 = (long)blockIdx.x * 32;
+    const long cell0 = (long)blockIdx.x * 32 * CB;
 
     // ---- feature tile: normalised averages, split into fp16 hi + lo, in MFMA B-operand order.  A thread keeps one
     // cell (tid & 31) and walks the octets of features (tid >> 5) + 2 GATE_NW i: eight loads (one 128-B line per half wave
     // each: the cells of a workgroup are consecutive in pool[b][k][cell]), one 16-B LDS store per image.
-    auto build = [&](float xscale) -> float {
+    auto build = [&](int cb, float xscale) -> float {
         float vmax = 0.0f;
+        _Float16 *XH = (_Float16 *)X + (size_t)cb * 64 * Fp, *XL = XH + 32 * Fp;
         const int cell = tid & 31;
-        const long cg = cell0 + cell;
+        const long cg = cell0 + 32 * cb + cell;
         const bool live = cg < ncell;
         const long cgl = live ? cg : ncell - 1;
         const int nci = a.hc * a.wc;
@@ -231,7 +278,9 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     if (false)
 #endif
     {
-        float vmax = build(1.0f);
+        float vmax = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) vmax = fmaxf(vmax, build(cb, 1.0f));
         atomicMax(&s_amax, __float_as_uint(vmax));          // non-negative floats order like their bits
         __syncthreads();
         const float wgmax = __uint_as_float(s_amax);
@@ -241,15 +290,18 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
             const float xs = ldexpf(1.0f, 10 - e);                        // brings the maximum to ~2^10
             inv_scale = ldexpf(1.0f, e - 10);
             __syncthreads();
-            (void)build(xs);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) (void)build(cb, xs);
         }
     }
     __syncthreads();
 
-    float part[G];
+    float part[CB][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) part[g] = 0.0f;
-    float *PB = X + 32 * Fp;                           // hidden bias + output-layer rows: [1 + G][Hid]
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < G; ++g) part[cb][g] = 0.0f;
+    float *PB = X + CB * 32 * Fp;                        // hidden bias + output-layer rows: [1 + G][Hid]
     if (act != 0) {
         for (int i = tid; i < Hid; i += GATE_NW * 64) {
             PB[i] = b1[i];
@@ -262,21 +314,25 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
         // single Linear: gate[cell][g] = W2[g][:] . x + b2[g]; 2 GATE_NW threads per cell split k
         constexpr int SUB = GATE_NW * 2;
         const int cell = tid / SUB, sub = tid % SUB;
-        for (int k = sub; k < F; k += SUB) {
-            const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
-            const float xv = ((float)XH[idx] + (float)XL[idx]) * inv_scale;
 #pragma unroll
-            for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(W2[(size_t)g * F + k], xv, part[g]);
-        }
+        for (int cb = 0; cb < CB; ++cb) {
+            const _Float16 *XH = (const _Float16 *)X + (size_t)cb * 64 * Fp, *XL = XH + 32 * Fp;
+            for (int k = sub; k < F; k += SUB) {
+                const int idx = (((k >> 4) * 64 + ((k >> 3) & 1) * 32 + cell) * 8) + (k & 7);
+                const float xv = ((float)XH[idx] + (float)XL[idx]) * inv_scale;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+                for (int g = 0; g < G; ++g) part[cb][g] = __builtin_fmaf(W2[(size_t)g * F + k], xv, part[cb][g]);
+            }
 #pragma unroll
-            for (int off = 1; off < SUB; off <<= 1) part[g] += __shfl_xor(part[g], off);
-        }
-        const long cg = cell0 + cell;
-        if (sub == 0 && cg < ncell) {
+            for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) gate[cg * G + g] = part[g] + b2[g];
+                for (int off = 1; off < SUB; off <<= 1) part[cb][g] += __shfl_xor(part[cb][g], off);
+            }
+            const long cg = cell0 + 32 * cb + cell;
+            if (sub == 0 && cg < ncell) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) gate[cg * G + g] = part[cb][g] + b2[g];
+            }
         }
         return;
     }
@@ -288,13 +344,14 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     // ---- hidden layer on the fp16 matrix cores (split operands): wave w takes hidden-row tiles w, w + GATE_NW, ...
     const int T = (Hid + 31) / 32;
     const int S = Fp / 16;
-    const f16x8 *xh = (const f16x8 *)XH + lane, *xl = (const f16x8 *)XL + lane;      // + s * 64 per k-step
-    // The A fragments (hidden-layer weight tiles) come straight from L2, one 16-B load per lane per MFMA triple; the
+    const f16x8 *xh = (const f16x8 *)X + lane;         // cell block cb: + cb * 8 * Fp; lo half: + 4 * Fp; k-step s: + s * 64
+    const int XLO = 4 * Fp, XCB = 8 * Fp;              // in f16x8 units (32 * Fp halves = 4 * Fp fragments)
+    // The A fragments (hidden-layer weight tiles) come straight from L2, one 16-B load per lane per CB MFMA triples; the
     // feature tile fills the LDS, so there is one workgroup per CU and the L2 latency is hidden by its own two waves per
     // SIMD plus software pipelining: the fragments of the next three groups of four k-steps (3 x 8 loads = 96 VGPRs) are
-    // in flight while the current group's twelve MFMAs run.  Groups are numbered through this wave's tiles:
+    // in flight while the current group's MFMAs run.  Groups are numbered through this wave's tiles:
     // g -> (tile wave + GATE_NW (g / GPT), k-steps 4 (g % GPT) ..).
-    auto epilogue = [&](int t, const f32x16 &acc) {    // bias, activation, contraction with the output layer
+    auto epilogue = [&](int t, const f32x16 &acc, float (&pt)[G]) {    // bias, activation, contraction with the output layer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -302,7 +359,7 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
                 const float yv = acc[r] * inv_scale + PB[j];
                 const float hv = (act == 1) ? yv / (1.0f + expf(-yv)) : (yv > 0.0f ? yv : 0.0f);
 #pragma unroll
-                for (int g = 0; g < G; ++g) part[g] = __builtin_fmaf(PB[(1 + g) * Hid + j], hv, part[g]);
+                for (int g = 0; g < G; ++g) pt[g] = __builtin_fmaf(PB[(1 + g) * Hid + j], hv, pt[g]);
             }
         }
     };
@@ -318,24 +375,30 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) { vh[u] = ah[(s0 + u) * 64]; vl[u] = al[(s0 + u) * 64]; }
         };
-        f32x16 acc;
+        f32x16 acc[CB];
         auto step = [&](int g, const f16x8 (&vh)[4], const f16x8 (&vl)[4]) {
             if (g >= NG) return;
             const int t = wave + GATE_NW * (g / GPT), s0 = 4 * (g % GPT);
             if (s0 == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            }
-            f16x8 bh[4], bl[4];
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { bh[u] = xh[(s0 + u) * 64]; bl[u] = xl[(s0 + u) * 64]; }
+                    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[u], bh[u], acc, 0, 0, 0);   // small terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bl[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bh[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const f16x8 bh = xh[cb * XCB + (s0 + u) * 64], bl = xh[cb * XCB + XLO + (s0 + u) * 64];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[u], bh, acc[cb], 0, 0, 0);   // small terms first
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[u], bh, acc[cb], 0, 0, 0);
+                }
             }
-            if (s0 + 4 == S) epilogue(t, acc);
+            if (s0 + 4 == S) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) epilogue(t, acc[cb], part[cb]);
+            }
         };
         if (NG > 0) {
             f16x8 h0[4], l0[4], h1[4], l1[4], h2[4], l2[4], h3[4], l3[4];
@@ -358,33 +421,44 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     for (int t = wave; t < T; t += GATE_NW) {
         const f16x8 *ah = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
         const f16x8 *al = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
-        f32x16 acc;
+        f32x16 acc[CB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
         for (int s0 = 0; s0 < S; ++s0) {
-            const f16x8 vh = ah[s0 * 64], vl = al[s0 * 64], bh = xh[s0 * 64], bl = xl[s0 * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, acc, 0, 0, 0);
+            const f16x8 vh = ah[s0 * 64], vl = al[s0 * 64];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f16x8 bh = xh[cb * XCB + s0 * 64], bl = xh[cb * XCB + XLO + s0 * 64];
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, acc[cb], 0, 0, 0);
+            }
         }
-        epilogue(t, acc);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) epilogue(t, acc[cb], part[cb]);
     }
     }
     __syncthreads();                                   // everyone is done reading X
-    float *red = X;                                    // [GATE_NW waves][G][32 cells]
+    float *red = X;                                    // [GATE_NW waves][CB][G][32 cells]
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        float v = part[g] + __shfl_xor(part[g], 32);
-        if (h == 0) red[(wave * G + g) * 32 + c] = v;
-    }
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float v = part[cb][g] + __shfl_xor(part[cb][g], 32);
+            if (h == 0) red[((wave * CB + cb) * G + g) * 32 + c] = v;
+        }
     __syncthreads();
-    if (tid < 32 * G) {
-        const int cell = tid / G, g = tid - cell * G;
-        const long cg = cell0 + cell;
+    if (tid < 32 * G * CB) {
+        const int cb = tid / (32 * G), rr = tid - cb * 32 * G;
+        const int cell = rr / G, g = rr - cell * G;
+        const long cg = cell0 + 32 * cb + cell;
         if (cg < ncell) {
             float v = 0.0f;
 #pragma unroll
-            for (int w = 0; w < GATE_NW; w += 2) v += red[(w * G + g) * 32 + cell] + red[((w + 1) * G + g) * 32 + cell];
+            for (int w = 0; w < GATE_NW; w += 2)
+                v += red[((w * CB + cb) * G + g) * 32 + cell] + red[(((w + 1) * CB + cb) * G + g) * 32 + cell];
             gate[cg * G + g] = v + b2[g];
         }
     }
@@ -436,6 +510,10 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         a.scale[i] = 1 << i;
     }
     a.nb = nb; a.B = B; a.C = C; a.hc = hc; a.wc = wc; a.groups = groups; a.eps = eps;
+    {
+        const char *e = getenv("DVQ_GATE_POOL_SCALAR");
+        a.vec = (e && e[0] == '1') ? 0 : 1;
+    }
     const int F = nb * C, Fp = (F + 15) & ~15;
     float2 *stats = (float2 *)ws;                            // (scale, shift) per (image, feature)
     float *pool = (float *)((char *)ws + align256r((size_t)B * F * sizeof(float2)));
@@ -449,16 +527,29 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     const _Float16 *imgL = imgH ? imgH + (size_t)((Hid + 31) / 32) * 32 * Fp : nullptr;
     hipLaunchKernelGGL(gate_pool_kernel, dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool);
     const long ncell = (long)B * hc * wc;
-    const unsigned grid = (unsigned)((ncell + 31) / 32);
-    const size_t shmem = ((size_t)32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
-    if (nb == 2) {
-        static unsigned long long done2 = 0;
-        { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<2>, 160 * 1024 - 256, &done2); if (rc) return rc; }
-        hipLaunchKernelGGL(router_gate_kernel<2>, dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool, imgH, imgL, b1, W2, b2, Hid, act, gate);
-    } else {
-        static unsigned long long done3 = 0;
-        { int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<3>, 160 * 1024 - 256, &done3); if (rc) return rc; }
-        hipLaunchKernelGGL(router_gate_kernel<3>, dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool, imgH, imgL, b1, W2, b2, Hid, act, gate);
+    // two blocks of 32 cells per workgroup when the split tile of 64 cells fits the LDS and there are enough cells to keep
+    // every CU busy that way
+    const size_t shmem2 = ((size_t)2 * 32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu = n > 0 ? n : 256;
     }
+    const bool cb2 = act != 0 && shmem2 <= 160 * 1024 - 512 && ncell >= 64L * ncu;
+    const int CBv = cb2 ? 2 : 1;
+    const unsigned grid = (unsigned)((ncell + 32 * CBv - 1) / (32 * CBv));
+    const size_t shmem = cb2 ? shmem2 : ((size_t)32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
+#define DVQ_GATE_LAUNCH(GG, CC)                                                                                        \
+    do {                                                                                                               \
+        static unsigned long long done_ = 0;                                                                           \
+        int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<GG, CC>, 160 * 1024 - 256, &done_);            \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((router_gate_kernel<GG, CC>), dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool,    \
+                           imgH, imgL, b1, W2, b2, Hid, act, gate);                                                    \
+    } while (0)
+    if (nb == 2) { if (cb2) DVQ_GATE_LAUNCH(2, 2); else DVQ_GATE_LAUNCH(2, 1); }
+    else         { if (cb2) DVQ_GATE_LAUNCH(3, 2); else DVQ_GATE_LAUNCH(3, 1); }
+#undef DVQ_GATE_LAUNCH
     return (int)hipGetLastError();
 }

@@ -284,6 +284,11 @@ def test_feature_router_logits(dev, which):
     ("triple", "none", "2layer-fc-SiLu", 1, 3, 2),
     ("triple", "group-16", "1layer-fc", 5, 8, 8),
     ("dual", "none", "2layer-fc-SiLu", 2, 4, 4),
+    # >= 64 cells per CU: the gate kernel takes two blocks of 32 cells per workgroup (ragged last workgroup, odd row
+    # length -> scalar pooling path; triple with three logits; the fp16-range rescale across both blocks)
+    ("dual", "group-32", "2layer-fc-SiLu", 70, 16, 15),
+    ("triple", "group-16", "2layer-fc-ReLu", 260, 8, 8),
+    ("dual", "none", "2layer-fc-SiLu", 64, 16, 16),
 ])
 def test_fused_router_gate_matches_torch_ops(dev, which, norm, gate_type, B, hc, wc):
     """the fused kernel (no_grad) against the same module evaluated with differentiable torch ops
