@@ -476,7 +476,7 @@ def run_rank(a):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from dynamicvectorquantization_amd.encode import CodeExchange
+    from dynamicvectorquantization_amd.encode import CodeExchange, StreamSlots
     from dynamicvectorquantization_amd.quantize import _CodebookPrep
 
     wl = (WeakDual if a.scaling == "weak" else StrongTriple)(a, rank, world, dev)
@@ -486,7 +486,7 @@ def run_rank(a):
     # max(2, S), so the all-gather of step i is completed when its object comes round again, two or more steps later
     # (a 0.6-MB all-gather is latency-bound on xGMI, and RCCL's kernel competes for CUs with a pass 1 that fills the chip)
     S = max(1, a.streams)
-    streams = [torch.cuda.current_stream(dev)] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
+    streams = [torch.cuda.current_stream(dev)] if S == 1 else [sl.stream for sl in StreamSlots(S, dev).slots]
     nx = max(2, S)
     xchs = ([CodeExchange(wl.slots[0].codes, wl.slots[0].grain, K, wl.Bglobal, numel_per_image=H * W * D) for _ in range(nx)]
             if (world > 1 or force_xch) else [])

@@ -546,3 +546,42 @@ def test_wide_kernel_codes_only_and_ragged(dev):
     zq1, c3, l1 = vq_assign(z, Et, pf, None, mode=_lib.MODE_FILTER)
     assert torch.equal(c2, c3) and torch.equal(zq0, zq1) and torch.equal(c0, c2)
     assert abs(float(l0[1]) - float(l1[1])) <= 1e-6 * abs(float(l0[1]))
+
+
+@pytest.mark.gpu
+def test_stream_slots_pipelined_encode_matches_serial(dev, oracle_mod):
+    """encode.StreamSlots: independent batches round-robin on 3 streams through ONE quantizer / router (per-stream
+    workspaces) give the bits of the serial calls, inputs produced on the caller's stream are ordered before the slot's
+    work, join() orders the caller after it"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import StreamSlots, encode_dual
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    B, K, D = 8, 512, 256
+    E = synth.codebook_trained(K, D, seed=31)
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(torch.from_numpy(E).to(dev))
+    router = DualGrainFixedEntropyRouter(os.path.join(os.path.dirname(__file__), "golden",
+                                                      "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    batches = [(synth.z_tokens(E, B, 32, 32, 7000 + i), synth.z_tokens(E, B, 16, 16, 7100 + i), synth.entropy_map(7200 + i, B, 16, 16))
+               for i in range(7)]
+    with torch.no_grad():
+        serial = []
+        for hf, hc, ent in batches:
+            q, loss, info, grain, gate = encode_dual(router, vq, t(hf), t(hc), t(ent))
+            serial.append((q.clone(), float(loss), info[2].clone(), grain.clone()))
+        torch.cuda.synchronize()
+        slots = StreamSlots(3)
+        outs = [None] * len(batches)
+        for i, (hf, hc, ent) in enumerate(batches):
+            a, b, c = t(hf) * 1.0, t(hc) * 1.0, t(ent) * 1.0          # produced on the caller's stream just before
+            with slots.next() as slot:
+                outs[i] = encode_dual(router, vq, a, b, c)
+                for x in (a, b, c):
+                    x.record_stream(slot.stream)
+        slots.join()
+        for i, (q, loss, info, grain, gate) in enumerate(outs):
+            assert torch.equal(q, serial[i][0]) and torch.equal(info[2], serial[i][2]) and torch.equal(grain, serial[i][3])
+            assert abs(float(loss) - serial[i][1]) <= 1e-6 * abs(serial[i][1])
+
