@@ -585,3 +585,39 @@ def test_stream_slots_pipelined_encode_matches_serial(dev, oracle_mod):
             assert torch.equal(q, serial[i][0]) and torch.equal(info[2], serial[i][2]) and torch.equal(grain, serial[i][3])
             assert abs(float(loss) - serial[i][1]) <= 1e-6 * abs(serial[i][1])
 
+
+@pytest.mark.gpu
+def test_fused_router_gate_fuzz(dev):
+    """40 random router configurations (branches, channels, grid, batch, normalisation, gate type): the fused gate
+    (one pooling pass + MLP kernel, either cell-block form, vector / scalar pooling) against the module's own torch ops"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    rng = np.random.default_rng(20261003)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for case in range(40):
+        nbr = int(rng.integers(2, 4))
+        Cc = int(rng.choice([32, 64, 128, 256]))
+        hc, wc, B = int(rng.integers(1, 13)), int(rng.integers(1, 13)), int(rng.integers(1, 10))
+        if case % 10 == 9:                                   # now and then enough cells for two blocks per workgroup
+            hc, wc, B = 16, 16, 64 + int(rng.integers(0, 3))
+            Cc = int(rng.choice([32, 64]))
+        norm = str(rng.choice(["none", "group-8", "group-32"]))
+        gate_type = str(rng.choice(["1layer-fc", "2layer-fc-SiLu"] + (["2layer-fc-ReLu"] if nbr == 3 else [])))
+        torch.manual_seed(100 + case)
+        r = (DualGrainFeatureRouter if nbr == 2 else TripleGrainFeatureRouter)(Cc, norm, gate_type).to(dev)
+        with torch.no_grad():
+            for n_, p_ in r.named_parameters():
+                if "feature_norm" in n_:
+                    p_.copy_(torch.randn_like(p_) * 0.5 + (1.0 if n_.endswith("weight") else 0.0))
+        feats = [t(synth.features(900 + 3 * case + i, B, Cc, hc << i, wc << i) * np.float32(1.5) + np.float32(0.3)) for i in range(nbr)]
+        kw = dict(h_coarse=feats[0], h_fine=feats[-1])
+        if nbr == 3:
+            kw["h_median"] = feats[1]
+        with torch.no_grad():
+            fused = r(**kw)
+            again = r(**kw)                                  # second call: cached weight images
+        ref = r(**kw).detach()
+        assert torch.equal(fused, again), case
+        err = float((fused - ref).abs().max())
+        assert err < 1e-4 * max(1.0, float(ref.abs().max())), (case, nbr, Cc, hc, wc, B, norm, gate_type, err)
+
