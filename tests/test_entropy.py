@@ -51,17 +51,20 @@ def test_fused_entropy_refuses_cpu_tensors():
 
 @pytest.mark.gpu
 def test_fused_entropy_full_batch(dev):
-    """B = 64: fused kernel vs the reference op sequence (torch ops) on the same device"""
+    """B = 64: fused kernel vs the reference op sequence as torch ops ON THE CPU (the reference path of record).  Not on
+    the GPU: flat patches whose gray value sits ~14.4 sigma below the first bin give a kernel value of one or two fp32
+    SUBNORMAL ulps, which the normalisation by (sum + 1e-40) turns into an entropy of ~1e-4; glibc's expf and this
+    kernel round such values to the nearest subnormal, torch's device exp flushes them to zero."""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.entropy import Entropy
     from oracle.entropy_torch import entropy_map
     img, noisy = synth.images_flat_noise(5001, 64)
-    x = torch.from_numpy(img).to(dev)
+    x = torch.from_numpy(img)
     with torch.no_grad():
-        a = Entropy(16, 256, 256)(x)
+        a = Entropy(16, 256, 256)(x.to(dev)).cpu()
         b = entropy_map(x, chunk=8)
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
-    assert np.array_equal((a > 1.6777750253677368).cpu().numpy(), noisy)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), float((a - b).abs().max())
+    assert np.array_equal((a > 1.6777750253677368).numpy(), noisy)
 
 
 @pytest.mark.gpu
@@ -88,3 +91,39 @@ def test_threshold_calibration_matches_reference_procedure(dev):
         gate = r(entropy=torch.from_numpy(ent.reshape(1, 1, -1).copy()).to(dev))
         frac = float(gate[..., 1].float().mean())
         assert abs(frac - 0.25) < 0.02, frac
+
+
+@pytest.mark.gpu
+def test_fused_entropy_value_sweep_and_special_pixels(dev):
+    """patches built to stress the two-exp factorisation of the fused kernel: flat patches at every offset between two
+    bin centres and outside [0, 1] (the reference's [-1, 1] images against bins on [0, 1]), smooth ramps, two-level
+    patches, and NaN / Inf pixels -- against the reference's op sequence as torch ops on the CPU"""
+    from dynamicvectorquantization_amd.entropy import Entropy
+    from oracle.entropy_torch import entropy_map
+    rng = np.random.default_rng(7)
+    img = np.zeros((4, 3, 256, 256), dtype=np.float32)
+    vals = np.concatenate([np.linspace(-0.25, 1.25, 200), rng.uniform(-1, 1, 56)]).astype(np.float32)
+    for i in range(256):                                         # image 0: flat patches, value sweep
+        py, px = divmod(i, 16)
+        img[0, :, py * 16:(py + 1) * 16, px * 16:(px + 1) * 16] = vals[i]
+    ramp = np.linspace(0, 1, 256, dtype=np.float32)
+    img[1] = ramp[None, None, :] * np.float32(0.9) + ramp[None, :, None] * np.float32(0.1)       # smooth ramps
+    two = rng.uniform(0, 1, (16, 16, 2)).astype(np.float32)
+    sel = rng.integers(0, 2, (256, 256))
+    for py in range(16):
+        for px in range(16):
+            blk = sel[py * 16:(py + 1) * 16, px * 16:(px + 1) * 16]
+            img[2, :, py * 16:(py + 1) * 16, px * 16:(px + 1) * 16] = two[py, px][blk]
+    img[3] = rng.uniform(-1, 1, (3, 256, 256)).astype(np.float32)
+    img[3, 0, 5, 5] = np.nan                                     # patch (0, 0): NaN -> NaN entropy
+    img[3, 1, 40, 200] = np.inf                                  # patch (2, 12): +Inf pixel contributes nothing ...
+    img[3, 2, 100, 100] = -np.inf                                # ... but 0.114 * -inf + finite = -inf, same
+    x = torch.from_numpy(img)
+    with torch.no_grad():
+        a = Entropy(16, 256, 256)(x.to(dev)).cpu().numpy()
+        b = entropy_map(x, chunk=2).numpy()                        # on the CPU: see test_fused_entropy_full_batch
+    nan_b = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan_b) and nan_b[3, 0, 0]
+    ok = ~nan_b
+    assert np.all(np.abs(a[ok] - b[ok]) <= 1e-5 * np.maximum(1.0, np.abs(b[ok]))), float(np.abs(a[ok] - b[ok]).max())
+

@@ -1,0 +1,118 @@
+"""One roofline line per kernel of the path at BASELINE sizes (algorithmic bytes / flops per
+launch divided by the launch's duration, against the MI355X peaks: HBM 8 TB/s, fp16 MFMA 2500 TFLOP/s dense, fp32 MFMA
+157.3 TFLOP/s).  Durations are HIP-event means over back-to-back launches of the ABI op that consists of (almost) only
+that kernel; multi-kernel ops are listed with what the bracket contains.  Prints one JSON object."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicvectorquantization_amd import synth, _lib
+from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
+from dynamicvectorquantization_amd.router import (DualGrainFeatureRouter, TripleGrainFeatureRouter, route_select_dual_entropy,
+                                                  route_select_triple)
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(a).to(dev)
+HBM, F16, F32 = 8000.0, 2500.0, 157.3      # GB/s, TFLOP/s, TFLOP/s
+THR = 1.6777750253677368
+
+
+def timeit(fn, n=60, warm=15):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3       # seconds
+
+
+rows = []
+def row(kernel, what, seconds, nbytes=None, flops=None, peak_tf=None, note=""):
+    r = {"kernel": kernel, "workload": what, "us": round(seconds * 1e6, 1)}
+    if nbytes is not None:
+        r["algorithmic_MB"] = round(nbytes / 1e6, 1)
+        r["GB_per_s"] = round(nbytes / seconds / 1e9, 1)
+        r["hbm_frac"] = round(nbytes / seconds / 1e9 / HBM, 3)
+    if flops is not None:
+        r["algorithmic_GFLOP"] = round(flops / 1e9, 1)
+        r["TFLOP_per_s"] = round(flops / seconds / 1e12, 1)
+        r["mfma_frac"] = round(flops / seconds / 1e12 / peak_tf, 3)
+        r["mfma_peak"] = peak_tf
+    if note:
+        r["note"] = note
+    rows.append(r)
+
+
+B, K, D = 256, 1024, 256
+En = synth.codebook_trained(K, D)
+b0 = 32
+tile = lambda x, BB=B: torch.cat([torch.roll(x, 5 * k, -1) for k in range((BB + b0 - 1) // b0)], 0)[:BB].contiguous()
+hf, hc, ent, E = (tile(t(synth.z_tokens(En, b0, 32, 32, 2903))), tile(t(synth.z_tokens(En, b0, 16, 16, 2913))),
+                  tile(t(synth.entropy_map(5903, b0, 16, 16))), t(En))
+N = B * 1024
+vq_bytes = N * (D * 4 * 2 + 8 + 4) + K * D * 4
+vq_flops = 2.0 * K * D * N
+zq = torch.empty_like(hf); codes = torch.empty((B, 32, 32), dtype=torch.int64, device=dev); loss = torch.empty(2, device=dev)
+grain = torch.empty((B, 16, 16), dtype=torch.int64, device=dev); cmask = torch.empty((B, 1, 32, 32), device=dev)
+gate = torch.empty((B, 16, 16, 2), dtype=torch.int64, device=dev); h_dual = torch.empty_like(hf)
+prep = _CodebookPrep()
+for _ in range(300):                          # bring the part out of its idle power state before the first measurement
+    vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None))
+torch.cuda.synchronize()
+s = timeit(lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1,
+                                         out=(zq, codes, None, grain, cmask, gate)))
+row("vq_assign_filter_kernel<256,1,true> (pass 1, select fused in)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
+    "bracket includes the 4.6-us counter-zero kernel; VQ-forward byte count (the kernel also does the select's work); socket power cap binds (DESIGN 5)")
+s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)))
+row("vq_assign_filter_kernel<256,0,true> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "bracket includes the counter-zero kernel")
+s_full = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER, out=(zq, codes, loss)))
+row("dense filter op (zero + pass 1 + resolver + list/finalize)", "B=256 K=1024", s_full, vq_bytes, vq_flops, F16)
+s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_EXACT, out=(zq, codes, loss)), n=10, warm=3)
+row("vq_assign_exact_kernel<256> (fp32 MFMA chain)", "B=256 K=1024", s, vq_bytes, vq_flops, F32)
+s = timeit(lambda: route_select_dual_entropy(ent, THR, hc, hf, out=(h_dual, grain, cmask, gate)))
+row("route_select_kernel (dual, entropy gate fused)", "B=256", s, N * (D * 4 * 2 + 4) + B * 256 * (4 + 8 + 16))
+# large codebook
+E16n = synth.codebook_trained(16384, 256)
+E16 = t(E16n)
+zb = t(synth.z_tokens(E16n, 64, 32, 32, 2005)).repeat(8, 1, 1, 1)
+p16 = _CodebookPrep()
+s = timeit(lambda: vq_assign(zb, E16, p16, None, mode=_lib.MODE_FILTER_PASS1), n=5, warm=2)
+row("vq_assign_filter_wide_kernel<256,true> (pass 1, K=16384)", "configs[4] B=512", s, 512 * 1024 * 2060 + 16384 * 1024, 2.0 * 16384 * 256 * 512 * 1024, F16,
+    "matrix-bound config; runs power-limited like the K=1024 loop")
+del zb, E16, p16
+# feature-router gate, triple B=128 and dual B=64: rocprof splits pool / MLP (profiles/r02_gate_kernels_*.txt); here the op
+r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
+f3 = [t(synth.z_tokens(En, 128, 8 << i, 8 << i, 2124 - 10 * i)) for i in range(3)]
+with torch.no_grad():
+    s = timeit(lambda: r3(h_fine=f3[2], h_median=f3[1], h_coarse=f3[0]))
+feat_bytes3 = sum(x.numel() * 4 for x in f3)
+row("gate_pool_kernel + router_gate_kernel<3,1> (triple gate op)", "configs[3] per-rank B=128", s, feat_bytes3,
+    3 * 2.0 * 768 * 768 * 128 * 64, F16, "bytes = the branch features once; flops = the 3-term split hidden layer; pool 35-37 us at the HBM read rate, MLP 49-51 us bound by the weight-fragment stream of one CU")
+r2 = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
+f2 = [t(synth.z_tokens(En, 64, 16 << i, 16 << i, 2112 - 10 * i)) for i in range(2)]
+with torch.no_grad():
+    s = timeit(lambda: r2(h_fine=f2[1], h_coarse=f2[0]))
+row("gate_pool_kernel + router_gate_kernel<2,2> (dual gate op)", "configs[1] B=64", s, sum(x.numel() * 4 for x in f2),
+    3 * 2.0 * 512 * 512 * 64 * 256, F16)
+# quant_conv
+from dynamicvectorquantization_amd.qconv import quant_conv, quant_conv_select
+qc = torch.nn.Conv2d(256, 256, 1).to(dev).eval()
+with torch.no_grad():
+    g2 = r2(h_fine=f2[1], h_coarse=f2[0])
+    s = timeit(lambda: quant_conv_select(qc, f2[0], f2[1], gate=g2))
+npos = 64 * 1024
+row("qconv_kernel<256,SEL> (select + 1x1 conv, split-fp16 MFMA)", "configs[1] B=64", s, npos * D * 4 * 2, 3 * 2.0 * 256 * 256 * npos, F16)
+# entropy map
+from dynamicvectorquantization_amd.entropy import Entropy
+img = t(synth.images_flat_noise(5000, 64)[0])
+ef = Entropy(16, 256, 256).to(dev)
+with torch.no_grad():
+    s = timeit(lambda: ef(img), n=20, warm=5)
+row("entropy_map_kernel", "B=64 images 3x256x256", s, img.numel() * 4 + 64 * 256 * 4, note="bound by exp / log throughput: 32 bins x 256 pixels per patch")
+# EMA statistics
+cs, vs = torch.zeros(K, device=dev), torch.zeros(K, D, device=dev)
+cod = torch.randint(0, K, (B, 32, 32), device=dev)
+def ema():
+    _lib.check(_lib.lib.dvq_ema_accumulate_nchw_f32(hf.data_ptr(), cod.data_ptr(), B, D, 1024, K, cs.data_ptr(), vs.data_ptr(), _lib.stream_ptr(dev)), "ema")
+s = timeit(ema, n=20, warm=5)
+row("ema_accumulate_kernel", "B=256 K=1024 (uniform random codes)", s, N * (D * 4 + 8), note="float atomics into K*D sums: atomic throughput, not HBM")
+print(json.dumps({"peaks": {"hbm_GB_per_s": HBM, "fp16_mfma_TFLOP_per_s": F16, "fp32_mfma_TFLOP_per_s": F32}, "rows": rows}, indent=1))
