@@ -527,6 +527,80 @@ class VectorQuantize2(nn.Module):
         self.codebook.invalidate_codebook_cache()
 
 
+class VectorQuantize2List(nn.Module):
+    """Reference modules/vector_quantization/quantize2_list.py:135-170 (class `VectorQuantize2` there): the input is a
+    LIST of channel-last tensors x_i [..., D] (one per image, any number of tokens each); returns
+    (list of x_q_i, loss, (None, None, list of codes_i)) with loss = mean over the items of
+    beta * mean((e - x_i)^2) + mean((e - x_i)^2).  Same parameters / buffers / state_dict keys as VectorQuantize2.
+
+    Inference (no gradient, eval mode): ONE assign over the concatenated token rows, split afterwards.  Training or
+    gradients: item by item through the same differentiable op as VectorQuantize2, so the EMA update after item i is
+    seen by item i + 1 exactly as in the reference's loop."""
+
+    def __init__(self, codebook_size, codebook_dim=None, commitment_beta=0.25, decay=0.99, restart_unused_codes=True):
+        super().__init__()
+        self.beta = commitment_beta
+        self.restart_unused_codes = restart_unused_codes
+        self.codebook = VQEmbedding(codebook_size, codebook_dim, decay=decay, restart_unused_codes=restart_unused_codes)
+        self.codebook.weight.data.uniform_(-1.0 / codebook_size, 1.0 / codebook_size)
+        self.assign_mode = _lib.MODE_FILTER
+
+    def forward(self, x_list, *ignorewargs, **ignorekwargs):
+        K, D = self.codebook.n_embed, self.codebook.weight.shape[1]
+        n_items = len(x_list)
+        if n_items == 0:
+            raise ValueError("x_list is empty")
+        needs_grad = torch.is_grad_enabled() and (any(x.requires_grad for x in x_list) or self.codebook.weight.requires_grad)
+        if not self.training and not needs_grad:
+            rows = [x.reshape(-1, D) for x in x_list]
+            counts = [r.shape[0] for r in rows]
+            z = torch.cat(rows, 0) if n_items > 1 else rows[0]
+            zq, codes, _ = vq_assign(z, self.codebook.weight[:K], self.codebook._prep, None, beta=float(self.beta),
+                                     want_loss=False, mode=self.assign_mode)
+            e = embed_gather(self.codebook.weight, codes.reshape(1, -1)).reshape(-1, D)
+            loss = z.new_zeros(())
+            xq_list, code_list, o = [], [], 0
+            for x, n in zip(x_list, counts):
+                m = torch.mean((e[o:o + n] - rows[len(xq_list)]) ** 2)
+                loss = loss + (self.beta * m + m)
+                xq_list.append(zq[o:o + n].reshape(x.shape))
+                code_list.append(codes[o:o + n].reshape(x.shape[:-1]))
+                o += n
+            return xq_list, loss / n_items, (None, None, code_list)
+        xq_list, code_list = [], []
+        loss = 0.0
+        for x in x_list:
+            z = x.reshape(-1, D)
+            if self.training:
+                self.codebook._prep.invalidate()
+            zq, l_i, codes = _VQStraightThrough.apply(z, self.codebook.weight, None, self.codebook._prep, K,
+                                                      float(self.beta), 1.0, self.assign_mode)
+            if self.training and self.codebook.ema:
+                with torch.no_grad():
+                    self.codebook._update_buffers(z, codes.reshape(-1))
+                    self.codebook._update_embedding()
+            loss = loss + l_i
+            xq_list.append(zq.reshape(x.shape))
+            code_list.append(codes.reshape(x.shape[:-1]))
+        return xq_list, loss / n_items, (None, None, code_list)
+
+    @torch.no_grad()
+    def get_soft_codes(self, x, temp=1.0, stochastic=False):
+        d = self.codebook.compute_distances(x)
+        soft = torch.softmax(d / (-temp), dim=-1)
+        if stochastic:
+            code = torch.multinomial(soft.reshape(-1, soft.shape[-1]), 1).reshape(soft.shape[:-1])
+        else:
+            code = torch.argmin(d, dim=-1)
+        return soft, code
+
+    def get_codebook_entry(self, indices, *kwargs):
+        return self.codebook.embed(indices)
+
+    def invalidate_codebook_cache(self):
+        self.codebook.invalidate_codebook_cache()
+
+
 class VectorQuantizer2(nn.Module):
     """Reference modules/vector_quantization/quantize_vqgan.py:213-341 (taming-style quantizer,
     used by the fixed-granularity VQModel with beta=0.25, remap=None, legacy=False)."""

@@ -211,3 +211,66 @@ def test_prep_cache_invalidation_and_streams(dev, oracle_mod):
         assert np.array_equal(res["b"][2][2].cpu().numpy().reshape(B, -1), ob["codes"])
         assert np.array_equal(res["b"][0].cpu().numpy(), ob["zq"])
         assert C.loss_close(float(res["a"][1]), oracle_mod.vq_loss(o1["sqerr"], o1["numel"], 0.25))
+
+
+def _list_items(E, seed):
+    from dynamicvectorquantization_amd import synth
+    out = []
+    for i, shp in enumerate([(5, 7), (33,), (2, 3, 4)]):
+        n = int(np.prod(shp))
+        z = synth.z_tokens(E, 1, n, 1, seed + i)
+        out.append(np.ascontiguousarray(z[0, :, :, 0].T).reshape(shp + (E.shape[1],)))
+    return out
+
+
+@pytest.mark.gpu
+def test_list_quantizer_eval_golden(dev):
+    """VectorQuantize2List (quantize2_list.py:135-170) in eval mode: one assign over the concatenated rows; codes and
+    x_q of every item bit-exact vs the imported reference, loss 1e-5"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2List
+    g = C.load("vq2_list_eval")
+    K, D = int(g["K"]), int(g["D"])
+    E = synth.codebook_trained(K, D, seed=7301)
+    xs = _list_items(E, 7310)
+    assert C.crc(E) == g["cb_crc"] and [C.crc(x) for x in xs] == list(g["x_crc"])
+    m = VectorQuantize2List(K, D).to(dev).eval()
+    m.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    assert sorted(m.state_dict().keys()) == ["codebook.cluster_size_ema", "codebook.embed_ema", "codebook.weight"]
+    with torch.no_grad():
+        xq, loss, (_, _, codes) = m([torch.from_numpy(x).to(dev) for x in xs])
+    for i, x in enumerate(xs):
+        assert codes[i].shape == x.shape[:-1] and xq[i].shape == x.shape
+        assert np.array_equal(codes[i].cpu().numpy(), g["codes%d" % i].astype(np.int64)), i
+        assert C.crc(xq[i].cpu().numpy()) == g["xq_crc%d" % i], i
+    assert C.loss_close(float(loss), g["loss"])
+
+
+@pytest.mark.gpu
+def test_list_quantizer_train_golden(dev, monkeypatch):
+    """train mode: the EMA update after item i is what item i + 1 is quantized with (the reference's loop), gradients
+    of every item, buffers and codebook after the step vs the imported reference"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2List
+    g = C.load("vq2_list_train")
+    K, D = int(g["K"]), int(g["D"])
+    E = synth.codebook_trained(K, D, seed=7401)
+    xs = _list_items(E, 7410)
+    gws = [synth.normal(7420 + i, x.shape) for i, x in enumerate(xs)]
+    assert C.crc(E) == g["cb_crc"] and [C.crc(x) for x in xs] == list(g["x_crc"])
+    m = VectorQuantize2List(K, D, restart_unused_codes=True).to(dev)
+    m.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    m.codebook.embed_ema.copy_(torch.from_numpy(E))
+    m.train()
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.arange(n - 1, -1, -1, device=device))
+    xt = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
+    xq, loss, (_, _, codes) = m(xt)
+    (sum((q * torch.from_numpy(gw).to(dev)).sum() for q, gw in zip(xq, gws)) + 2.0 * loss).backward()
+    for i in range(len(xs)):
+        assert np.array_equal(codes[i].cpu().numpy(), g["codes%d" % i].astype(np.int64)), i
+        assert _close(xt[i].grad.cpu().numpy(), g["grad%d" % i], 1e-6), i
+    assert C.loss_close(float(loss), g["loss"])
+    for name, got in (("cluster_size_ema", m.codebook.cluster_size_ema), ("embed_ema", m.codebook.embed_ema),
+                      ("weight_after", m.codebook.weight[:K])):
+        assert _close(got.detach().cpu().numpy(), g[name], 1e-5), name
+
