@@ -309,7 +309,7 @@ class WeakDual:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
+        return "vq_assign_filter_kernel<256, 0, true>" if self.a.path == "select" else "vq_assign_filter_kernel<256, 1, true> (router select fused in)"
 
     def parity(self, slot):
         """the step's outputs, still in HBM, against the oracle on ALL images of this rank"""
@@ -424,7 +424,7 @@ class StrongTriple:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256,false>" if self.a.path == "select" else "vq_assign_filter_kernel<256,true> (router select fused in)"
+        return "vq_assign_filter_kernel<256, 0, true>" if self.a.path == "select" else "vq_assign_filter_kernel<256, 1, true> (router select fused in)"
 
     def parity(self, slot):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
