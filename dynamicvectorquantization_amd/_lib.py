@@ -13,7 +13,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libdvq.so")
+# DVQ_LIBRARY: load another build of the same sources instead (tools/ use csrc/libdvq_tuning.so, made by
+# `make -C csrc tuning`, which additionally exports the A/B switches dvq_tuning_set / dvq_tuning_buffers)
+LIB_PATH = os.environ.get("DVQ_LIBRARY") or os.path.join(CSRC, "libdvq.so")
 
 DVQ_OK = 0
 MODE_EXACT = 0
@@ -32,7 +34,7 @@ EXPORTS = (
     "dvq_embed_gather_f32",
     "dvq_vq_assign_routed_workspace_bytes", "dvq_vq_assign_routed_dual_f32", "dvq_vq_assign_routed_triple_f32",
     "dvq_vq_assign_routed_fallback_count_offset",
-    "dvq_exchange_bytes", "dvq_exchange_pack", "dvq_exchange_unpack", "dvq_set_pass1_variant", "dvq_debug_filter_scores_f32",
+    "dvq_exchange_bytes", "dvq_exchange_pack", "dvq_exchange_unpack", "dvq_debug_filter_scores_f32",
     "dvq_qconv_prep_bytes", "dvq_qconv_prepare_f32", "dvq_qconv_f32", "dvq_qconv_select_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
     "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_prep_bytes", "dvq_router_gate_prepare_f32", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
@@ -92,10 +94,13 @@ def _load():
     lib.dvq_qconv_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.dvq_qconv_select_f32.restype = i32
     lib.dvq_qconv_select_f32.argtypes = [i32, vp, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    if hasattr(lib, "dvq_tuning_set"):                     # tuning build only
+        lib.dvq_tuning_set.restype = i32
+        lib.dvq_tuning_set.argtypes = [ctypes.c_char_p, i32]
+        lib.dvq_tuning_buffers.restype = i32
+        lib.dvq_tuning_buffers.argtypes = [vp, vp]
     lib.dvq_debug_filter_scores_f32.restype = i32
     lib.dvq_debug_filter_scores_f32.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
-    lib.dvq_set_pass1_variant.restype = i32
-    lib.dvq_set_pass1_variant.argtypes = [i32, i32]
     lib.dvq_exchange_bytes.restype = sz
     lib.dvq_exchange_bytes.argtypes = [i64, i64, i32, i32]
     lib.dvq_exchange_pack.restype = i32

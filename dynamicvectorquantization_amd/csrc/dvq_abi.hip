@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 201   // 0.2.1
+#define DVQ_VERSION 300   // 0.3.0
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -34,7 +34,6 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
                       double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st);
-size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
@@ -71,7 +70,6 @@ size_t dvq_qconv_prep_bytes_impl(int D);
 int dvq_launch_qconv_prep(const float *Wt, const float *bias, int D, void *prep, hipStream_t st);
 int dvq_launch_qconv(const float *x, const DvqRouted *rv, const void *prep, int D, int HW, long N, float *hout,
                      hipStream_t st);
-int dvq_choose_pass1_variant(int dense, int routed);
 int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
                                    float *thr2W, float *xn, float *scale_b_out, hipStream_t st);
 size_t dvq_xch_bytes(long cpi, long gpi, int b_max, int num_codes);
@@ -200,8 +198,7 @@ size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int 
     const int HWout = SC * hc * SC * wc;
     const long N = (long)B * HWout;
     (void)mode;                                          // sized for the filter path in every mode
-    return partials_bytes_for(routed_ids(num_branches, B, N)) + dvq_filter_ws_extra_bytes(D, HWout, K, N) +
-           dvq_routed_tables_bytes(num_branches, B, hc, wc) + 256;
+    return partials_bytes_for(routed_ids(num_branches, B, N)) + dvq_filter_ws_extra_bytes(D, HWout, K, N) + 256;
 }
 
 size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K)
@@ -227,7 +224,6 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
     int SC;
     if (!routed_dims(nb, hc, wc, &SC)) { dvq_set_error("%s: hc*wc=%ld exceeds %d coarse cells", fn, (long)hc * wc, DVQ_ROUTE_MAX_CELLS_ABI); return DVQ_EUNSUPPORTED; }
-    if (nb == 2 && wc % 2 != 0) { dvq_set_error("%s: wc=%d must be even (codebook_mask rows move as 16-byte pieces)", fn, wc); return DVQ_EUNSUPPORTED; }
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
     if (pass1_only) mode = DVQ_MODE_FILTER;
     if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("%s: unknown mode %d", fn, mode); return DVQ_EINVAL; }
@@ -510,7 +506,7 @@ int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, floa
     if (N >= (1L << 31)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
     DvqRouted rv{};
     rv.G = num_branches; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = SC * wc; rv.HWout = SC * hc * SC * wc;
-    rv.dense = 1; rv.gate = gate; rv.gate_mode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
+    rv.gate = gate; rv.gate_mode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
     rv.thr = threshold; rv.indices = (const long long *)indices;
     rv.indices_out = (long long *)indices; rv.cmask_out = cmask; rv.gate_out = (long long *)gate_out;
     if (num_branches == 2) {
@@ -530,15 +526,6 @@ int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, in
     if (!dim_ok(D)) { dvq_set_error("dvq_debug_filter_scores_f32: D=%d unsupported", D); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_filter_scores_debug(tokens, n, prep, D, K, scores, threshold, xn, scale, (hipStream_t)stream),
                   "filter_scores_debug");
-}
-
-int dvq_set_pass1_variant(int dense_variant, int routed_variant)
-{
-    if (dvq_choose_pass1_variant(dense_variant, routed_variant) != 0) {
-        dvq_set_error("dvq_set_pass1_variant: dense in -2..3, routed in {-2, 0..3}");
-        return DVQ_EINVAL;
-    }
-    return DVQ_OK;
 }
 
 size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes)

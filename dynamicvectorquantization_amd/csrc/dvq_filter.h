@@ -1,6 +1,6 @@
-// dvq_filter.h -- declarations shared by the fp16-filter assign kernels (vq_assign_filter.hip: dense
-// pass 1, resolver; vq_assign_routed.hip: routing prepass + routed / low-register pass 1) and by the
-// exact kernel's routed list mode (vq_assign_exact.hip).
+// dvq_filter.h -- declarations shared by the fp16-filter assign kernels (vq_assign_filter.hip: pass 1,
+// resolver), the routing prepass of the exact routed mode (vq_assign_routed.hip), the 1x1 conv with the select
+// fused in (qconv.hip) and the exact kernel's routed list mode (vq_assign_exact.hip).
 #pragma once
 #include "dvq_common.h"
 
@@ -25,10 +25,10 @@ static constexpr int RES_CAND = 512;              // resolver: candidate pairs p
 // record of one queued token (written by pass 1, read by the resolver)
 //   [zf: D*4 B in channel order][meta 32 B]   (the resolver re-derives the fp16 fragments: same RNE conversion)
 __host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; }
-//   n:    output position of the token (b*HW + hw); a routed token covers the rep x rep block whose top-left
-//         corner is n (rows Wout apart)
+//   n:    output position of the token (b*HW + hw); rep = 1 (a token that covered rep x rep positions, rows Wout apart,
+//         belonged to the de-duplicated forms of round 2; the resolver still honours the field)
 //   best: merged (distance, code) key of the sliced resolver (large K), ~0 = none yet; written ~0 by pass 1
-//   tokid: what the exact list carries for the token (dense: n; routed: its unique-token id, slot*32 + lane)
+//   tokid: what the exact list carries for the token (= n)
 struct RecMeta { int n; float xn; float thr; int tokid; unsigned long long best; int prov; int rep; };   // 32 B
 
 // The bound W on |G - truth| (derivation: header of vq_assign_filter.hip);
@@ -72,32 +72,19 @@ __device__ __forceinline__ float vmax3_raw(float a, float b, float c)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Routed token view: the unique tokens of a dual / triple granularity batch, addressed straight in
-// the encoder branches (no h_dual / h_triple tensor exists).
+// Routed token view: a dual / triple granularity batch addressed straight in the encoder branches (no
+// h_dual / h_triple tensor exists).  One token per OUTPUT POSITION: the select is fused into a dense assign,
+// every wave owns whole output rows, and the grain of a position's cell comes straight from the gate
+// (pass 1) or from `indices` (exact-list kernel, resolver).
 //
 // Grain type g (0 coarse, [1 median,] G-1 fine) owns a source tensor src[g] [B, D, sub_g*hc, sub_g*wc]
-// (sub = tokens per coarse-cell edge: dual 1 / 2, triple 1 / 2 / 4) and covers rep_g x rep_g output
-// positions per token (rep = SC / sub, SC = sub of the fine type).
-//
-// Token order: inside an image, row-major by the token's TOP-LEFT output position (y0, x0); images in
-// batch order; no padding anywhere, types mix freely (source stride and replication are per lane).  So
-// the 32 tokens of a wave (a "slot") cover one or two whole rows of the output grid: a row of a fine
-// region takes its fine tokens left to right, interleaved with the coarse / median tokens whose block
-// starts in that row, and every 128-B line of z_q is written completely by one wave or by two adjacent
-// waves of one workgroup within a microsecond -- the L2 merges them.  (With the types in separate waves
-// the 8-byte pieces of a line arrived from different CUs at different times and every line went to HBM
-// as read-modify-write: measured 2.2x slower.)
-// The routing prepass (routed_prepass_kernel) writes, per image, the table rank -> token (`tok`) and the
-// image's token count; imgstart[b] = number of tokens before image b, imgstart[B] = all of them.
+// (sub = tokens per coarse-cell edge: dual 1 / 2, triple 1 / 2 / 4); an element of it is the value of
+// rep_g x rep_g output positions (rep = SC / sub, SC = sub of the fine type).
+// (Scoring only the unique tokens -- 640 of 1024 per image at fine ratio 0.5 -- was built three times in round 2 and
+// measured slower every time: the z_q lines are then assembled from 8-byte pieces by different instructions; see
+// DESIGN.md section 4.3 and profiles/r02_*dedup*.)
 // ---------------------------------------------------------------------------------------------
 #define DVQ_ROUTE_MAX_CELLS 1024
-
-// tok entry: [15:14] grain type, [13:12] sy, [11:10] sx (position inside the coarse cell, in the type's grid),
-// [9:0] coarse cell index
-__host__ __device__ inline unsigned short dvq_tok_pack(int g, int sy, int sx, int cell)
-{
-    return (unsigned short)((g << 14) | (sy << 12) | (sx << 10) | cell);
-}
 
 struct DvqRouted {
     const float *src[3];
@@ -105,54 +92,66 @@ struct DvqRouted {
     int rep[3];               // output positions per token edge
     int G, B, D, hc, wc;
     int Wout, HWout;          // output grid: SC*wc, (SC*hc)*(SC*wc)
-    const int *imgstart;      // [B + 1]
-    const unsigned short *tok;   // [B][HWout]
-    int dense;                // 1: one token per OUTPUT POSITION (no de-duplication; rank = position, rep = 1):
-                              //    the select fused into a dense assign, every wave owns whole output rows.
-                              //    No tables: the grain of a position's cell comes from `indices` (written by the
-                              //    prepass or by pass 1 itself), or straight from the gate (dvq_gate_argmax)
-    const long long *indices; // [B, hc, wc] grain index per coarse cell (dense form)
-    const void *gate;         // router output the grain is derived from (pass 1 of the dense form)
+    const long long *indices; // [B, hc, wc] grain index per coarse cell (what the list kernel re-derives a token's source from)
+    const void *gate;         // router output the grain is derived from (pass 1)
     int gate_mode;            // 0 f32 logits [.., G], 1 int64 [.., G], 2 f32 entropy map + thr
     float thr;
-    long long *indices_out;   // outputs the dense pass 1 writes itself (null: the prepass wrote them)
+    long long *indices_out;   // outputs pass 1 writes itself (null: a prepass wrote them)
     float *cmask_out;
     long long *gate_out;
-    const int *wgd;           // row-complete de-duplicated form (non-null): per workgroup slot [B][HWout / 128] four ints
-                              // {first row of cells, rows of cells, unique tokens, 0}, written by the prepass; rows = 0:
-                              // slot unused.  Downstream (resolver, list kernel) sees the dense view (dense = 1).
 };
 
-// row-complete de-duplication packs whole rows of cells into one pass-1 workgroup: at most this many unique tokens
-// (its 4 waves x 32 token lanes) and this many output positions (the z_q staging buffer in LDS)
-#define DVQ_RD_MAX_TOKENS 128
-#define DVQ_RD_MAX_POS 512
+// The G gate values of one cell, fetched (fetch) and reduced to the grain index (reduce) separately so that a kernel
+// can put other memory operations between the two.  Reduce = argmax with torch semantics (first maximal value wins,
+// NaN counts as the maximum); mode 2: entropy > thr (NaN compares false -> 0).
+struct DvqGateRaw { float f[3]; long long i[3]; };
 
-// argmax over the G gate values of one cell with torch semantics (first maximal value wins, NaN counts as the
-// maximum); mode 2: entropy > thr (NaN compares false -> 0)
-__device__ __forceinline__ int dvq_gate_argmax(const void *gate, int mode, int G, size_t cell, float thr)
+__device__ __forceinline__ DvqGateRaw dvq_gate_fetch(const void *gate, int mode, int G, size_t cell)
 {
-    if (mode == 2) return (((const float *)gate)[cell] > thr) ? 1 : 0;
-    int bi = 0;
-    if (mode == 1) {
+    DvqGateRaw r;
+    r.f[0] = r.f[1] = r.f[2] = 0.0f;
+    r.i[0] = r.i[1] = r.i[2] = 0;
+    if (mode == 2) {
+        r.f[0] = ((const float *)gate)[cell];
+    } else if (mode == 1) {
         const long long *g = (const long long *)gate + cell * G;
-        long long best = g[0];
-        for (int i = 1; i < G; ++i) {
-            const long long v = g[i];
-            if (v > best) { best = v; bi = i; }
-        }
+        r.i[0] = g[0];
+        r.i[1] = g[1];
+        if (G == 3) r.i[2] = g[2];
     } else {
         const float *g = (const float *)gate + cell * G;
-        float best = g[0];
-        for (int i = 1; i < G; ++i) {
-            const float v = g[i];
-            if ((v > best) || (v != v && best == best)) { best = v; bi = i; }
+        r.f[0] = g[0];
+        r.f[1] = g[1];
+        if (G == 3) r.f[2] = g[2];
+    }
+    return r;
+}
+
+__device__ __forceinline__ int dvq_gate_reduce(const DvqGateRaw &r, int mode, int G, float thr)
+{
+    if (mode == 2) return (r.f[0] > thr) ? 1 : 0;
+    int bi = 0;
+    if (mode == 1) {
+        long long best = r.i[0];
+        if (r.i[1] > best) { best = r.i[1]; bi = 1; }
+        if (G == 3 && r.i[2] > best) { best = r.i[2]; bi = 2; }
+    } else {
+        float best = r.f[0];
+#pragma unroll
+        for (int i = 1; i < 3; ++i) {
+            const float v = r.f[i];
+            if (i < G && ((v > best) || (v != v && best == best))) { best = v; bi = i; }
         }
     }
     return bi;
 }
 
-// dense form: source of output position (y, x) of image b whose cell has grain g
+__device__ __forceinline__ int dvq_gate_argmax(const void *gate, int mode, int G, size_t cell, float thr)
+{
+    return dvq_gate_reduce(dvq_gate_fetch(gate, mode, G, cell), mode, G, thr);
+}
+
+// source of output position (y, x) of image b whose cell has grain g
 __device__ __forceinline__ const float *dvq_dense_source(const DvqRouted &rv, int b, int y, int x, int g, int &stride)
 {
     const int sub = rv.sub[g], rep = rv.rep[g];
@@ -164,91 +163,22 @@ __device__ __forceinline__ const float *dvq_dense_source(const DvqRouted &rv, in
 struct DvqTok {
     const float *src;   // channel 0 of the token
     int stride;         // elements between channels
-    long n;             // top-left output position (b*HWout + y0*Wout + x0); code / mask index
-    int rep;
+    long n;             // output position (b*HWout + y*Wout + x); code / mask index
     bool valid;
 };
 
-// image of token t, starting the walk at image b_hint (imgstart[b_hint] <= t must hold)
-__device__ __forceinline__ int dvq_routed_image(const DvqRouted &rv, int t, int b_hint)
-{
-    int b = b_hint;
-    while (b + 1 < rv.B && t >= rv.imgstart[b + 1]) ++b;
-    return b;
-}
-
-// last image whose first token is <= t (binary search; t < imgstart[B])
-__device__ __forceinline__ int dvq_routed_image_search(const DvqRouted &rv, int t)
-{
-    int lo = 0, hi = rv.B;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rv.imgstart[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// token t of the batch (any value; beyond the end -> invalid, clamped to token 0's addresses)
-__device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, int t, int b_hint)
+// token t = output position t of the batch (any value; out of range -> invalid, clamped to position 0's addresses)
+__device__ __forceinline__ DvqTok dvq_routed_lookup(const DvqRouted &rv, long t)
 {
     DvqTok k;
-    if (rv.dense) {                                              // rank = output position
-        const long total = (long)rv.B * rv.HWout;
-        k.valid = t >= 0 && t < total;
-        const int tt = k.valid ? t : 0;
-        const int b = tt / rv.HWout, pos = tt - b * rv.HWout;
-        const int y = pos / rv.Wout, x = pos - y * rv.Wout;
-        const int SC = rv.sub[rv.G - 1];
-        const int g = (int)rv.indices[(size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + x / SC];
-        k.src = dvq_dense_source(rv, b, y, x, g, k.stride);
-        k.n = tt;
-        k.rep = 1;
-        return k;
-    }
-    const int total = rv.imgstart[rv.B];
+    const long total = (long)rv.B * rv.HWout;
     k.valid = t >= 0 && t < total;
-    const int tt = k.valid ? t : 0;
-    const int b = dvq_routed_image(rv, tt, k.valid ? b_hint : 0);
-    const unsigned e = (total > 0) ? rv.tok[(size_t)b * rv.HWout + (tt - rv.imgstart[b])] : 0u;
-    const int g = (int)(e >> 14), sy = (int)((e >> 12) & 3u), sx = (int)((e >> 10) & 3u), cell = (int)(e & 1023u);
-    const int cy = cell / rv.wc, cx = cell - cy * rv.wc;
-    const int sub = rv.sub[g], rep = rv.rep[g];
-    const int gy = cy * sub + sy, gx = cx * sub + sx;             // position in the type's own grid
-    const int gwid = rv.wc * sub, plane = rv.hc * sub * gwid;
-    k.src = rv.src[g] + (size_t)b * rv.D * plane + (size_t)gy * gwid + gx;
-    k.stride = plane;
-    k.n = (long)b * rv.HWout + (long)(gy * rep) * rv.Wout + gx * rep;
-    k.rep = rep;
+    const int tt = k.valid ? (int)t : 0;
+    const int b = tt / rv.HWout, pos = tt - b * rv.HWout;
+    const int y = pos / rv.Wout, x = pos - y * rv.Wout;
+    const int SC = rv.sub[rv.G - 1];
+    const int g = (int)rv.indices[(size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + x / SC];
+    k.src = dvq_dense_source(rv, b, y, x, g, k.stride);
+    k.n = tt;
     return k;
 }
-
-// number of tokens of the batch
-__device__ __forceinline__ int dvq_routed_total(const DvqRouted &rv)
-{
-    return rv.dense ? rv.B * rv.HWout : rv.imgstart[rv.B];
-}
-
-// arguments of the low-register pass-1 kernel (vq_assign_routed.hip: vq_pass1_kernel)
-struct P1Args {
-    const float *z;            // dense source [B, D, HW] (ROUTED = false)
-    int HW;
-    long N;
-    DvqRouted rv;              // routed source (ROUTED = true)
-    const char *img;
-    const DvqF16Meta *meta;
-    const float *E;
-    const float *mask;         // [B, HWout] or null
-    int K;
-    float *zq;                 // [B, D, HWout] or null
-    long long *codes;          // [B, HWout]
-    double *partials;          // one per workgroup of the launch, or null
-    int *counters;
-    int *exact_list;
-    char *records;
-    int rec_cap;               // per shard
-    int stagger_ticks;         // > 0: the odd "layers" of the first generation of workgroups start this many
-                               // 100-MHz ticks late, so co-resident workgroups alternate HBM and matrix phases
-    int stagger_blocks;        // workgroups per layer (= CUs) and first-generation size
-    int stagger_first;
-    int debug;                 // timing experiments only (DVQ_P1_DEBUG): 1 no second-row store of coarse tokens, 2 no coarse stores, 4 no fine stores
-};

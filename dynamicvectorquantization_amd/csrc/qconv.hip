@@ -119,22 +119,23 @@ __global__ __launch_bounds__(256, 2) void qconv_kernel(
         for (int i = wave; i < PIECES; i += 4) glds16(src + i * 1024 + lane * 16, buf + i * 1024);
         if (wave == 0) glds4(src + 2 * IMG + lane * 4, buf + 2 * IMG);
     };
-    stage(0, lds);
-
     const float *zp;
     size_t st;
     if (SEL) {
         const int y = pos / rv.Wout, xx = pos - y * rv.Wout;
         const int SC = rv.sub[rv.G - 1];
         const size_t cell = (size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + xx / SC;
-        const int g = dvq_gate_argmax(rv.gate, rv.gate_mode, rv.G, cell, rv.thr);
+        // (the gate is read before the first LDS-DMA is in flight: an ordinary load whose value is used while one is
+        // makes hipcc drain the whole vector-memory queue)
+        const DvqGateRaw graw = dvq_gate_fetch(rv.gate, rv.gate_mode, rv.G, cell);
+        const int g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
         const int rep_g = rv.rep[g];
         if (n >= 0 && h == 0 && rv.cmask_out != nullptr) {
             rv.cmask_out[n] = 1.0f / (float)(rep_g * rep_g);
             if (y % SC == 0 && xx % SC == 0) {
                 rv.indices_out[cell] = g;
                 if (rv.gate_mode == 2 && rv.gate_out != nullptr) {
-                    const float e = ((const float *)rv.gate)[cell];
+                    const float e = graw.f[0];
                     longlong2 gg; gg.x = (e <= rv.thr) ? 1 : 0; gg.y = (e > rv.thr) ? 1 : 0;
                     *(longlong2 *)(rv.gate_out + 2 * cell) = gg;
                 }
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void qconv_kernel(
         zp = x + ((size_t)b * D + 8 * h) * HW + pos;
         st = (size_t)HW;
     }
+    stage(0, lds);
     float xf[S16][8];
 #pragma unroll
     for (int s = 0; s < S16; ++s)

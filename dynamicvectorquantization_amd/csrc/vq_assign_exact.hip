@@ -22,8 +22,8 @@
 #include "dvq_filter.h"
 #include <type_traits>
 
-// ROUTED: the tokens are the unique tokens of a routed batch (dvq_filter.h: DvqRouted), addressed in the
-// encoder branches by their rank in the batch's token order; a token covers rep x rep output positions.
+// ROUTED: token = output position of a routed batch (dvq_filter.h: DvqRouted), read from the encoder branch that
+// won its cell.
 template <int D, bool LIST, bool ROUTED>
 __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
@@ -66,15 +66,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const float *zp;                                   // channel h of the token; channel k = 2s + h at zp + 2s*stride
     int stride, rep = 1, Wout = 0, HWo = HW;
     if (ROUTED) {
-        const int total = dvq_routed_total(rv);
-        const int tid_ = (nn >= 0 && nn < total) ? (int)nn : 0;
-        const DvqTok tk = dvq_routed_lookup(rv, (nn >= 0 && nn < total) ? (int)nn : -1,
-                                            (total > 0 && !rv.dense) ? dvq_routed_image_search(rv, tid_) : 0);   // token id -> branch tensor address
+        const DvqTok tk = dvq_routed_lookup(rv, nn);          // output position -> address in the branch that won its cell
         valid = valid && tk.valid;
         stride = tk.stride;
         zp = tk.src + (size_t)h * stride;
         n = nn = tk.n;
-        rep = tk.rep;
         Wout = rv.Wout;
         HWo = rv.HWout;
     } else {

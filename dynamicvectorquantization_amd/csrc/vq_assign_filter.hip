@@ -30,38 +30,21 @@
 // W is the sum with ||e_j||, en_j, ||eta_j|| replaced by their maxima over the codebook.
 #include "dvq_filter.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 // z is read once and z_q written once per launch: stream them past L2 (nt) so that the codebook
 // image and the fp32 codebook rows keep their lines
-#ifndef DVQ_NT
-#define DVQ_NT 1
-#endif
-#if DVQ_NT
 #define DVQ_LOAD_Z(p) __builtin_nontemporal_load(p)
 #define DVQ_STORE_ZQ(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define DVQ_LOAD_Z(p) (*(p))
-#define DVQ_STORE_ZQ(p, v) (*(p) = (v))
-#endif
-
-// the select-fused prologue reads lines of h_fine / h_coarse that neighbouring waves (the other rows of a coarse cell)
-// read again: keep them in L2 (plain loads) unless DVQ_SEL_NT says otherwise
-#ifndef DVQ_SEL_NT
-#define DVQ_SEL_NT 0
-#endif
-#if DVQ_SEL_NT
-#define DVQ_LOAD_SEL(p) __builtin_nontemporal_load(p)
-#else
+// the per-lane select prologue (SEL = 1) reads lines of the coarser branches that neighbouring waves read again:
+// plain loads keep them in L2
 #define DVQ_LOAD_SEL(p) (*(p))
-#endif
-#ifndef DVQ_MFMA16_DEFAULT
-#define DVQ_MFMA16_DEFAULT 1     // code loop of the legacy pass 1 on v_mfma_f32_16x16x32_f16 (same bits out; +1 % at K = 1024, +7 % at 16384)
-#endif
-static bool dvq_mfma16_enabled();
-static size_t dvq_img16_offset_of(int K, int D);
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
+#endif
+#ifndef DVQ_LOCK_MAX_SPINS
+#define DVQ_LOCK_MAX_SPINS 4000  // anti-phase lock: give up waiting after about 3 ms
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -217,23 +200,53 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // pass 1: 4-wave workgroups of 128 consecutive tokens, TWO per CU (<= 256 VGPRs).  A wave keeps its
 // 32 tokens twice in registers -- fp32 (D/2 VGPRs, read once, reused for z_q and the resolver
 // record: z is never re-read, HBM traffic = the algorithmic bytes) and fp16 MFMA fragments (D/4).
-// Only two waves share a SIMD, so the code loop is written for per-wave matrix-core duty: seeds
-// read before the barrier, A fragments rotated through four register sets one k-step group ahead.
+// The code loop runs on v_mfma_f32_16x16x32_f16 (tile image "16" of the prep buffer): the latents are
+// converted in the load layout (lane = token, 8 consecutive channels) and permuted into the B-operand
+// order through a 2-KiB per-wave LDS scratch; every A fragment (16 codes x 32 k) feeds two MFMAs.
+//
+// SEL: 0 = dense z.
+//      1 = the router select fused in (DvqRouted, dense view): token n is output position n, its source
+//          vector sits in the encoder branch that won its cell (per-lane source pointer and channel stride).
+//      2 = the same for a 32-wide output grid (every reference config): the workgroup's four output rows
+//          need exactly ONE 128-B line per channel of the 2x-coarser branch (dual: coarse; triple: median)
+//          and one 32-B piece of the 4x-coarser one (triple: coarse).  Those are DMA'd ONCE per workgroup
+//          into ring slots the code loop does not need yet and read back with ds_read_b32; the fine branch
+//          is read by every lane with the dense kernel's load pattern.  With the per-lane form (SEL = 1) the
+//          two / four waves that share a coarse line each fetched it (PMC: 2.1x the coarse bytes).
+// Anti-phase (cu_lock != null): the two workgroups a CU holds take turns in the code loop (a lock word per
+// CU, keyed by XCC_ID / HW_ID), so that one workgroup's HBM phases (epilogue, and the prologue of the
+// workgroup dispatched into the freed slot) run beside the other's matrix phase in EVERY generation
+// instead of all resident workgroups moving through the three phases in lockstep.
 // ---------------------------------------------------------------------------------------------
-// SEL: the router select fused in (DvqRouted with dense = 1): token n is output position n, its source vector
-// sits in the encoder branch that won its cell (per-lane source pointer and channel stride); outputs as dense.
-// M16: the code loop on v_mfma_f32_16x16x32_f16 (image "16"): same flops per cycle, but the part holds a higher clock
-// under this shape when power-limited; the latents' fragments are permuted into its operand order once per wave.
-template <int D, int SEL, bool M16>
+#ifdef DVQ_TUNING
+// diagnostics of the tuning build only: per-workgroup clock stamps around the code loop (s_memtime / s_memrealtime,
+// MI355X guide "DVFS give-back" item 6) and per-token (best, second, 2W, code) of the production arithmetic for the
+// bound audit.  Written to buffers of their own; no output value is computed from them.
+__device__ unsigned long long *g_dvq_stamps = nullptr;     // [grid][8]: CU slot, realtime at entry / before the lock / loop start, cycles at loop
+                                                           // start, realtime / cycles at loop end, realtime at exit (100 MHz / shader clock)
+__device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
+#endif
+
+__device__ __forceinline__ int dvq_cu_slot()
+{
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // HW_ID[15:8] = {se_id, sh_id, cu_id}; XCC_ID[3:0]
+    return (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu));
+}
+
+template <int D, int SEL>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, int *__restrict__ cu_lock)
 {
     constexpr int NW = 4;
     constexpr int S16 = D / 16;
+    constexpr int S32 = S16 / 2;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
     constexpr int CPW = (S16 + NW - 1) / NW;
@@ -247,6 +260,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const int c = lane & 31, h = lane >> 5;
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
+    char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;   // this wave's permutation scratch
+#ifdef DVQ_TUNING
+    unsigned long long st_entry = 0, st_pro = 0, st_r0 = 0, st_c0 = 0;
+    if (g_dvq_stamps != nullptr && tid == 0) st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // DMA of code tile t into its ring slot, in PER_TILE pieces (q < CPW: 1 KiB of the image, q == CPW:
     // this wave's copy of the seeds).  Past the end: harmless repeat, so the counts stay constant.
@@ -266,27 +284,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
     const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
-    // SEL == 2, row-complete de-duplication: this workgroup owns dd_ng whole rows of cells of ONE image (slot
-    // tile_id of the prepass's table), dd_U unique tokens in its first ceil(dd_U / 32) waves
-    int dd_g0 = 0, dd_ng = 0, dd_U = 0;
-    if (SEL == 2) {
-        const int *dsc = rv.wgd + 4 * (size_t)tile_id;
-        dd_g0 = __builtin_amdgcn_readfirstlane(dsc[0]);
-        dd_ng = __builtin_amdgcn_readfirstlane(dsc[1]);
-        dd_U = __builtin_amdgcn_readfirstlane(dsc[2]);
-        if (dd_ng == 0) {                                    // unused slot (before any DMA or barrier)
-            if (partials != nullptr && tid == 0) partials[blockIdx.x] = 0.0;
-            return;
-        }
-    }
-    const bool wave_active = (SEL != 2) || (wave * 32 < dd_U);      // wave-uniform
-    issue(0);
-    issue(1);
-    issue(2);
+    // SEL == 2 parks the coarser branches in the ring slots from `pre` on: 2 slots = D x 128 B for the 2x-coarser
+    // branch (dual: slots 2, 3; triple: slots 1, 2), slot 3 for the triple's 4x-coarser branch (D x 32 B)
+    const int pre = (SEL == 2) ? ((rv.G == 2) ? 2 : 1) : 3;  // code tiles in flight before the prologue
 
     const int n_raw = (tile_id * NW + wave) * 32 + c;
-    int n = (n_raw < N) ? n_raw : -1;
-    int dd_lp = 0, dd_rep = 1;                               // SEL == 2: top-left position inside the workgroup's rows; copies per edge
+    const int n = (n_raw < N) ? n_raw : -1;
     auto token_base = [&]() -> size_t {
         const long nn = (n >= 0) ? n : N - 1;
         const long bimg = nn / HW;
@@ -295,89 +298,91 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     };
     float zf[S16][8];
     float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell
-    if (SEL == 2) {
-        // unique tokens of the workgroup's rows of cells in row-major order of their top-left output positions (a wave's
-        // lanes then read mostly one row of one source: two or three 128-B lines per load instruction), through a token
-        // table in LDS (ring slot 3: its first DMA is issued after the loop's first barrier).  Thread t < rows * wc
-        // owns (output row t / wc, cell t % wc) and lists the tokens of that cell whose top-left corner is in that row.
-        const int wc = rv.wc, SC = rv.sub[rv.G - 1];
-        const int b = tile_id / (HW / 128);
-        const int nrc = dd_ng * SC * wc;                     // <= 256 (DVQ_RD_MAX_POS / 2)
-        int *tokl = (int *)(lds + 3 * IMG_BYTES);
-        int g = 0, cnt = 0;
-        const int yl_t = tid / wc, cx_t = tid - yl_t * wc;
-        if (tid < nrc) {
-            g = (int)rv.indices[((size_t)b * rv.hc + dd_g0 + yl_t / SC) * wc + cx_t];
-            cnt = ((yl_t % SC) % rv.rep[g] == 0) ? rv.sub[g] : 0;
-        }
-        int inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
-        }
-        if (lane == 63) tokl[DVQ_RD_MAX_TOKENS + wave] = inc;
-        __syncthreads();
-        {
-            int start = inc - cnt;
-            for (int w2 = 0; w2 < wave; ++w2) start += tokl[DVQ_RD_MAX_TOKENS + w2];
-            for (int q = 0; q < cnt; ++q) tokl[start + q] = (yl_t << 12) | (cx_t << 6) | (q << 2) | g;
-        }
-        __syncthreads();
-        const int u_raw = wave * 32 + c;
-        const bool has = u_raw < dd_U;
-        const int e = tokl[has ? u_raw : dd_U - 1];
-        const int yl = e >> 12, cx = (e >> 6) & 63, kx = (e >> 2) & 15, tg = e & 3;
-        const int rep = rv.rep[tg];
-        const int x = cx * SC + kx * rep, y = dd_g0 * SC + yl;
-        dd_lp = yl * rv.Wout + x;
-        dd_rep = rep;
-        n = has ? (b * HW + y * rv.Wout + x) : -1;
-        sel_mask = 1.0f / (float)(rep * rep);
-        // (a wave without tokens reads one cached line 128 times instead of branching around the loads: the straight-line
-        // prologue is what keeps this kernel free of spills)
-        int stride_l;
-        const float *zp = dvq_dense_source(rv, b, y, x, tg, stride_l) + (size_t)8 * h * stride_l;
-        if (!wave_active) { zp = E; stride_l = 0; }
-        const size_t st = (size_t)stride_l;
-        __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-        for (int s = 0; s < S16; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
-        __builtin_amdgcn_s_setprio(0);
-    } else if (SEL == 1) {
+    int sel_g = 0;                                           // SEL == 2: grain of this lane's cell
+    unsigned stg_a = 0, stg_b = 0;                           // SEL == 2: LDS byte address of this lane's value of channel 8h in the
+                                                             // image of the 2x-coarser / 4x-coarser branch
+    if (SEL != 0) {
         // the router select, fused in: grain of this position's cell straight from the gate, source = the branch
-        // that won the cell; indices / codebook_mask / the int64 gate are written here as by-products
+        // that won the cell; indices / codebook_mask / the int64 gate are written here as by-products.
+        // Ordinary loads whose values are used while an LDS-DMA is in flight make hipcc drain the whole vector-memory
+        // queue (s_waitcnt vmcnt(0)), so: the gate is fetched BEFORE the first DMA is issued, and (SEL == 2) reduced only
+        // after this wave's loads are on their way.
         const int nn = (n >= 0) ? n : (int)(N - 1);
         const int b = nn / HW, pos = nn - b * HW;
         const int y = pos / rv.Wout, x = pos - y * rv.Wout;
         const int SC = rv.sub[rv.G - 1];
         const size_t cell = (size_t)b * rv.hc * rv.wc + (y / SC) * rv.wc + x / SC;
-        const int g = dvq_gate_argmax(rv.gate, rv.gate_mode, rv.G, cell, rv.thr);
-        const int rep_g = rv.rep[g];
-        sel_mask = 1.0f / (float)(rep_g * rep_g);            // 1, 0.25, 0.0625: exact
-        if (n >= 0 && h == 0 && rv.cmask_out != nullptr) {
-            rv.cmask_out[n] = sel_mask;
-            if (y % SC == 0 && x % SC == 0) {
-                rv.indices_out[cell] = g;
-                if (rv.gate_mode == 2 && rv.gate_out != nullptr) {
-                    const float e = ((const float *)rv.gate)[cell];
-                    longlong2 gg; gg.x = (e <= rv.thr) ? 1 : 0; gg.y = (e > rv.thr) ? 1 : 0;
-                    *(longlong2 *)(rv.gate_out + 2 * cell) = gg;
+        const DvqGateRaw graw = dvq_gate_fetch(rv.gate, rv.gate_mode, rv.G, cell);
+        auto by_products = [&](int g) {
+            const int rep_g = rv.rep[g];
+            sel_mask = 1.0f / (float)(rep_g * rep_g);        // 1, 0.25, 0.0625: exact
+            if (n >= 0 && h == 0 && rv.cmask_out != nullptr) {
+                rv.cmask_out[n] = sel_mask;
+                if (y % SC == 0 && x % SC == 0) {
+                    rv.indices_out[cell] = g;
+                    if (rv.gate_mode == 2 && rv.gate_out != nullptr) {
+                        const float e = graw.f[0];
+                        longlong2 gg; gg.x = (e <= rv.thr) ? 1 : 0; gg.y = (e > rv.thr) ? 1 : 0;
+                        *(longlong2 *)(rv.gate_out + 2 * cell) = gg;
+                    }
                 }
             }
+        };
+        if (SEL == 1) {
+            const int g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
+            by_products(g);
+            for (int t = 0; t < pre; ++t) issue(t);
+            int stride_l;
+            const float *zp = dvq_dense_source(rv, b, y, x, g, stride_l) + (size_t)8 * h * stride_l;
+            const size_t st = (size_t)stride_l;
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int s = 0; s < S16; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            for (int t = 0; t < pre; ++t) issue(t);
+            // workgroup = output rows y0 .. y0 + 3 of image b (wave = row, lane = column); both are wave-uniform
+            const int bw = __builtin_amdgcn_readfirstlane(b);
+            const int y0 = __builtin_amdgcn_readfirstlane(y) - wave;
+            char *img_a = lds + pre * IMG_BYTES;             // 2x-coarser branch [D][32 floats]
+            char *img_b = lds + 3 * IMG_BYTES;               // 4x-coarser branch [D][8 floats] (triple only)
+            {
+                // branch G-2 (rep 2): rows y0/2, y0/2 + 1 of a 16-wide grid = 32 consecutive floats per channel;
+                // a wave-instruction moves 8 channels x 8 pieces of 16 B
+                const int ga = rv.G - 2;
+                const int plane = rv.hc * rv.sub[ga] * 16;
+                const float *src = rv.src[ga] + (size_t)bw * D * plane + (size_t)(y0 >> 1) * 16 + (lane & 7) * 4;
+                for (int i = wave; i < D / 8; i += NW)
+                    glds16(src + (size_t)(i * 8 + (lane >> 3)) * plane, img_a + i * 1024);
+            }
+            if (rv.G == 3) {
+                // branch 0 (rep 4): row y0/4 of an 8-wide grid = 8 floats per channel; 32 channels x 2 pieces per instruction
+                const int plane = rv.hc * 8;
+                const float *src = rv.src[0] + (size_t)bw * D * plane + (size_t)(y0 >> 2) * 8 + (lane & 1) * 4;
+                for (int i = wave; i < D / 32; i += NW)
+                    glds16(src + (size_t)(i * 32 + (lane >> 1)) * plane, img_b + i * 1024);
+            }
+            stg_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)img_a +
+                    (unsigned)((8 * h) * 128 + (((wave >> 1) * 16 + (c >> 1)) << 2));
+            stg_b = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)img_b +
+                    (unsigned)((8 * h) * 32 + ((c >> 2) << 2));
+            const float *zp = rv.src[rv.G - 1] + ((size_t)b * D + 8 * h) * HW + pos;
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int s = 0; s < S16; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the branch images (and its loads) landed;
+            __builtin_amdgcn_s_barrier();                      // the barrier makes that true for the other waves' pieces
+            asm volatile("" ::: "memory");
+            sel_g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
+            by_products(sel_g);
         }
-        int stride_l;
-        const float *zp = dvq_dense_source(rv, b, y, x, g, stride_l) + (size_t)8 * h * stride_l;
-        const size_t st = (size_t)stride_l;
-        __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-        for (int s = 0; s < S16; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
-        __builtin_amdgcn_s_setprio(0);
     } else {
+        for (int t = 0; t < pre; ++t) issue(t);
         const float *zp = z + token_base();
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -386,14 +391,32 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
         __builtin_amdgcn_s_setprio(0);
     }
-    f16x8 zh[S16];
-    f16x8 zb[2][M16 ? S16 / 2 : 1];                          // M16: B operands of the 16x16x32 loop, [token half][k-step of 32]
+    f16x8 zb[2][S32];                                        // B operands of the 16x16x32 loop, [token half][k-step of 32]
     float xn, thr2W;
     {
         float pa[2][8];
         float amax = 0.0f, zeta2 = 0.0f;
+        f16x8 zprev = {};
 #pragma unroll
         for (int s = 0; s < S16; ++s) {
+            if (SEL == 2) {
+                // lanes whose cell went to a coarser branch: its value of channel 16 s + 8 h + j replaces the fine one
+                // (the LDS reads execute under the lanes' exec mask and land in the same registers: no select needed)
+                if (sel_g == rv.G - 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        asm volatile("ds_read_b32 %0, %1 offset:%c2" : "+v"(zf[s][j]) : "v"(stg_a), "i"((16 * s + j) * 128));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                if (rv.G == 3 && sel_g == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        asm volatile("ds_read_b32 %0, %1 offset:%c2" : "+v"(zf[s][j]) : "v"(stg_b), "i"((16 * s + j) * 32));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(zf[s][j]));
+            }
             u32x4 packed;
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
@@ -410,21 +433,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 zeta2 = __builtin_fmaf(r0, r0, zeta2);
                 zeta2 = __builtin_fmaf(r1, r1, zeta2);
             }
-            zh[s] = __builtin_bit_cast(f16x8, packed);
-            if (M16 && (s & 1)) {
+            const f16x8 zcur = __builtin_bit_cast(f16x8, packed);
+            if (s & 1) {
                 // tokens 16 t2 + (lane & 15), k = 32 s' + 8 (lane >> 4) + j  <-  lane (c, h) = (16 t2 + (lane & 15), (lane >> 4) & 1),
-                // k-step 2 s' + (lane >> 5) of the 32x32x16 layout: through a 2-KiB per-wave LDS scratch (a wave's LDS
+                // k-step 2 s' + (lane >> 5) of the load layout: through the per-wave LDS scratch (a wave's LDS
                 // operations execute in order, so no barrier; 128 ds_bpermutes instead spilled 54 VGPRs)
                 const int sp = s >> 1;
-                char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;
-                *(f16x8 *)(scr + lane * 16) = zh[s - 1];
-                *(f16x8 *)(scr + 1024 + lane * 16) = zh[s];
+                *(f16x8 *)(scr + lane * 16) = zprev;
+                *(f16x8 *)(scr + 1024 + lane * 16) = zcur;
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const int srcl = 16 * t2 + (lane & 15) + 32 * ((lane >> 4) & 1);
                     zb[t2][sp] = *(const f16x8 *)(scr + (lane >> 5) * 1024 + srcl * 16);
                 }
             }
+            zprev = zcur;
         }
         float t8[8];
 #pragma unroll
@@ -443,114 +466,43 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         zeta2 += __shfl_xor(zeta2, 32);
         thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     }
-    // SEL == 2: the two per-lane values only the epilogue needs sit out the code loop in LDS (the loop has no VGPR to spare)
-    int *dd_stash = (int *)(lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048) + lane;   // this wave's own scratch
     if (SEL == 2) {
-        *dd_stash = dd_lp * 8 + dd_rep;
+        __builtin_amdgcn_s_barrier();                        // every wave has read the branch images: the slots join the ring
         asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0..2 (own DMA) landed during the prologue
+    for (int t = pre; t < 3; ++t) issue(t);                  // (SEL == 2) the code tiles that waited for those slots
+    // anti-phase: this CU's other workgroup may be in its code loop; wait for it (bounded: a lost lock costs
+    // overlap, never progress).  Lane 0 of wave 0 spins; the other waves wait at the loop's first barrier.
+#ifdef DVQ_TUNING
+    if (g_dvq_stamps != nullptr && tid == 0) st_pro = __builtin_amdgcn_s_memrealtime();
+#endif
+    int lock_slot = 0;
+    if (cu_lock != nullptr) {
+        lock_slot = dvq_cu_slot();
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_exchange(&cu_lock[lock_slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                   spins < DVQ_LOCK_MAX_SPINS) {
+                __builtin_amdgcn_s_sleep(24);
+                ++spins;
+            }
+        }
+    }
+#ifdef DVQ_TUNING
+    if (g_dvq_stamps != nullptr && tid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
-    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
-    int t1 = 0;
+    // ---- 16x16x32 code loop: fragment F = c2 * S32 + s' of the tile feeds two MFMAs (token halves t2 = 0, 1);
+    // accumulator acc16[c2][t2][i] = code 16 c2 + 4 (lane >> 4) + i against token 16 t2 + (lane & 15)
     float best, second;
     int code;
-    if constexpr (!M16) {
-        for (int t = 0; t < T; ++t) {
-            if (SEL == 2 && !wave_active) {                  // no tokens in this wave: keep its share of the ring DMA going
-                if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue(t + 3);
-                continue;
-            }
-            // accumulator seeds of tile t: this wave's own DMA copy, landed one step ago -> no barrier needed
-            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
-            f32x16 acc;
-    #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-    #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[4 * g + q] = e4[q];
-            }
-            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
-            asm volatile("" ::: "memory");
-            if (S16 != 16) issue(t + 3);                         // D = 256: pieces ride between the MFMAs below
-            // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
-            // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
-            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
-                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
-            f16x8 a0, a1, a2, a3;
-            // make the compiler wait for the seed reads HERE (an opaque use of acc); otherwise its own
-            // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
-            asm volatile("" : "+v"(acc));
-            __builtin_amdgcn_sched_barrier(0);
-    #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-    #define DVQ_MM(src, S, WAIT, NEXT)                                                      \
-            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[S], acc, 0, 0, 0);         \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-            if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
-            NEXT
-            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
-            __builtin_amdgcn_s_setprio(1);
-            if (S16 == 16) {
-                // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
-                // then overlaps the MFMA already in the pipe instead of preceding the whole chain
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-                DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
-                DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
-                DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
-            } else if (S16 == 8) {
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-                DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
-            } else {
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
-            }
-    #undef DVQ_MM
-    #undef DVQ_RD
-            __builtin_amdgcn_s_setprio(0);
-            const float om = m1;
-    #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                // running top-2 over the pair (g0, g1): with m2 <= m1 the new second-best is
-                // max(m2, med3(m1, g0, g1)) and the new best max3(m1, g0, g1): 2.5 VALU ops per score
-                float g0 = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
-                float g1 = __uint_as_float((__float_as_uint(acc[r + 1]) & 0xFFFFFFF0u) | (unsigned)(r + 1));
-                float md = __builtin_amdgcn_fmed3f(m1, g0, g1);
-                m1 = vmax3_raw(m1, g0, g1);
-                m2 = vmax_raw(m2, md);
-            }
-            t1 = (m1 != om) ? t : t1;
-        }
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-        const int ot = __shfl_xor(t1, 32);
-        const bool other_wins = (o1 > m1) || (o1 == m1 && h == 1);
-        best = other_wins ? o1 : m1;
-        second = fmaxf(other_wins ? m1 : o1, fmaxf(m2, o2));
-        const int wt = other_wins ? ot : t1;
-        const int wh = other_wins ? (h ^ 1) : h;
-        const int r = (int)(__float_as_uint(best) & 15u);
-        code = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-    } else {
-        // ---- 16x16x32 code loop: fragment F = c2 * S32 + s' of the tile feeds two MFMAs (token halves t2 = 0, 1);
-        // accumulator acc16[c2][t2][i] = code 16 c2 + 4 (lane >> 4) + i against token 16 t2 + (lane & 15)
-        constexpr int S32 = S16 / 2;
+    {
         const int q16 = lane >> 4;
         float b1[2] = {-__builtin_inff(), -__builtin_inff()}, b2[2] = {-__builtin_inff(), -__builtin_inff()};
         int bt[2] = {0, 0};
         for (int t = 0; t < T; ++t) {
-            if (SEL == 2 && !wave_active) {                  // no tokens in this wave: keep its share of the ring DMA going
-                if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue(t + 3);
-                continue;
-            }
+            // accumulator seeds of tile t: this wave's own DMA copy, landed by the previous step's wait (tile 0: before
+            // the prologue's loads) -> no barrier needed
             const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16;
             f32x4 acc16[2][2];
 #pragma unroll
@@ -559,13 +511,17 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 acc16[c2][0] = e4;
                 acc16[c2][1] = e4;
             }
-            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // all but the youngest tile's DMA: tiles <= t + 1 landed
             __builtin_amdgcn_s_barrier();                    // tile t (everybody's DMA) landed; t-1 consumed
             asm volatile("" ::: "memory");
-            if (S16 != 16) issue(t + 3);
+            if (S16 != 16) issue(t + 3);                     // D = 256: pieces ride between the MFMAs below
+            // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
+            // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
             const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
                                         lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
             f16x8 a0, a1, a2, a3;
+            // make the compiler wait for the seed reads HERE (an opaque use of the accumulators); otherwise its own
+            // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
             asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][1]), "+v"(acc16[1][0]), "+v"(acc16[1][1]));
             __builtin_amdgcn_sched_barrier(0);
 #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
@@ -580,6 +536,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
             __builtin_amdgcn_s_setprio(1);
             if (S16 == 16) {
+                // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
+                // then overlaps the MFMA already in the pipe instead of preceding the whole chain
                 DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
                 DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
                 DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
@@ -597,7 +555,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             for (int t2 = 0; t2 < 2; ++t2) {
                 const float om = b1[t2];
 #pragma unroll
-                for (int r = 0; r < 8; r += 2) {         // r = 4 c2 + i
+                for (int r = 0; r < 8; r += 2) {             // r = 4 c2 + i
+                    // running top-2 over the pair (g0, g1): with b2 <= b1 the new second-best is max(b2, med3(b1, g0, g1))
+                    // and the new best max3(b1, g0, g1): 2.5 VALU ops per score; the register index rides in 4 mantissa bits
                     const float v0 = acc16[r >> 2][t2][r & 3], v1 = acc16[(r + 1) >> 2][t2][(r + 1) & 3];
                     float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
                     float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
@@ -608,7 +568,18 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 bt[t2] = (b1[t2] != om) ? t : bt[t2];
             }
         }
+#ifdef DVQ_TUNING
+        if (g_dvq_stamps != nullptr && tid == 0) {
+            unsigned long long *sp = g_dvq_stamps + 8 * (size_t)blockIdx.x;
+            sp[0] = (unsigned long long)dvq_cu_slot(); sp[1] = st_entry; sp[2] = st_pro; sp[3] = st_r0; sp[4] = st_c0;
+            sp[5] = __builtin_amdgcn_s_memrealtime(); sp[6] = __builtin_amdgcn_s_memtime();
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+        if (cu_lock != nullptr) {
+            __builtin_amdgcn_s_barrier();                    // every wave is out of the loop: hand the matrix cores over
+            if (tid == 0) __hip_atomic_store(&cu_lock[lock_slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // merge the four lane groups of a token column (lower lane wins ties), then hand the results to the lanes
         // that own the token in the (c, h) layout of the prologue / epilogue
         float rb[2], rs[2];
@@ -640,16 +611,16 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         second = (c >> 4) ? y1 : y0;
         code = (c >> 4) ? c1 : c0;
     }
-    if (SEL == 2) {
-        asm volatile("" ::: "memory");
-        const int v = *dd_stash;
-        dd_lp = v >> 3;
-        dd_rep = v & 7;
-    }
     const float thr = best - thr2W;
     const bool final_ok = (best - second) > thr2W;
     const bool valid = n >= 0;
     bool hopeless = !(code < K) || !(thr == thr);
+#ifdef DVQ_TUNING
+    if (g_dvq_tokdbg != nullptr && valid && h == 0) {
+        f32x4 dbg = {best, second, thr2W, (float)code};
+        *(f32x4 *)(g_dvq_tokdbg + 4 * (size_t)n) = dbg;
+    }
+#endif
     // undecided tokens are queued for the resolver.  The slot comes from an atomic whose result is not
     // needed until the record is written, so: bump the shard counter now (one atomic per wave, lane 0,
     // by the number of undecided tokens), run the z_q / loss phase while it is in flight, and only then
@@ -660,115 +631,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     int slot_raw = 0;
     if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
     if (valid && hopeless && h == 0) {
-        if (SEL == 2) {                                      // the list kernel sees the dense view: every covered position
-            for (int ry = 0; ry < dd_rep; ++ry)
-                for (int rx = 0; rx < dd_rep; ++rx) {
-                    int pos = atomicAdd(&counters[1], 1);
-                    exact_list[pos] = n + ry * rv.Wout + rx;
-                }
-        } else {
-            int pos = atomicAdd(&counters[1], 1);
-            exact_list[pos] = n;
-        }
+        int pos = atomicAdd(&counters[1], 1);
+        exact_list[pos] = n;
     }
     float lsum = 0.0f;
-    if (SEL == 2) {
-        // row-complete writers: every value goes through LDS so that z_q and the codes leave the workgroup as whole,
-        // contiguous rows (a channel's positions of this workgroup are P consecutive floats in HBM), however the
-        // unique tokens were spread over lanes and however many positions each one covers.
-        const int Wo = rv.Wout, SC = rv.sub[rv.G - 1];
-        const int P = dd_ng * SC * Wo, P4 = P >> 2;          // P <= DVQ_RD_MAX_POS, multiple of 4
-        const int b = tile_id / (HW / 128);
-        const size_t p0 = (size_t)dd_g0 * SC * Wo;           // first position of the workgroup inside the image
-        const bool wr = valid && !hopeless;
-        const float m = sel_mask * (float)(dd_rep * dd_rep); // mask x copies = 1 (the resolver takes back mask[n] * rep^2)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                     // every wave is out of the code loop: ring and seeds are free
-        int *cl_ = (int *)(lds + NBUF * IMG_BYTES);          // codes per local position (seed area: 4 KiB)
-        if (valid && h == 0) {
-            const int cw = hopeless ? 0 : code;              // (hopeless tokens: the list kernel rewrites their positions)
-            for (int ry = 0; ry < dd_rep; ++ry)
-                for (int rx = 0; rx < dd_rep; ++rx) cl_[dd_lp + ry * Wo + rx] = cw;
-        }
-        if (zq != nullptr) {
-            const float *ep = E + (size_t)(wr ? code : 0) * D + 8 * h;
-            // staging buffer [2][16 channels][P] floats at the start of LDS.  Addresses are carried as running values made
-            // opaque once per step: left to itself the compiler precomputes all 16 steps' pointers and spills
-            unsigned sw = (unsigned)((8 * h) * P + dd_lp);                  // float index of this lane's first staged value, buffer 0
-            unsigned sr = (unsigned)(wave * P + 4 * lane);                  // copy-out: channel `wave`, float4 `lane`
-            size_t go = (size_t)b * D * HW + p0 + (size_t)wave * HW + 4 * lane;
-            const size_t gstep = (size_t)4 * HW;
-            float *const stage = (float *)lds;
-            f32x4 eg[2], en[2];
-            eg[0] = *(const f32x4 *)(ep);
-            eg[1] = *(const f32x4 *)(ep + 4);
-#pragma unroll
-            for (int s = 0; s < S16; ++s) {
-                asm volatile("" : "+v"(sw), "+v"(sr), "+v"(go), "+v"(lsum));
-                if (s + 1 < S16) {
-                    en[0] = *(const f32x4 *)(ep + 16 * (s + 1));
-                    en[1] = *(const f32x4 *)(ep + 16 * (s + 1) + 4);
-                }
-                float *sb = stage + sw + ((s & 1) ? 16 * P : 0);
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float e = eg[j >> 2][j & 3];
-                    const float diff = __fsub_rn(e, zf[s][j]);
-                    v[j] = __fadd_rn(zf[s][j], diff);
-                    lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-                }
-                if (wr) {
-                    if (dd_rep == 1) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sb[j * P] = v[j];
-                    } else if (dd_rep == 2) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const f32x2 vv = {v[j], v[j]};
-                            *(f32x2 *)(sb + j * P) = vv;
-                            *(f32x2 *)(sb + j * P + Wo) = vv;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const f32x4 vv = {v[j], v[j], v[j], v[j]};
-#pragma unroll
-                            for (int ry = 0; ry < 4; ++ry) *(f32x4 *)(sb + j * P + ry * Wo) = vv;
-                        }
-                    }
-                }
-                __syncthreads();                             // chunk s staged (the other buffer is being refilled meanwhile)
-                const float *rb = stage + sr + ((s & 1) ? 16 * P : 0);
-                float *gp = zq + go;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    if (lane < P4)
-                        __builtin_nontemporal_store(*(const f32x4 *)(rb + 4 * cc * P), (f32x4 *)(gp + cc * gstep));
-                    if (lane + 64 < P4)
-                        __builtin_nontemporal_store(*(const f32x4 *)(rb + 4 * cc * P + 256), (f32x4 *)(gp + cc * gstep + 256));
-                }
-                go += 4 * gstep;
-                eg[0] = en[0];
-                eg[1] = en[1];
-            }
-            if (!wr) lsum = 0.0f;
-        } else if (partials != nullptr && wr) {
-            const float *ep = E + (size_t)code * D + 8 * h;
-#pragma unroll
-            for (int s = 0; s < S16; ++s) {
-                const f32x4 e0 = *(const f32x4 *)(ep + 16 * s), e1 = *(const f32x4 *)(ep + 16 * s + 4);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float diff = __fsub_rn(j < 4 ? e0[j & 3] : e1[j & 3], zf[s][j]);
-                    lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
-                }
-            }
-        }
-        __syncthreads();                                     // cl_ complete
-        long long *cb = codes + (size_t)b * HW + p0;
-        for (int i = tid; i < P; i += 256) cb[i] = (long long)cl_[i];
-    } else
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
         if (zq != nullptr || partials != nullptr) {
@@ -812,11 +678,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         slot = undecided ? slot : -1;
         if (undecided && slot >= rec_cap) {                 // shard full: full exact evaluation instead; the
             if (h == 0) {                                   // provisional code / z_q written above are overwritten
-                for (int ry = 0; ry < dd_rep; ++ry)         // by the exact-list kernel, the loss term is dropped here
-                    for (int rx = 0; rx < dd_rep; ++rx) {   // (dd_rep = 1 unless SEL == 2)
-                        int pos = atomicAdd(&counters[1], 1);
-                        exact_list[pos] = n + ry * ((SEL == 2) ? rv.Wout : 0) + rx;
-                    }
+                int pos = atomicAdd(&counters[1], 1);       // by the exact-list kernel, the loss term is dropped here
+                exact_list[pos] = n;
             }
             lsum = 0.0f;
             slot = -1;
@@ -832,8 +695,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             }
             if (h == 0) {
                 RecMeta rm;
-                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = (SEL == 2) ? (-1 - n) : n; rm.prov = code;
-                rm.best = ~0ull; rm.rep = dd_rep;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = n; rm.prov = code;
+                rm.best = ~0ull; rm.rep = 1;
                 *(RecMeta *)(rec + (size_t)D * 4) = rm;
             }
         }
@@ -848,7 +711,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+#ifdef DVQ_TUNING
+    if (g_dvq_stamps != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's stores have left
+        g_dvq_stamps[8 * (size_t)blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+
+
 
 // ---------------------------------------------------------------------------------------------
 // pass 1, large codebooks ("wide" form, D = 256): a wave scores TWO blocks of 32 tokens against every
@@ -858,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 // >= 2 MiB of codebook every token is scored against.  Same top-2 tracking, same bound, same queue,
 // records and outputs as vq_assign_filter_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int D, bool M16>
+template <int D>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -914,8 +785,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     }
 
     // ---- prologue: per block, z in batches of four k-steps -> fp16 fragments, exact-order norm, bound
-    f16x8 zh[2][M16 ? 2 : S16];                             // M16: only the current pair of k-steps lives
-    f16x8 zb[2][2][M16 ? S16 / 2 : 1];                       // M16: [block][token half][k-step of 32] in 16x16x32 operand order
+    f16x8 zh[2][2];                                          // only the current pair of k-steps lives in the load layout
+    f16x8 zb[2][2][S16 / 2];                                 // [block][token half][k-step of 32] in 16x16x32 operand order
     float xn[2], thr2W[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -951,27 +822,22 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
                     zeta2 = __builtin_fmaf(r0, r0, zeta2);
                     zeta2 = __builtin_fmaf(r1, r1, zeta2);
                 }
-                if constexpr (!M16) {
-                    zh[u][s] = __builtin_bit_cast(f16x8, packed);
-                } else {
-                    zh[u][s & 1] = __builtin_bit_cast(f16x8, packed);
-                    if (s & 1) {                             // same permutation as vq_assign_filter_kernel, per-wave LDS scratch
-                        char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;
-                        *(f16x8 *)(scr + lane * 16) = zh[u][0];
-                        *(f16x8 *)(scr + 1024 + lane * 16) = zh[u][1];
+                zh[u][s & 1] = __builtin_bit_cast(f16x8, packed);
+                if (s & 1) {                                 // same permutation as vq_assign_filter_kernel, per-wave LDS scratch
+                    char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;
+                    *(f16x8 *)(scr + lane * 16) = zh[u][0];
+                    *(f16x8 *)(scr + 1024 + lane * 16) = zh[u][1];
 #pragma unroll
-                        for (int t2 = 0; t2 < 2; ++t2) {
-                            const int srcl = 16 * t2 + (lane & 15) + 32 * ((lane >> 4) & 1);
-                            zb[u][t2][s >> 1] = *(const f16x8 *)(scr + (lane >> 5) * 1024 + srcl * 16);
-                        }
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int srcl = 16 * t2 + (lane & 15) + 32 * ((lane >> 4) & 1);
+                        zb[u][t2][s >> 1] = *(const f16x8 *)(scr + (lane >> 5) * 1024 + srcl * 16);
                     }
                 }
             }
             // one batch of 32 loads at a time (register budget): the next batch's addresses depend,
             // opaquely, on this batch's last converted fragment
             zpb += (size_t)64 * HW;
-            if constexpr (M16) asm volatile("" : "+v"(zpb) : "v"(zb[u][1][(sb + 3) >> 1]));
-            else asm volatile("" : "+v"(zpb) : "v"(zh[u][M16 ? 1 : sb + 3]));
+            asm volatile("" : "+v"(zpb) : "v"(zb[u][1][(sb + 3) >> 1]));
         }
         float t8[8];
 #pragma unroll
@@ -998,76 +864,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
     float thr[2];
     bool undecided[2], hopeless[2], valid[2];
     float bestv[2], secondv[2];
-    if constexpr (!M16) {
-        // ---- code loop: 32 MFMAs per tile and wave, every A fragment used for both token blocks
-        float m1[2] = {-__builtin_inff(), -__builtin_inff()}, m2[2] = {-__builtin_inff(), -__builtin_inff()};
-        int t1[2] = {0, 0};
-        for (int t = 0; t < T; ++t) {
-            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * h;
-            f32x16 acc0, acc1;
-    #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 e4 = *(const f32x4 *)(seeds + 8 * g);
-    #pragma unroll
-                for (int q = 0; q < 4; ++q) { acc0[4 * g + q] = e4[q]; acc1[4 * g + q] = e4[q]; }
-            }
-            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            __builtin_amdgcn_s_barrier();                        // tile t (everybody's DMA) landed; t-1 consumed
-            asm volatile("" ::: "memory");
-            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
-                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
-            f16x8 a0, a1, a2, a3;
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
-            __builtin_amdgcn_sched_barrier(0);
-    #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-    #define DVQ_MM2(src, S, WAIT, NEXT)                                                     \
-            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                      \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[0][S], acc0, 0, 0, 0);    \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(src, zh[1][S], acc1, 0, 0, 0);    \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-            if ((S) + 4 < S16) { DVQ_RD(src, ((S) + 4 < S16 ? (S) + 4 : 0)); }              \
-            NEXT
-            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
-            __builtin_amdgcn_s_setprio(1);
-            DVQ_MM2(a0, 0, 3, ) DVQ_MM2(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM2(a2, 2, 3, ) DVQ_MM2(a3, 3, 3, )
-            DVQ_MM2(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM2(a1, 5, 3, ) DVQ_MM2(a2, 6, 3, ) DVQ_MM2(a3, 7, 3, issue_piece(t + 3, 2);)
-            DVQ_MM2(a0, 8, 3, ) DVQ_MM2(a1, 9, 3, ) DVQ_MM2(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM2(a3, 11, 3, )
-            DVQ_MM2(a0, 12, 3, ) DVQ_MM2(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM2(a2, 14, 1, ) DVQ_MM2(a3, 15, 0, )
-    #undef DVQ_MM2
-    #undef DVQ_RD
-            __builtin_amdgcn_s_setprio(0);
-    #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float om = m1[u];
-    #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float v0 = u == 0 ? acc0[r] : acc1[r], v1 = u == 0 ? acc0[r + 1] : acc1[r + 1];
-                    float g0 = __uint_as_float((__float_as_uint(v0) & 0xFFFFFFF0u) | (unsigned)r);
-                    float g1 = __uint_as_float((__float_as_uint(v1) & 0xFFFFFFF0u) | (unsigned)(r + 1));
-                    float md = __builtin_amdgcn_fmed3f(m1[u], g0, g1);
-                    m1[u] = vmax3_raw(m1[u], g0, g1);
-                    m2[u] = vmax_raw(m2[u], md);
-                }
-                t1[u] = (m1[u] != om) ? t : t1[u];
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-
-
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float o1 = __shfl_xor(m1[u], 32), o2 = __shfl_xor(m2[u], 32);
-            const int ot = __shfl_xor(t1[u], 32);
-            const bool other_wins = (o1 > m1[u]) || (o1 == m1[u] && h == 1);
-            bestv[u] = other_wins ? o1 : m1[u];
-            secondv[u] = fmaxf(other_wins ? m1[u] : o1, fmaxf(m2[u], o2));
-            const int wt = other_wins ? ot : t1[u];
-            const int wh = other_wins ? (h ^ 1) : h;
-            const int r = (int)(__float_as_uint(bestv[u]) & 15u);
-            code[u] = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * wh;
-        }
-    } else {
+    {
         // 16x16x32 form: every A fragment (16 codes x 32 k) feeds four MFMAs (two blocks x two token halves)
         constexpr int S32 = S16 / 2;
         const int q16 = lane >> 4;
@@ -1463,16 +1260,9 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         const char *r2 = srec + tid * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
-            if (m2.tokid >= 0) {
+            {
                 int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
                 exact_list[pos] = m2.tokid;               // pass 1's loss term for it is taken back below
-            } else {                                      // row-complete de-duplicated pass 1: the list kernel sees the
-                const int p0 = -1 - m2.tokid;             // dense view, so every covered position goes on the list
-                for (int ry = 0; ry < m2.rep; ++ry)
-                    for (int rx = 0; rx < m2.rep; ++rx) {
-                        int pos = atomicAdd(&counters[1], 1);
-                        exact_list[pos] = p0 + ry * Wout + rx;
-                    }
             }
             int pos = atomicAdd(&misc[1], 1);
             rewrite[pos] = (tid << 20) | 0xFFFFF;
@@ -1539,14 +1329,20 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
 // audit aid (dvq_debug_filter_scores_f32, tools/bound_audit.py): pass 1's score arithmetic on a few tokens
 // given as rows [n, D] -- same fp16 conversion, same seeded accumulator, same MFMA chain in the same order,
 // same index packing, same threshold -- with every score written out instead of reduced to a top-2.
-// One wave per 32 tokens; A fragments straight from the prep image.
 // ---------------------------------------------------------------------------------------------
-template <int D, bool M16>
+// audit aid (dvq_debug_filter_scores_f32, tools/bound_audit.py): pass 1's score arithmetic on a few tokens
+// given as rows [n, D] -- same fp16 conversion, same seeded accumulator, same MFMA chain in the same order
+// (v_mfma_f32_16x16x32_f16 over tile image "16"), same index packing, same threshold -- with every score
+// written out instead of reduced to a top-2.  One wave per 32 tokens; A fragments straight from the prep image.
+// (The tuning build can also dump best / second / 2W of the PRODUCTION kernel per token: g_dvq_tokdbg.)
+// ---------------------------------------------------------------------------------------------
+template <int D>
 __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     const float *__restrict__ tokens, int n, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     int K, float *__restrict__ G, float *__restrict__ thr2W_out, float *__restrict__ xn_out)
 {
     constexpr int S16 = D / 16;
+    constexpr int S32 = D / 32;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
@@ -1555,12 +1351,10 @@ __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     const float *zp = tokens + (size_t)(valid ? tok : n - 1) * D + 8 * h;
     const int T = dvq_num_tiles(K), Kpad = 32 * T;
     const float sB = meta->scale_b;
-    f16x8 zh[S16];
     float pa[2][8];
     float amax = 0.0f, zeta2 = 0.0f;
 #pragma unroll
     for (int s = 0; s < S16; ++s) {
-        u32x4 packed;
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
             const float v0 = zp[16 * s + 2 * j2], v1 = zp[16 * s + 2 * j2 + 1];
@@ -1571,12 +1365,10 @@ __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
             amax = vmax_abs(amax, v1);
             f32x2 vv = {v0, v1};
             f16x2 hh = __builtin_convertvector(vv, f16x2);
-            packed[j2] = __builtin_bit_cast(unsigned, hh);
             const float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
             zeta2 = __builtin_fmaf(r0, r0, zeta2);
             zeta2 = __builtin_fmaf(r1, r1, zeta2);
         }
-        zh[s] = __builtin_bit_cast(f16x8, packed);
     }
     float t8[8];
 #pragma unroll
@@ -1593,81 +1385,63 @@ __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     zeta2 += __shfl_xor(zeta2, 32);
     const float thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     if (valid && h == 0) { thr2W_out[tok] = thr2W; xn_out[tok] = xn; }
-    if constexpr (M16) {
-        // the 16x16x32 code loop of pass 1 (image "16" passed as img): lane (c16, q) holds tokens c16 / 16 + c16 of the
-        // block, k = 32 s' + 8 q + j -- the same fp16 values pass 1 permutes into this order
-        constexpr int S32 = D / 32;
-        const int c16 = lane & 15, q16 = lane >> 4;
-        f16x8 zb[2][S32];
+    // the 16x16x32 code loop of pass 1: lane (c16, q) holds tokens c16 / 16 + c16 of the block, k = 32 s' + 8 q + j --
+    // the same fp16 values pass 1 permutes into this order
+    const int c16 = lane & 15, q16 = lane >> 4;
+    f16x8 zb[2][S32];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int tk = blockIdx.x * 32 + 16 * t2 + c16;
-            const float *zq_ = tokens + (size_t)(tk < n ? tk : n - 1) * D + 8 * q16;
+    for (int t2 = 0; t2 < 2; ++t2) {
+        const int tk = blockIdx.x * 32 + 16 * t2 + c16;
+        const float *zq_ = tokens + (size_t)(tk < n ? tk : n - 1) * D + 8 * q16;
 #pragma unroll
-            for (int sp = 0; sp < S32; ++sp) {
-                u32x4 pk;
+        for (int sp = 0; sp < S32; ++sp) {
+            u32x4 pk;
 #pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    f32x2 vv = {zq_[32 * sp + 2 * j2], zq_[32 * sp + 2 * j2 + 1]};
-                    f16x2 hh = __builtin_convertvector(vv, f16x2);
-                    pk[j2] = __builtin_bit_cast(unsigned, hh);
-                }
-                zb[t2][sp] = __builtin_bit_cast(f16x8, pk);
+            for (int j2 = 0; j2 < 4; ++j2) {
+                f32x2 vv = {zq_[32 * sp + 2 * j2], zq_[32 * sp + 2 * j2 + 1]};
+                f16x2 hh = __builtin_convertvector(vv, f16x2);
+                pk[j2] = __builtin_bit_cast(unsigned, hh);
             }
+            zb[t2][sp] = __builtin_bit_cast(f16x8, pk);
         }
-        for (int t = 0; t < T; ++t) {
-            const char *tile = img + (size_t)t * TILE_STRIDE;
-            const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * q16;
-            f32x4 acc16[2][2];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
-                acc16[c2][0] = e4;
-                acc16[c2][1] = e4;
-            }
-#pragma unroll
-            for (int F = 0; F < 2 * S32; ++F) {
-                const f16x8 a = *(const f16x8 *)(tile + F * 1024 + lane * 16);
-                acc16[F / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[0][F % S32], acc16[F / S32][0], 0, 0, 0);
-                acc16[F / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[1][F % S32], acc16[F / S32][1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int tk = blockIdx.x * 32 + 16 * t2 + c16;
-                if (tk < n) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int code = t * 32 + 16 * (r >> 2) + 4 * q16 + (r & 3);
-                        G[(size_t)tk * Kpad + code] = __uint_as_float((__float_as_uint(acc16[r >> 2][t2][r & 3]) & 0xFFFFFFF0u) | (unsigned)r);
-                    }
-                }
-            }
-        }
-        return;
     }
     for (int t = 0; t < T; ++t) {
         const char *tile = img + (size_t)t * TILE_STRIDE;
-        const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * h;
-        f32x16 acc;
+        const float *seeds = (const float *)(tile + IMG_BYTES) + 4 * q16;
+        f32x4 acc16[2][2];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 e4 = *(const f32x4 *)(seeds + 8 * g4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g4 + q] = e4[q];
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
+            acc16[c2][0] = e4;
+            acc16[c2][1] = e4;
         }
 #pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            const f16x8 a = *(const f16x8 *)(tile + s * 1024 + lane * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, zh[s], acc, 0, 0, 0);
+        for (int F = 0; F < 2 * S32; ++F) {
+            const f16x8 a = *(const f16x8 *)(tile + F * 1024 + lane * 16);
+            acc16[F / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[0][F % S32], acc16[F / S32][0], 0, 0, 0);
+            acc16[F / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, zb[1][F % S32], acc16[F / S32][1], 0, 0, 0);
         }
-        if (valid) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                G[(size_t)tok * Kpad + code] = __uint_as_float((__float_as_uint(acc[r]) & 0xFFFFFFF0u) | (unsigned)r);
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int tk = blockIdx.x * 32 + 16 * t2 + c16;
+            if (tk < n) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int code = t * 32 + 16 * (r >> 2) + 4 * q16 + (r & 3);
+                    G[(size_t)tk * Kpad + code] = __uint_as_float((__float_as_uint(acc16[r >> 2][t2][r & 3]) & 0xFFFFFFF0u) | (unsigned)r);
+                }
             }
         }
     }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// the 16x16x32-order image follows the 32x32x16-order one (which the resolver reads)
+static size_t dvq_img16_offset(int K, int D)
+{
+    const size_t tile = (size_t)(D / 16) * 1024 + 256;
+    return ((size_t)dvq_num_tiles(K) * tile + 255) / 256 * 256;
 }
 
 int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
@@ -1676,28 +1450,25 @@ int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep,
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
     const DvqF16Meta *meta = (const DvqF16Meta *)base;
-    const char *img = base + 256;
+    const char *im = base + 256 + dvq_img16_offset(K, D);
     const int blocks = (n + 31) / 32;
-    // the arithmetic pass 1 uses: DVQ_MFMA16 (default DVQ_MFMA16_DEFAULT) picks the 16x16x32 loop and its image
-    const bool m16 = dvq_mfma16_enabled();
-    const char *im = m16 ? img + dvq_img16_offset_of(K, D) : img;
-#define DVQ_DBG(DD) do { if (m16) hipLaunchKernelGGL((filter_scores_debug_kernel<DD, true>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); \
-                         else hipLaunchKernelGGL((filter_scores_debug_kernel<DD, false>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); } while (0)
     switch (D) {
-    case 64:  DVQ_DBG(64); break;
-    case 128: DVQ_DBG(128); break;
-    case 256: DVQ_DBG(256); break;
+    case 64:  hipLaunchKernelGGL(filter_scores_debug_kernel<64>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+    case 128: hipLaunchKernelGGL(filter_scores_debug_kernel<128>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+    case 256: hipLaunchKernelGGL(filter_scores_debug_kernel<256>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
     default:  return -1000;
     }
-#undef DVQ_DBG
     if (scale_b_out != nullptr)
         (void)hipMemcpyAsync(scale_b_out, &meta->scale_b, sizeof(float), hipMemcpyDeviceToDevice, st);
     return (int)hipGetLastError();
 }
 
+// counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
+// [1] exact-list count, [4] finalize ticket, [5] prepass ticket, [DVQ_QCOUNT0 ..] per-shard queue counts,
+// [DVQ_LOCK0 ..] one anti-phase lock word per (XCC, CU)
 __global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict__ chunk_sync, int nsync)
 {
-    for (int i = threadIdx.x; i < DVQ_QCOUNT0 + DVQ_QSHARDS; i += blockDim.x) counters[i] = 0;
+    for (int i = threadIdx.x; i < DVQ_COUNTER_BYTES / 4; i += blockDim.x) counters[i] = 0;
     for (int i = threadIdx.x; i < nsync; i += blockDim.x) chunk_sync[i] = 0;      // sliced resolver only
 }
 
@@ -1709,7 +1480,37 @@ int dvq_launch_exact_list(const float *z, const float *prep, const float *E, con
                           const int *list, const int *list_count, DvqLossTail tail, const DvqRouted *rv,
                           hipStream_t st);
 
-static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+// Launch-time choices of the filter path.  They are compile-time constants of the production library; only the
+// tuning build (-DDVQ_TUNING: libdvq_tuning.so, tools/) can change them, through dvq_tuning_set().
+struct DvqTune {
+    int antiphase;       // pass 1: the two workgroups of a CU take turns in the code loop (per-CU lock)
+    int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
+    int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
+};
+#ifndef DVQ_ANTIPHASE_DEFAULT
+#define DVQ_ANTIPHASE_DEFAULT 1
+#endif
+#ifdef DVQ_TUNING
+static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0};
+extern "C" int dvq_tuning_set(const char *key, int value)
+{
+    if (!strcmp(key, "antiphase")) g_tune.antiphase = value;
+    else if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
+    else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
+    else return -1;
+    return 0;
+}
+// device buffers the tuning build's pass 1 writes its diagnostics to (null = off): stamps [grid][8] u64 (see
+// g_dvq_stamps); tokdbg [N][4] f32 = best, second, 2W, code
+extern "C" int dvq_tuning_buffers(void *stamps, void *tokdbg)
+{
+    hipError_t rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_stamps), &stamps, sizeof(void *));
+    if (rc == hipSuccess) rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
+    return (int)rc;
+}
+#else
+static constexpr DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0};
+#endif
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
 static int shard_capacity(long N)
@@ -1732,10 +1533,7 @@ bool dvq_filter_supported(int D, int HW, int K, long N)
 // resolver slices over the code tiles: 1 up to 64 tiles (K <= 2048), then one per 64 tiles, at most 8
 static int resolver_slices(int K)
 {
-    {
-        const char *v = getenv("DVQ_RES_SLICES");           // tuning aid
-        if (v && *v) { int x = atoi(v); if (x >= 1 && x <= 8) return x; }
-    }
+    if (g_tune.res_slices >= 1 && g_tune.res_slices <= 8) return g_tune.res_slices;
     int T = dvq_num_tiles(K);
     int ns = (T + 63) / 64;
     return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
@@ -1743,20 +1541,11 @@ static int resolver_slices(int K)
 
 // ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk]
 //           [exact list N ints][records cap * rec_bytes]
-// counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
-// [1] exact-list count, [4] finalize ticket, [DVQ_QCOUNT0 ..] per-shard queue counts
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
     return DVQ_COUNTER_BYTES + align256((size_t)rec_capacity(N) / RES_SLOTS * 2 * sizeof(int)) +
            align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
-}
-
-// the 16x16x32-order image follows the 32x32x16-order one
-static size_t dvq_img16_offset(int K, int D)
-{
-    const size_t tile = (size_t)(D / 16) * 1024 + 256;
-    return ((size_t)dvq_num_tiles(K) * tile + 255) / 256 * 256;
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -1784,58 +1573,8 @@ static int list_blocks(long N)
     return (int)(nb < DVQ_EXACT_LIST_BLOCKS ? nb : DVQ_EXACT_LIST_BLOCKS);
 }
 
-// ---- low-register pass 1 (vq_assign_routed.hip)
-int dvq_launch_pass1_lowreg(int D, bool routed, int variant, const P1Args &a, int nblocks, hipStream_t st);
-int dvq_pass1_tokens_per_block(int variant);
 int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr, int B, int hc, int wc,
-                              long long *indices, float *cmask, long long *gate_out, int *imgcount,
-                              unsigned short *tok, int *imgstart, int *ticket, int dense, hipStream_t st);
-
-// Which pass-1 kernel: DVQ_PASS1_VARIANT = -1 legacy (fp32 copy of z in registers, 2 waves / SIMD; the wide
-// form for large codebooks), 0..3 the low-register forms of vq_assign_routed.hip.  The routed op always
-// takes a low-register form (DVQ_ROUTED_VARIANT, default 0).
-static int env_int(const char *name, int dflt, int lo, int hi)
-{
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    int x = atoi(v);
-    return (x < lo || x > hi) ? dflt : x;
-}
-#ifndef DVQ_PASS1_DEFAULT
-#define DVQ_PASS1_DEFAULT -1
-#endif
-#ifndef DVQ_ROUTED_DEFAULT
-#define DVQ_ROUTED_DEFAULT 0
-#endif
-#ifndef DVQ_ROUTED_DEDUP_DEFAULT
-#define DVQ_ROUTED_DEDUP_DEFAULT 0
-#endif
-#ifndef DVQ_STAGGER_DEFAULT_US
-#define DVQ_STAGGER_DEFAULT_US 0
-#endif
-static int g_dense_variant = -2, g_routed_variant = -2;      // -2: not chosen yet (environment / default)
-static bool dvq_mfma16_enabled() { return env_int("DVQ_MFMA16", DVQ_MFMA16_DEFAULT, 0, 1) != 0; }
-static size_t dvq_img16_offset_of(int K, int D) { return dvq_img16_offset(K, D); }
-static int dense_variant()
-{
-    int v = __atomic_load_n(&g_dense_variant, __ATOMIC_RELAXED);
-    if (v == -2) { v = env_int("DVQ_PASS1_VARIANT", DVQ_PASS1_DEFAULT, -1, 3); __atomic_store_n(&g_dense_variant, v, __ATOMIC_RELAXED); }
-    return v;
-}
-static int routed_variant()
-{
-    int v = __atomic_load_n(&g_routed_variant, __ATOMIC_RELAXED);
-    if (v == -2) { v = env_int("DVQ_ROUTED_VARIANT", DVQ_ROUTED_DEFAULT, 0, 3); __atomic_store_n(&g_routed_variant, v, __ATOMIC_RELAXED); }
-    return v;
-}
-// tuning / testing aid (dvq_set_pass1_variant): -2 keeps the current choice
-int dvq_choose_pass1_variant(int dense, int routed)
-{
-    if (dense < -2 || dense > 3 || routed < -2 || routed > 3 || routed == -1) return -1;
-    if (dense != -2) __atomic_store_n(&g_dense_variant, dense, __ATOMIC_RELAXED);
-    if (routed != -2) __atomic_store_n(&g_routed_variant, routed, __ATOMIC_RELAXED);
-    return 0;
-}
+                              long long *indices, float *cmask, long long *gate_out, hipStream_t st);
 
 struct FilterWs {
     int *counters, *chunk_sync, *exact_list;
@@ -1856,66 +1595,63 @@ static FilterWs carve_ws(void *ws_extra, long N, int D)
     return w;
 }
 
-template <int D, int SEL, bool M16>
-static int launch_legacy_form(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
-                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
-                              double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st)
+// SEL = 2 applies to the reference's grids: output rows of 32 positions, whole workgroups of 4 rows per image, and
+// branch tensors the 16-byte DMA pieces can address
+static bool staged_select_ok(const DvqRouted &rv)
+{
+    if (!g_tune.sel_staged || rv.Wout != 32 || rv.HWout % 128 != 0) return false;
+    for (int g = 0; g < rv.G; ++g)
+        if (((uintptr_t)rv.src[g] & 15) != 0) return false;
+    return true;
+}
+
+template <int D, int SEL>
+static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta *meta, const float *E,
+                             const float *mask, int HW, int K, long N, float *zq, long long *codes,
+                             double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st)
 {
     static unsigned long long done = 0;
-    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + ((M16 || SEL == 2) ? 4 * 2048 : 0);
-    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, M16>, (int)shmem1, &done);
+    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL>, (int)shmem1, &done);
     if (rc) return rc;
-    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, M16>), dim3((unsigned)((N + 127) / 128)), dim3(256), shmem1, st,
-                       z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, rv);
+    const unsigned grid = (unsigned)((N + 127) / 128);
+    // anti-phase pays when every CU holds two workgroups for more than one generation
+    int *lock = (g_tune.antiphase && grid >= 1024) ? w.counters + DVQ_LOCK0 : nullptr;
+    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL>), dim3(grid), dim3(256), shmem1, st,
+                       z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                       w.cap / DVQ_QSHARDS, rv, lock);
     return (int)hipGetLastError();
 }
 
 template <int D>
-static int launch_legacy_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
-                               const float *mask, int HW, int K, long N, float *zq, long long *codes,
-                               double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
-                               hipStream_t st)
+static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
+                        const float *mask, int HW, int K, long N, float *zq, long long *codes,
+                        double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
+                        hipStream_t st)
 {
-    const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float);
     const int nb1 = (int)((N + 127) / 128);
-    // DVQ_MFMA16 = 1: the code loop on v_mfma_f32_16x16x32_f16 (second tile image of the prep buffer)
-    const bool m16 = dvq_mfma16_enabled();
-    const char *img16 = img + dvq_img16_offset(K, D);
-    if (rv != nullptr) {                                     // select fused in (rv->dense): legacy form only
-        if constexpr (D == 256) {
-            if (rv->wgd != nullptr)                          // unique tokens only, rows of cells per workgroup
-                return m16 ? launch_legacy_form<D, 2, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
-                           : launch_legacy_form<D, 2, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
-        }
-        return m16 ? launch_legacy_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st)
-                   : launch_legacy_form<D, 1, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+    const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
+    if (rv != nullptr) {                                     // select fused in
+        if (staged_select_ok(*rv))
+            return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+        return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
     }
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
                                                              // with two 256-token workgroups: two blocks per wave
-            static unsigned long long done_w = 0, done_w16 = 0;
+            static unsigned long long done_w = 0;
             const unsigned gridw = (unsigned)((N + 255) / 256);
-            if (m16) {
-                const size_t shm = shmem1 + 4 * 2048;        // + the per-wave permutation scratch
-                int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D, true>, (int)shm, &done_w16);
-                if (rc) return rc;
-                hipLaunchKernelGGL((vq_assign_filter_wide_kernel<D, true>), dim3(gridw), dim3(256), shm, st,
-                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list,
-                                   w.records, w.cap / DVQ_QSHARDS, nb1);
-            } else {
-                int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D, false>, (int)shmem1, &done_w);
-                if (rc) return rc;
-                hipLaunchKernelGGL((vq_assign_filter_wide_kernel<D, false>), dim3(gridw), dim3(256), shmem1, st,
-                                   z, img, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list,
-                                   w.records, w.cap / DVQ_QSHARDS, nb1);
-            }
+            const size_t shm = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
+            int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_wide_kernel<D>, (int)shm, &done_w);
+            if (rc) return rc;
+            hipLaunchKernelGGL((vq_assign_filter_wide_kernel<D>), dim3(gridw), dim3(256), shm, st,
+                               z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list,
+                               w.records, w.cap / DVQ_QSHARDS, nb1);
             return (int)hipGetLastError();
         }
     }
     const DvqRouted none = {};
-    return m16 ? launch_legacy_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st)
-               : launch_legacy_form<D, 0, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
+    return launch_pass1_form<D, 0>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
 }
 
 template <int D>
@@ -1942,8 +1678,8 @@ static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, con
     }
 }
 
-// Dense op: z [B, D, HW].  Routed op (rv != nullptr): the unique tokens of rv; N = B * HWout (the
-// all-fine worst case sizes the workspace and the grids), mask = the codebook_mask the prepass wrote.
+// Dense op: z [B, D, HW].  Routed op (rv != nullptr): one token per output position of rv (the select fused into
+// pass 1); N = B * HWout, mask = the codebook_mask pass 1 writes.
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
@@ -1956,50 +1692,18 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     const FilterWs w = carve_ws(ws_extra, N, D);
     const bool routed = rv != nullptr;
-    if (!routed) {
-        // [0] queue, [1] exact list, [4] finalize ticket, [5] prepass ticket.  A kernel rather than
-        // hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of kernel
-        // nodes under hipGraph capture.  (The routed op zeroes them before its prepass.)
-        hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
-                           resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-    }
-    // routed + de-duplicated: always a low-register form; routed without de-duplication (rv->dense): the legacy
-    // form with the select fused in unless DVQ_ROUTED_VARIANT picks a low-register one explicitly
-    int variant = routed ? routed_variant() : ((force_wide || D != 256) ? -1 : dense_variant());
-    if (routed && rv->dense && (rv->wgd != nullptr || env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) == 0)) variant = -1;
-    int rc, np1;
-    if (variant < 0) {
-        np1 = (int)((N + 127) / 128);
-        switch (D) {
-        case 64:  rc = launch_legacy_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
-        case 128: rc = launch_legacy_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
-        case 256: rc = launch_legacy_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
-        default:  return -1000;
-        }
-    } else {
-        const int tpb = dvq_pass1_tokens_per_block(variant);
-        np1 = (int)((N + tpb - 1) / tpb);                      // routed: the all-fine worst case sizes the grid
-        P1Args a;
-        a.z = z; a.HW = HW; a.N = N;
-        if (routed) a.rv = *rv; else a.rv = DvqRouted{};
-        a.img = img; a.meta = meta; a.E = E; a.mask = mask; a.K = K; a.zq = zq; a.codes = codes;
-        a.partials = partials; a.counters = w.counters; a.exact_list = w.exact_list; a.records = w.records;
-        a.rec_cap = w.cap / DVQ_QSHARDS;
-        {
-            const int stag = env_int("DVQ_STAGGER_US", DVQ_STAGGER_DEFAULT_US, 0, 1000);   // read per launch: a tuning aid
-            static int ncu = 0;
-            if (ncu == 0) {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                ncu = n > 0 ? n : 256;
-            }
-            const int per_cu = (variant == 1) ? 3 : ((variant >= 2) ? 2 : 4);
-            a.stagger_ticks = stag * 100;
-            a.stagger_blocks = ncu;
-            a.stagger_first = ncu * per_cu;
-            a.debug = env_int("DVQ_P1_DEBUG", 0, 0, 7);
-        }
-        rc = dvq_launch_pass1_lowreg(D, routed, variant, a, np1, st);
+    // A kernel rather than hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of
+    // kernel nodes under hipGraph capture.
+    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
+                       resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    const int np1 = (int)((N + 127) / 128);
+    switch (D) {
+    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+    default:  return -1000;
     }
     if (rc || pass1_only) return rc;
     const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
@@ -2016,17 +1720,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
 }
 
 // ---- routed op ---------------------------------------------------------------------------------
-// routing tables behind the filter workspace: [imgcount B ints][imgstart B+1 ints][tok B*HWout u16]
-size_t dvq_routed_tables_bytes(int G, int B, int hc, int wc)
-{
-    const int SC = (G == 2) ? 2 : 4;
-    return align256((size_t)B * sizeof(int)) + align256((size_t)(B + 1) * sizeof(int)) +
-           align256((size_t)B * SC * hc * SC * wc * sizeof(unsigned short));
-}
-
-// zero counters -> prepass (indices, codebook_mask, gate_out, routing tables) -> the filter op (or, exact
-// mode, every unique token by the exact chain).  ws_extra: dvq_filter_ws_extra_bytes(N = B*HWout) bytes
-// followed by dvq_routed_tables_bytes.
+// filter mode: zero counters -> pass 1 with the select fused in (it derives the grain of every position's cell from the
+// gate and writes indices / codebook_mask / gate_out itself: no prepass, no tables) -> resolver -> list + loss finalize.
+// exact mode: a prepass writes indices / codebook_mask / gate_out, then every position by the exact chain.
 int dvq_launch_exact(const float *z, const float *prep, const float *E, const float *mask,
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                      const DvqRouted *rv, hipStream_t st);
@@ -2042,36 +1738,15 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
     const int SC = (G == 2) ? 2 : 4;
     const int Wout = SC * wc, HWout = SC * hc * Wout;
     const long N = (long)B * HWout;
-    const FilterWs w = carve_ws(ws_extra, N, D);
-    char *tab = (char *)ws_extra + dvq_filter_ws_extra_bytes(D, HWout, K, N);
-    int *imgcount = (int *)tab;
-    int *imgstart = (int *)(tab + align256((size_t)B * sizeof(int)));
-    unsigned short *tok = (unsigned short *)((char *)imgstart + align256((size_t)(B + 1) * sizeof(int)));
-    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
-                       resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-    // DVQ_ROUTED_DEDUP = 1: score unique tokens only (token tables from the prepass, low-register pass 1);
-    // 0 (default DVQ_ROUTED_DEDUP_DEFAULT): one token per output position -- the select fused into the legacy
-    // pass-1 kernel, which derives the grain from the gate itself: no prepass, no tables
-    // 2: unique tokens only, whole rows of cells per legacy pass-1 workgroup, z_q staged through LDS so that it leaves
-    //    as whole rows (D = 256, 32-wide output grid; anything else takes form 0)
-    int form = env_int("DVQ_ROUTED_DEDUP", DVQ_ROUTED_DEDUP_DEFAULT, 0, 2);
-    if (form == 2 && (exact || D != 256 || Wout != 32 || HWout % 128 != 0)) form = 0;
-    const bool rowdedup = form == 2;
-    const int dense = (form == 1) ? 0 : 1;
-    const bool lowreg_dense = dense && !rowdedup && env_int("DVQ_ROUTED_DENSE_LOWREG", 0, 0, 1) != 0;
-    const bool need_prepass = !dense || exact || lowreg_dense || rowdedup;
     int rc = 0;
-    if (need_prepass) {
-        rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, imgcount, tok,
-                                       imgstart, w.counters + 5, rowdedup ? 2 : dense, st);
+    if (exact) {
+        rc = dvq_launch_routed_prepass(G, gate_mode, gate, thr, B, hc, wc, indices, cmask, gate_out, st);
         if (rc) return rc;
     }
     DvqRouted rv{};
     rv.G = G; rv.B = B; rv.D = D; rv.hc = hc; rv.wc = wc; rv.Wout = Wout; rv.HWout = HWout;
-    rv.imgstart = imgstart; rv.tok = tok; rv.dense = dense;
     rv.indices = indices; rv.gate = gate; rv.gate_mode = gate_mode; rv.thr = thr;
-    if (!need_prepass) { rv.indices_out = indices; rv.cmask_out = cmask; rv.gate_out = gate_out; }
-    rv.wgd = rowdedup ? (const int *)tok : nullptr;
+    if (!exact) { rv.indices_out = indices; rv.cmask_out = cmask; rv.gate_out = gate_out; }
     if (G == 2) {
         rv.src[0] = h_coarse; rv.src[1] = h_fine; rv.src[2] = nullptr;
         rv.sub[0] = 1; rv.sub[1] = 2; rv.sub[2] = 1;

@@ -11,7 +11,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch
  *     tensor's data_ptr()); nothing is allocated or freed inside;
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
- *     are stream-ordered, never synchronise, and are re-entrant;
+ *     are stream-ordered, never synchronise, and are re-entrant: the library keeps
+ *     no mutable process-wide state and reads no environment variable (kernel
+ *     choices are compile-time constants; the A/B switches of the tuning build,
+ *     libdvq_tuning.so made by `make tuning`, are not part of this ABI);
  *   - return value: DVQ_OK (0) or a negative DVQ_E* code; the message of the
  *     last failure on the calling thread is dvq_last_error_string();
  *   - tensors are dense, C-contiguous, float32 unless stated; code indices and
@@ -137,10 +140,12 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
  * Routed assignment: routing tail + VectorQuantize2.forward as ONE op straight from the encoder
  * branches -- replaces dvq_route_select_{dual,triple}_f32 followed by dvq_vq_assign_nchw_f32
  * (EncoderDual.py:134-149 / EncoderTriple.py:148-176 + quantize2_mask.py:157-191) when nothing sits
- * between select and quantizer.  The 2x2 / 4x4 output positions of a coarse (median) cell are copies of
- * one source vector, so each UNIQUE token is scored once and its code / z_q written to every position it
- * covers; h_dual / h_triple is never materialised.  Same per-token arithmetic as the dense op: codes,
- * z_q, indices, cmask identical bit for bit to select + assign, loss within 1e-5.
+ * between select and quantizer.  The select is fused into the assign's first kernel: every OUTPUT POSITION is a
+ * token, read from the branch that won its cell (the grain is derived from the gate inside the kernel), scored,
+ * and written; h_dual / h_triple is never materialised and indices / cmask / gate_out come out as by-products.
+ * (The 2x2 / 4x4 positions of a coarse cell are copies of one vector and so get the same code; scoring each unique
+ * vector once was built and measured slower -- DESIGN.md section 4.3.)  Same per-token arithmetic as the dense op:
+ * codes, z_q, indices, cmask identical bit for bit to select + assign, loss within 1e-5.
  *   gate      DVQ_GATE_F32 / DVQ_GATE_I64: [B, hc, wc, G]; DVQ_GATE_ENTROPY (dual only): entropy [B, hc, wc]
  *             with `threshold` (gate = [(e <= thr), (e > thr)], written to gate_out [B, hc, wc, 2] if non-NULL)
  *   h_coarse  [B, D, hc, wc]; h_median [B, D, 2hc, 2wc] (triple); h_fine [B, D, S hc, S wc], S = 2 (dual) / 4 (triple)
@@ -148,7 +153,8 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
  *   indices   [B, hc, wc] int64 grain index per coarse cell; cmask [B, 1, S hc, S wc] (0.0625 / 0.25 / 1.0)
  *   ws        >= dvq_vq_assign_routed_workspace_bytes(num_branches, ...), 256-byte aligned
  *   mode      DVQ_MODE_EXACT / DVQ_MODE_FILTER (/ DVQ_MODE_FILTER_PASS1)
- * hc * wc <= 1024 coarse cells per image, B <= 32768.
+ * hc * wc <= 1024 coarse cells per image, B <= 32768; any hc, wc (32-wide output grids, i.e. every reference
+ * config, take a form that stages the coarser branches through LDS).
  */
 size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int hc, int wc, int K, int mode);
 int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,
@@ -190,14 +196,6 @@ int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, floa
  *   scores [n, 32*ceil(K/32)] (padding codes hold -3e38), threshold [n], xn [n], scale [1] (nullable) */
 int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,
                                 float *threshold, float *xn, float *scale, void *stream);
-
-/* Tuning / testing aid: which pass-1 kernel DVQ_MODE_FILTER launches (process-wide; results are identical
- * for every choice).  dense_variant: -1 = the 2-waves-per-SIMD kernel that keeps an fp32 copy of z in
- * registers (wide form for K >= 2048), 0..3 = the low-register forms (0: 4-wave workgroups, 2-slot codebook
- * ring, 4 per CU; 1: 4 waves, 3 slots, 3 per CU; 2: 8 waves, 4 slots, 2 per CU; 3: 8 waves, 3 slots, 2 per
- * CU); routed_variant: 0..3 (the routed op always takes a low-register form); -2 keeps the current choice.
- * Defaults: environment DVQ_PASS1_VARIANT / DVQ_ROUTED_VARIANT, else the built-in choice. */
-int dvq_set_pass1_variant(int dense_variant, int routed_variant);
 
 /* as dvq_vq_assign_fallback_count_offset, for a routed workspace */
 size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K);

@@ -5,7 +5,10 @@
                         resolver (quantize2_mask.py:157-191).  The reference's dense [N, K] distance
                         matrix would be 8.6 GB, so it is run 16 images at a time (tokens are independent).
 
-Usage: python oracle/gen_golden_dispatch.py
+  vq2_K16384_B512_crc   the same at BASELINE configs[4]'s full size, B = 512 (524288 tokens; its first 128 images are
+                        the images of the B = 128 fixture).
+
+Usage: python oracle/gen_golden_dispatch.py [B ...]        (default: 128)
 """
 import os
 import sys
@@ -19,9 +22,9 @@ from oracle import refimport  # noqa: E402
 from oracle.gen_golden import crc, per_image_crc, save  # noqa: E402
 from dynamicvectorquantization_amd import synth  # noqa: E402
 
-if __name__ == "__main__":
+def generate(B):
     VQ2, _ = refimport.quantizers()
-    B, H, W, K, D, seed = 128, 32, 32, 16384, 256, 2605
+    H, W, K, D, seed = 32, 32, 16384, 256, 2605
     E = synth.codebook_trained(K, D)
     z = synth.z_tokens(E, B, H, W, seed)
     mask = np.where(synth.bernoulli(seed + 1, (B, 1, H, W), 0.5), 1.0, 0.25).astype(np.float32)
@@ -35,7 +38,12 @@ if __name__ == "__main__":
             zq_crc.append(per_image_crc(xq.numpy()))
             sq += float(loss) / 1.25 * (16 * H * W * D)               # loss = 1.25 * mean over the chunk
     codes = np.concatenate(codes, 0)
-    save("vq2_K16384_B128_crc", cls="VectorQuantize2", B=B, H=H, W=W, K=K, D=D, cb_kind="trained", seed=seed, masked=1,
+    save("vq2_K16384_B%d_crc" % B, cls="VectorQuantize2", B=B, H=H, W=W, K=K, D=D, cb_kind="trained", seed=seed, masked=1,
          beta=np.float32(0.25), z_crc=crc(z), cb_crc=crc(E), mask_crc=crc(mask), codes_crc=per_image_crc(codes),
          zq_crc=np.concatenate(zq_crc, 0), codes_image0=codes[0].astype(np.int16),
          loss=np.float32(1.25 * sq / (B * H * W * D)))
+
+
+if __name__ == "__main__":
+    for b in ([int(x) for x in sys.argv[1:]] or [128]):
+        generate(b)

@@ -9,10 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mfma16", ["1", "0"])
-def test_bound_holds_with_margin(dev, mfma16, monkeypatch):
-    """both code-loop arithmetics of pass 1: v_mfma_f32_16x16x32_f16 (default) and 32x32x16"""
-    monkeypatch.setenv("DVQ_MFMA16", mfma16)
+def test_bound_holds_with_margin(dev):
+    """the code-loop arithmetic of pass 1 (v_mfma_f32_16x16x32_f16 over tile image "16"), restated by the audit kernel"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bound_audit", os.path.join(root, "tools", "bound_audit.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -1,7 +1,9 @@
 """GPU (-m gpu): the routed assign (dvq_vq_assign_routed_{dual,triple}_f32 -- routing tail + VectorQuantize2
-as one op on the unique tokens) against the CPU oracle's select + assign on the same seeded inputs, and
-the parity holes VERDICT r1 named at DISPATCH size: the exact bench step at B = 256 on all images, the
-triple encode at the per-rank size B = 128, K = 16384 through the wide pass-1 kernel + sliced resolver.
+as one op, the select fused into pass 1) against the CPU oracle's select + assign on the same seeded inputs, at
+every form pass 1 takes (32-wide output grids stage the coarser branches through LDS, other grids address them per
+lane; >= 1024 workgroups switch the per-CU anti-phase lock on), and at DISPATCH size: the exact bench step at
+B = 256 on all images, configs[1] end to end at B = 64, the triple encode at the per-rank size B = 128, K = 16384
+through the wide pass-1 kernel + sliced resolver at B = 128 and at configs[4]'s B = 512.
 Bar: codes, grain indices, codebook_mask, gate and z_q bit-exact; loss 1e-5."""
 import numpy as np
 import pytest
@@ -28,40 +30,14 @@ def _check_dual(r, o_sel, o, B, beta=0.25, oracle_mod=None):
         assert C.loss_close(float(r["loss"][1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], beta)), "loss"
 
 
-# routed-op forms: ("dedup", v) = unique tokens only, low-register pass-1 variant v; ("fused", -1) = one token per
-# output position with the select fused into the legacy pass-1 kernel (the default); ("fused", v) = the same on a
-# low-register form; ("fused32", -1) = the default with the 32x32x16 code loop instead of 16x16x32
-# ("rows", -1) / ("rows32", -1) = unique tokens only, whole rows of cells per legacy pass-1 workgroup, z_q staged through
-# LDS (DVQ_ROUTED_DEDUP=2; D = 256 and a 32-wide output grid, other shapes take the fused form)
-FORMS = [("dedup", 0), ("dedup", 1), ("dedup", 2), ("dedup", 3), ("fused", -1), ("fused", 1), ("fused32", -1),
-         ("rows", -1), ("rows32", -1)]
-
-
-@pytest.fixture(params=FORMS, ids=["%s%d" % f for f in FORMS])
-def variant(request):
-    import os
-    from dynamicvectorquantization_amd import _lib
-    kind, v = request.param
-    assert _lib.lib.dvq_set_pass1_variant(-2, max(v, 0)) == 0
-    os.environ["DVQ_ROUTED_DEDUP"] = "1" if kind == "dedup" else ("2" if kind.startswith("rows") else "0")
-    os.environ["DVQ_ROUTED_DENSE_LOWREG"] = "1" if (kind == "fused" and v >= 0) else "0"
-    os.environ["DVQ_MFMA16"] = "0" if kind.endswith("32") else "1"      # code loop of the legacy pass 1: 16x16x32 (default) / 32x32x16
-    yield 0 if request.param == FORMS[0] else 1 + FORMS.index(request.param)
-    _lib.lib.dvq_set_pass1_variant(-2, 0)
-    os.environ.pop("DVQ_ROUTED_DEDUP", None)
-    os.environ.pop("DVQ_ROUTED_DENSE_LOWREG", None)
-    os.environ.pop("DVQ_MFMA16", None)
-
-
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 4, 6), (9, 16, 16), (17, 5, 8), (2, 32, 32)])
-def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode, variant):
-    """ragged batches (not a multiple of the 8-image group), grids from 1x2 to 32x32 cells, every pass-1 variant;
+@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 4, 6), (9, 16, 16), (17, 5, 8), (2, 32, 32), (3, 5, 7), (4, 2, 16)])
+def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode):
+    """ragged batches, grids from 1x2 to 32x32 cells incl. odd widths (15-wide grids: 240-px images); the 32-wide
+    output grids (9, 16, 16) / (4, 2, 16) take the LDS-staged form, the others the per-lane form;
     int64 gate, f32 logits (ties / NaN) and the fused entropy router"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
-    if mode == 0 and variant not in (0, 5):
-        pytest.skip("the exact mode does not use pass 1 (run once per token layout)")
     B, hc, wc = shape
     K, D = 333, 256
     E = synth.codebook_trained(K, D, seed=500 + hc)
@@ -97,12 +73,11 @@ def test_routed_dual_vs_oracle(dev, oracle_mod, shape, mode, variant):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 2, 3), (10, 8, 8), (2, 16, 16)])
-def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 2, 3), (10, 8, 8), (2, 16, 16), (5, 3, 8)])
+def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode):
+    """(10, 8, 8) and (5, 3, 8) are 32 positions wide: median and coarse branches staged through LDS"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_triple
-    if mode == 0 and variant not in (0, 5):
-        pytest.skip("the exact mode does not use pass 1 (run once per token layout)")
     B, hc, wc = shape
     K, D = 1024, 256
     E = synth.codebook_trained(K, D)
@@ -122,15 +97,11 @@ def test_routed_triple_vs_oracle(dev, oracle_mod, shape, mode, variant):
         _check_dual(r, o_sel, o, B, oracle_mod=oracle_mod)
 
 
-@pytest.mark.parametrize("m16", ["1", "0"])
-def test_rows_form_special_tokens(dev, oracle_mod, m16, monkeypatch):
-    """row-complete de-duplicated pass 1 (DVQ_ROUTED_DEDUP=2) on a 32-wide grid, dual and triple: NaN / Inf / huge
-    tokens in every branch (exact list: every covered position), zero tokens, all-coarse and all-fine images (8-row
-    and 2-row workgroups), codes-only and loss-only calls"""
+def test_staged_form_special_tokens(dev, oracle_mod):
+    """the LDS-staged select (32-wide grid), dual and triple: NaN / Inf / huge tokens in every branch (exact list),
+    zero tokens, all-coarse and all-fine images, codes-only and loss-only calls"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
-    monkeypatch.setenv("DVQ_ROUTED_DEDUP", "2")
-    monkeypatch.setenv("DVQ_MFMA16", m16)
     t = _t(dev)
     B, K, D = 6, 300, 256
     E = synth.codebook_trained(K, D, seed=91)
@@ -144,8 +115,8 @@ def test_rows_form_special_tokens(dev, oracle_mod, m16, monkeypatch):
         a[4, :, 0, 1] = 0.0
         a[5, :, 7, 7] = np.nan
     lg = synth.grain_logits_triple(95, B, 8, 8)
-    lg[4] = np.array([1.0, 0.0, -1.0], dtype=np.float32)          # all coarse: 8 tokens per row of cells
-    lg[5] = np.array([-1.0, 0.0, 1.0], dtype=np.float32)          # all fine: 128 tokens per row of cells
+    lg[4] = np.array([1.0, 0.0, -1.0], dtype=np.float32)          # all coarse
+    lg[5] = np.array([-1.0, 0.0, 1.0], dtype=np.float32)          # all fine
     prep = _CodebookPrep()
     r = vq_assign_routed_triple(t(hco), t(hm), t(hf), t(E), prep, t(lg))
     o_sel = oracle_mod.route_select_triple(lg, hco, hm, hf)
@@ -169,13 +140,11 @@ def test_rows_form_special_tokens(dev, oracle_mod, m16, monkeypatch):
     assert abs(float(r3["loss"][1]) - ol) <= 1e-5 * abs(ol)
 
 
-@pytest.mark.parametrize("dedup", ["1", "0", "2"])
-def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkeypatch):
+def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod):
     """NaN / Inf / huge tokens in every branch go through the exact list (routed ids); a codebook with widely
     mixed norms overflows the resolver queue; D = 64 / 128"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
-    monkeypatch.setenv("DVQ_ROUTED_DEDUP", dedup)
     t = _t(dev)
     B, hc, wc, K, D = 5, 4, 4, 200, 256
     E = synth.codebook_trained(K, D, seed=71)
@@ -206,9 +175,8 @@ def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkey
     r1 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p1, gate=t(g2), mode=_lib.MODE_FILTER)
     r0 = vq_assign_routed_dual(t(hc2), t(hf2), t(E2), p0, gate=t(g2), mode=_lib.MODE_EXACT)
     queued, listed = p1.fallback_count()
-    # 64 shards full, the rest through the exact list (form 2 leaves a quarter of the workgroup slots, hence some
-    # shards, unused)
-    assert queued >= (2048 if dedup == "2" else 4096) and listed > 500, (queued, listed)
+    # 64 shards full, the rest through the exact list
+    assert queued >= 4096 and listed > 500, (queued, listed)
     assert torch.equal(r0["codes"], r1["codes"]) and torch.equal(r0["zq"], r1["zq"])
     assert abs(float(r0["loss"][1]) - float(r1["loss"][1])) <= 1e-6 * abs(float(r0["loss"][1]))
     o_sel = oracle_mod.route_select_dual(g2, hc2, hf2)
@@ -224,10 +192,10 @@ def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod, dedup, monkey
         _check_dual(r3, o_sel, o, 3, oracle_mod=oracle_mod)
 
 
-def test_bench_step_full_size_all_images(dev, oracle_mod, variant):
-    """BASELINE configs[2] exactly as bench.py runs it (entropy gate + routing + masked
-    assign, B = 256, K = 1024), every one of the 256 images against the oracle, both the routed op and the
-    round-1 select + dense assign path"""
+def test_bench_step_full_size_all_images(dev, oracle_mod):
+    """BASELINE configs[2] exactly as bench.py runs it (entropy gate + routing + masked assign, B = 256, K = 1024:
+    2048 workgroups, LDS-staged select, anti-phase lock on), every one of the 256 images against the oracle, both
+    the routed op and the round-1 select + dense assign path; codes-only call as the tokenisation path makes it"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
     from dynamicvectorquantization_amd.router import route_select_dual_entropy
@@ -247,12 +215,13 @@ def test_bench_step_full_size_all_images(dev, oracle_mod, variant):
     assert np.array_equal(r["gate"].cpu().numpy(), og)
     queued, listed = prep.fallback_count()
     assert 0 < queued < 0.2 * B * 1024 and listed == 0, (queued, listed)
-    if variant == 0:
-        sel = route_select_dual_entropy(tent, THR, thc, thf)
-        zq, codes, loss = vq_assign(sel["h_dual"], tE, _CodebookPrep(), sel["codebook_mask"])
-        assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
-        assert torch.equal(zq, r["zq"]) and torch.equal(codes, r["codes"])
-        assert C.loss_close(float(loss[1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    sel = route_select_dual_entropy(tent, THR, thc, thf)
+    zq, codes, loss = vq_assign(sel["h_dual"], tE, _CodebookPrep(), sel["codebook_mask"])
+    assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+    assert torch.equal(zq, r["zq"]) and torch.equal(codes, r["codes"])
+    assert C.loss_close(float(loss[1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    r2 = vq_assign_routed_dual(thc, thf, tE, _CodebookPrep(), entropy=tent, threshold=THR, want_zq=False, want_loss=False)
+    assert torch.equal(r2["codes"], r["codes"]) and torch.equal(r2["indices"], r["indices"])
 
 
 def test_triple_encode_per_rank_size(dev, oracle_mod):
@@ -288,61 +257,84 @@ def test_triple_encode_per_rank_size(dev, oracle_mod):
     assert counts.min() > 0.1 * counts.sum()                      # the router really mixes the three grains
 
 
-@pytest.mark.parametrize("dense_variant", [-1, 2])
-def test_k16384_dispatch_size_vs_oracle_and_golden(dev, oracle_mod, dense_variant):
-    """K = 16384, D = 256, N = 131072 tokens (B = 128, 32x32) through DVQ_MODE_FILTER: the
-    wide (two-blocks-per-wave) pass-1 kernel + 8-slice resolver (dense_variant -1) or a low-register form.
+@pytest.mark.parametrize("fixture", ["vq2_K16384_B128_crc", "vq2_K16384_B512_crc"])
+def test_k16384_dispatch_size_vs_oracle_and_golden(dev, oracle_mod, fixture):
+    """K = 16384, D = 256 through DVQ_MODE_FILTER: the wide (two-blocks-per-wave) pass-1 kernel + 8-slice resolver, at
+    N = 131072 tokens (B = 128, the smallest size that dispatches them) and at BASELINE configs[4]'s full B = 512.
     All images against the golden CRCs captured from the imported reference; 8 whole images against the oracle"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
-    g = C.load("vq2_K16384_B128_crc")
+    g = C.load(fixture)
     z, E, mask = C.vq2_inputs(g)
     B = int(g["B"])
     assert B * 1024 >= 131072 and int(g["K"]) == 16384
-    assert _lib.lib.dvq_set_pass1_variant(dense_variant, -2) == 0
-    try:
-        prep = _CodebookPrep()
-        t = _t(dev)
-        zq, codes, loss = vq_assign(t(z), t(E), prep, t(mask), mode=_lib.MODE_FILTER)
-        queued, listed = prep.fallback_count()
-    finally:
-        _lib.lib.dvq_set_pass1_variant(-1, -2)
+    prep = _CodebookPrep()
+    t = _t(dev)
+    zq, codes, loss = vq_assign(t(z), t(E), prep, t(mask), mode=_lib.MODE_FILTER)
+    queued, listed = prep.fallback_count()
     assert queued > 0                                             # the sliced resolver had work
     codes_np, zq_np = codes.cpu().numpy(), zq.cpu().numpy()
     assert np.array_equal(codes_np[0], g["codes_image0"].astype(np.int64))
     assert np.array_equal(C.per_image_crc(codes_np), g["codes_crc"])
     assert np.array_equal(C.per_image_crc(zq_np), g["zq_crc"])
     assert C.loss_close(float(loss[1]), g["loss"])
-    sel = np.arange(0, B, 16)                                     # 8 whole images
+    sel = np.arange(0, B, B // 8)                                 # 8 whole images
     o = oracle_mod.vq_assign_nchw(z[sel], E, mask[sel])
     assert np.array_equal(codes_np[sel].reshape(len(sel), -1), o["codes"]) and np.array_equal(zq_np[sel], o["zq"])
 
 
-@pytest.mark.parametrize("dense_variant", [0, 1, 2, 3])
-def test_low_register_pass1_dense(dev, oracle_mod, dense_variant):
-    """the low-register pass-1 forms on a dense tensor (DVQ_MODE_FILTER, D = 256): golden cfg-2 fixture,
-    ragged token counts, codes-only, vs the oracle"""
-    from dynamicvectorquantization_amd import synth, _lib
-    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+def test_dual_feature_router_config_end_to_end(dev, oracle_mod):
+    """BASELINE configs[1] (DQ-VAE dual, feature router, F = 16 / 8, B = 64) end to end through the encode glue: fused
+    feature-router gate -> routed op (no quant_conv), and -> select + 1x1 quant_conv kernel -> dense assign (the
+    order of every reference checkpoint, dqvae_dual_feat.py:59-68).  Every image against the oracle GIVEN the
+    router's logits (the gate is a 1e-4-tolerance kernel with its own tests) and, on the conv path, given the kernel's h"""
+    from dynamicvectorquantization_amd import synth, qconv
+    from dynamicvectorquantization_amd.encode import encode_dual
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter
+    B, K, D = 64, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hco = synth.z_tokens(E, B, 32, 32, 3002), synth.z_tokens(E, B, 16, 16, 3012)
     t = _t(dev)
-    assert _lib.lib.dvq_set_pass1_variant(dense_variant, -2) == 0
-    try:
-        g = C.load("vq2_cfg2_B4")
-        z, E, mask = C.vq2_inputs(g)
-        zq, codes, loss = vq_assign(t(z), t(E), _CodebookPrep(), t(mask))
-        assert np.array_equal(codes.cpu().numpy(), g["codes"].astype(np.int64))
-        assert np.array_equal(C.per_image_crc(zq.cpu().numpy()), g["zq_crc"]) and C.loss_close(float(loss[1]), g["loss"])
-        for (B, H, W, K) in ((1, 1, 33, 40), (3, 7, 11, 1000), (2, 16, 16, 2048)):
-            E2 = synth.codebook_trained(K, 256, seed=900 + K)
-            z2 = synth.z_tokens(E2, B, H, W, 910 + K)
-            o = oracle_mod.vq_assign_nchw(z2, E2, None)
-            zq2, c2, l2 = vq_assign(t(z2), t(E2), _CodebookPrep(), None)
-            assert np.array_equal(c2.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq2.cpu().numpy(), o["zq"])
-            assert C.loss_close(float(l2[1]), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
-            _, c3, _ = vq_assign(t(z2), t(E2), _CodebookPrep(), None, want_zq=False, want_loss=False)
-            assert torch.equal(c2, c3)
-    finally:
-        _lib.lib.dvq_set_pass1_variant(-1, -2)
+    router = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu")
+    sd = {k: torch.from_numpy(synth.seeded_param(6002, i, k, tuple(v.shape)))
+          for i, (k, v) in enumerate(router.state_dict().items())}
+    router.load_state_dict(sd)
+    router = router.to(dev).eval()
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    thf, thc = t(hf), t(hco)
+    with torch.no_grad():
+        quant, emb_loss, info, grain, gate = encode_dual(router, vq, thf, thc)
+    assert tuple(gate.shape) == (B, 2, 16, 16)
+    lg = gate.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    o_sel = oracle_mod.route_select_dual(lg, hco, hf)
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+    assert np.array_equal(grain.cpu().numpy(), o_sel["indices"])
+    assert np.array_equal(info[2].cpu().numpy().reshape(B, -1), o["codes"])
+    assert np.array_equal(quant.cpu().numpy(), o["zq"])
+    assert C.loss_close(float(emb_loss), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    counts = np.bincount(o_sel["indices"].reshape(-1), minlength=2)
+    assert counts.min() > 0.1 * counts.sum()                      # the router mixes the grains
+    # the model's order: select -> quant_conv -> quantizer
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(synth.normal(6012, (D, D, 1, 1), 0.0, 1.0 / 16.0)))
+        conv.bias.copy_(t(synth.normal(6013, (D,), 0.0, 0.1)))
+        q2, l2, info2, grain2, gate2 = encode_dual(router, vq, thf, thc, quant_conv=conv)
+        sel = qconv.quant_conv_select(conv, thc, thf, gate=gate2.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(grain2, grain) and torch.equal(gate2, gate)
+    h = sel["h"].cpu().numpy()                                    # the kernel's h: codes / z_q are exact GIVEN it
+    o2 = oracle_mod.vq_assign_nchw(h, E, o_sel["codebook_mask"])
+    assert np.array_equal(info2[2].cpu().numpy().reshape(B, -1), o2["codes"])
+    assert np.array_equal(q2.cpu().numpy(), o2["zq"])
+    assert C.loss_close(float(l2), oracle_mod.vq_loss(o2["sqerr"], o2["numel"], 0.25))
+    # and h itself against the conv in float64 (contract 1e-5 * sum |w||x|)
+    w64 = conv.weight.double().cpu().numpy()[:, :, 0, 0]
+    x64 = o_sel["h_dual"].astype(np.float64)[:4]
+    ref = np.einsum("ok,bkhw->bohw", w64, x64) + conv.bias.double().cpu().numpy()[None, :, None, None]
+    bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64))
+    assert np.all(np.abs(h[:4] - ref) <= 1e-5 * bound + 1e-30)
 
 
 def test_routed_op_is_graph_capturable(dev):

@@ -46,14 +46,7 @@ def run(ncases=150, seed=12345, verbose=True):
       pe, pf = _CodebookPrep(), _CodebookPrep()
       zq0, c0, l0 = vq_assign(zt_, Et_, pe, mt_, mode=_lib.MODE_EXACT)
       fmode = _lib.MODE_FILTER_WIDE if (D == 256 and case % 3 == 0) else _lib.MODE_FILTER     # every third D=256 case: wide pass 1
-      # the other D = 256 cases rotate through the legacy pass 1 (-1) and the low-register forms 0..3
-      _lib.lib.dvq_set_pass1_variant((case // 3) % 5 - 1 if D == 256 else -1, -2)
-      os.environ["DVQ_MFMA16"] = str(case & 1)              # legacy pass 1: 32x32x16 / 16x16x32 code loop alternate
-      try:
-          zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=fmode)
-      finally:
-          _lib.lib.dvq_set_pass1_variant(-1, -2)
-          os.environ.pop("DVQ_MFMA16", None)
+      zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=fmode)
       torch.cuda.synchronize()
       okc = torch.equal(c0, c1)
       okz = bool(((zq0 == zq1) | (torch.isnan(zq0) & torch.isnan(zq1))).all())

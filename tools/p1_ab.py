@@ -1,0 +1,146 @@
+"""A/B of pass 1 (BASELINE configs[2] size: B = 256, 32x32x256, K = 1024) on the TUNING build of the library:
+
+    DVQ_LIBRARY=dynamicvectorquantization_amd/csrc/libdvq_tuning.so python tools/p1_ab.py [out.json]
+
+For the dense kernel and the select-fused kernel (LDS-staged and per-lane forms), with the per-CU anti-phase lock off
+and on, on random and on all-zero latents: time per launch (HIP events, back-to-back launches after a 2-s spin-up on the
+same data), socket power meanwhile (hwmon sysfs), and from the in-kernel stamps of the last launch (s_memtime /
+s_memrealtime, MI355X guide DVFS item 6): the shader clock inside the code loop, the duration of prologue / lock wait /
+code loop / epilogue per workgroup, and a census of the lock words (CU slots) -- how many there are, how many workgroups
+each served, and how many pairs of code loops on one slot overlapped in time (anti-phase on: must be 0).
+Every variant's codes / z_q are compared with the first one's (same bits required)."""
+import glob, json, os, sys, threading, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicvectorquantization_amd import synth, _lib
+from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
+
+assert hasattr(_lib.lib, "dvq_tuning_set"), "run with DVQ_LIBRARY=<...>/libdvq_tuning.so (make -C csrc tuning)"
+B, K = int(os.environ.get("AB_B", "256")), 1024
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(a).to(dev)
+THR = 1.6777750253677368
+En = synth.codebook_trained(K, 256)
+b0 = 32
+tile = lambda x: torch.cat([torch.roll(x, 5 * k, -1) for k in range((B + b0 - 1) // b0)], 0)[:B].contiguous()
+hf, hc, ent, E = tile(t(synth.z_tokens(En, b0, 32, 32, 2903))), tile(t(synth.z_tokens(En, b0, 16, 16, 2913))), tile(t(synth.entropy_map(5903, b0, 16, 16))), t(En)
+hf0, hc0 = torch.zeros_like(hf), torch.zeros_like(hc)
+zq = torch.empty_like(hf); codes = torch.empty((B, 32, 32), dtype=torch.int64, device=dev); loss = torch.empty(2, device=dev)
+grain = torch.empty((B, 16, 16), dtype=torch.int64, device=dev); cmask = torch.empty((B, 1, 32, 32), device=dev)
+gate = torch.empty((B, 16, 16, 2), dtype=torch.int64, device=dev)
+G = B * 1024 // 128
+stamps = torch.zeros((G, 8), dtype=torch.int64, device=dev)
+prep = _CodebookPrep()
+
+
+def tune(**kw):
+    for k, v in kw.items():
+        assert _lib.lib.dvq_tuning_set(k.encode(), int(v)) == 0, k
+
+
+def launch(kind, data, mode, want_zq=True):
+    f, c = (hf, hc) if data == "random" else (hf0, hc0)
+    if kind == "dense":
+        vq_assign(f, E, prep, None, mode=mode, out=(zq if want_zq else None, codes, loss if mode == _lib.MODE_FILTER else None))
+    else:
+        vq_assign_routed_dual(c, f, E, prep, entropy=ent, threshold=THR, mode=mode,
+                              out=(zq if want_zq else None, codes, loss if mode == _lib.MODE_FILTER else None, grain, cmask, gate))
+
+
+hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+def read_power():
+    for h in hw:
+        for f in ("power1_average", "power1_input"):
+            try:
+                return float(open(os.path.join(h, f)).read()) * 1e-6
+            except Exception:
+                pass
+    return None
+
+
+def measure(fn, spin_s=2.0, n=200):
+    pw, stop = [], [False]
+    def sampler():
+        while not stop[0]:
+            p = read_power()
+            if p is not None:
+                pw.append(p)
+            time.sleep(0.05)
+    th = threading.Thread(target=sampler); th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < spin_s:
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    stop[0] = True; th.join()
+    return s.elapsed_time(e) / n * 1e3, (float(np.mean(pw[len(pw) // 3:])) if pw else None)
+
+
+def stamp_stats():
+    st = stamps.cpu().numpy().astype(np.int64)
+    slot, r_in, r_pro, r_l0, c_l0, r_l1, c_l1, r_out = (st[:, i] for i in range(8))
+    ok = (r_l1 > r_l0) & (r_out >= r_l1)
+    us = lambda d: float(np.median(d[ok])) / 100.0            # 100 MHz ticks -> us
+    clk = (c_l1 - c_l0)[ok] / np.maximum(1, (r_l1 - r_l0)[ok]) * 100.0   # MHz
+    uniq, cnt = np.unique(slot[ok], return_counts=True)
+    overlaps = 0
+    for u in uniq:
+        idx = np.where(ok & (slot == u))[0]
+        a, b = r_l0[idx], r_l1[idx]
+        o = np.argsort(a)
+        a, b = a[o], b[o]
+        overlaps += int(np.sum(a[1:] < np.maximum.accumulate(b)[:-1]))
+    return {"wg_stamped": int(ok.sum()), "clock_MHz_in_loop_median": float(np.median(clk)), "clock_MHz_p10_p90": [float(np.percentile(clk, 10)), float(np.percentile(clk, 90))],
+            "loop_cycles_median": float(np.median((c_l1 - c_l0)[ok])),
+            "prologue_us": us(r_pro - r_in), "lock_wait_us": us(r_l0 - r_pro), "loop_us": us(r_l1 - r_l0), "epilogue_us": us(r_out - r_l1),
+            "kernel_span_us": float(r_out[ok].max() - r_in[ok].min()) / 100.0,
+            "cu_slots": int(len(uniq)), "wg_per_slot_min_max": [int(cnt.min()), int(cnt.max())], "loop_overlaps_on_one_slot": overlaps}
+
+
+res = {"B": B, "K": K, "variants": []}
+ref = {}
+variants = [("dense", 0, 1), ("dense", 1, 1), ("routed", 0, 1), ("routed", 1, 1), ("routed", 0, 0), ("routed", 1, 0)]
+for rep in range(int(os.environ.get("AB_REPS", "2"))):
+    for kind, anti, staged in variants:
+        for data in ("random", "zeros"):
+            tune(antiphase=anti, sel_staged=staged)
+            _lib.lib.dvq_tuning_buffers(0, 0)
+            us_p1, w_p1 = measure(lambda: launch(kind, data, _lib.MODE_FILTER_PASS1))
+            row = {"kind": kind, "antiphase": anti, "sel_staged": staged, "data": data, "rep": rep, "pass1_us": round(us_p1, 1), "pass1_socket_W": w_p1}
+            if data == "random":
+                us_c, _ = measure(lambda: launch(kind, data, _lib.MODE_FILTER_PASS1, want_zq=False), spin_s=0.5)
+                us_op, w_op = measure(lambda: launch(kind, data, _lib.MODE_FILTER), spin_s=0.5)
+                row.update(pass1_codes_only_us=round(us_c, 1), whole_op_us=round(us_op, 1))
+            # stamps of one launch in steady state (back-to-back launches before it)
+            stamps.zero_()
+            for _ in range(30):
+                launch(kind, data, _lib.MODE_FILTER_PASS1)
+            _lib.lib.dvq_tuning_buffers(stamps.data_ptr(), 0)
+            launch(kind, data, _lib.MODE_FILTER_PASS1)
+            torch.cuda.synchronize()
+            _lib.lib.dvq_tuning_buffers(0, 0)
+            row["stamps"] = stamp_stats()
+            if data == "random":
+                launch(kind, data, _lib.MODE_FILTER)
+                torch.cuda.synchronize()
+                key = kind
+                cur = (codes.clone(), zq.clone(), float(loss[1]))
+                if key not in ref:
+                    ref[key] = cur
+                row["same_bits_as_first_variant"] = bool(torch.equal(cur[0], ref[key][0]) and torch.equal(cur[1], ref[key][1]))
+            res["variants"].append(row)
+            print(json.dumps(row), flush=True)
+# dense == routed on the routed batch is not expected (different inputs); exact mode agrees with the filter
+tune(antiphase=1, sel_staged=1)
+launch("routed", "random", _lib.MODE_EXACT)
+torch.cuda.synchronize()
+res["routed_exact_equals_filter"] = bool(torch.equal(codes, ref["routed"][0]) and torch.equal(zq, ref["routed"][1]))
+print(json.dumps({"routed_exact_equals_filter": res["routed_exact_equals_filter"]}))
+if len(sys.argv) > 1:
+    json.dump(res, open(sys.argv[1], "w"), indent=1)
