@@ -10,10 +10,14 @@ One "step" = one pass of the hot path over one batch that is already resident in
                    images is split over the ranks (128 per GPU at N = 8): fused feature-router gate +
                    triple routing + assignment.
 
-The 1x1 quant_conv between select and VQ is a vendor GEMM outside the path and
-is not run.  With N > 1 ranks the step ends by launching the single packed RCCL all-gather of the emitted
-code / grain indices and the loss pair; it runs asynchronously under the next step's kernels and every
-exchange is waited for and unpacked inside the timed region.
+--path routed (default) is the hot path north_star names: gate + routing + assign as ONE op (no quant_conv between
+select and quantizer); --path model adds the stage-1 models' 1x1 quant_conv in the reference's order (select ->
+quant_conv -> quantizer, dqvae_dual_entropy.py:124-134: select + conv as one kernel, then the dense assign);
+--path tokens is the codes-only tokenisation stage 2 consumes (routed assign without z_q + permuter, no host sync);
+--path select is round 1's two-kernel path.  Every stream slot owns its INPUTS as well as its outputs (different seeds:
+no step re-reads bytes the previous step read).  With N > 1 ranks the step ends by launching the single packed RCCL
+all-gather of the emitted code / grain indices and the loss pair; it runs asynchronously under the next step's kernels
+and every exchange is waited for and unpacked inside the timed region.
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line (rank 0).
 `--gpus N` with no RANK in the environment makes this process a launcher: it starts N fresh rank
@@ -47,10 +51,14 @@ def parse():
                     help="weak: images per GPU (default 256); strong: GLOBAL batch (default 1024)")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
-    ap.add_argument("--path", choices=["routed", "select"], default="routed",
+    ap.add_argument("--path", choices=["routed", "select", "model", "tokens"], default="routed",
                     help="routed: ONE assign op straight from the encoder branches (the router select is fused into "
                          "pass 1, h_dual is never written); select: route-select kernel writing h_dual, then the "
-                         "dense assign (round-1 path)")
+                         "dense assign (round-1 path); model: select + the models' 1x1 quant_conv as one kernel, then the "
+                         "dense assign (what a reference checkpoint runs); tokens: routed assign, codes only, + permuter")
+    ap.add_argument("--model-chunks", type=int, default=1,
+                    help="--path model: run conv + assign over this many slices of the batch, so that a slice's h "
+                         "(268 MB / chunks) is still in the Infinity Cache when the assign reads it")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
@@ -102,6 +110,16 @@ def launch_ranks(a):
         return 1
     print(line, flush=True)
     return 0
+
+
+def source_sha16():
+    """hash of what decides the timed kernels: bench.py + the csrc sources (rocprof summaries under profiles/ carry it)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "dynamicvectorquantization_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cpus():
@@ -222,7 +240,9 @@ class Slot:
 
 
 class WeakDual:
-    """BASELINE configs[2]: entropy router + dual routing + VectorQuantize2 assign, B images per rank"""
+    """BASELINE configs[2]: entropy router + dual routing + VectorQuantize2 assign, B images per rank.
+    paths: routed (one op) | select (select kernel + dense assign) | model (select + quant_conv kernel, dense assign) |
+    tokens (routed assign without z_q + permuter)"""
     name = "dual"
 
     def __init__(self, a, rank, world, dev):
@@ -237,100 +257,213 @@ class WeakDual:
         self.K, self.D, self.H, self.W = K, D, H, W
         self.mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
         self.E_np = synth.codebook_trained(K, D)
-        off = rank * B
-        b0 = min(B, 256)
-        t = lambda x: torch.from_numpy(x).to(dev)
-        self.h_fine = tile_images(t(synth.z_tokens(self.E_np, b0, H, W, 2903, image_offset=off)), B)
-        self.h_coarse = tile_images(t(synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913, image_offset=off)), B)
-        self.ent = tile_images(t(synth.entropy_map(5903, b0, H // 2, W // 2, image_offset=off)), B)
-        self.E = t(self.E_np)
+        self.E = torch.from_numpy(self.E_np).to(dev)
         self.prep = _CodebookPrep()
-        # preallocated outputs, one set per stream slot: the step allocates nothing
-        self.slots = [self.new_slot() for _ in range(a.streams)]
+        self.rank = rank
+        self.conv = None
+        if a.path == "model":
+            self.conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+            with torch.no_grad():
+                self.conv.weight.copy_(torch.from_numpy(synth.normal(6012, (D, D, 1, 1), 0.0, 1.0 / 16.0)).to(dev))
+                self.conv.bias.copy_(torch.from_numpy(synth.normal(6013, (D,), 0.0, 0.1)).to(dev))
+        self.permuter = None
+        if a.path == "tokens":
+            from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+            self.permuter = DualGrainSeperatePermuter(coarse_hw=H // 2, fine_hw=H, content_pad_code=K, content_eos_code=K + 1)
+        # one set of inputs AND outputs per stream slot, preallocated: the step allocates nothing and no step reads the
+        # bytes the previous step read
+        self.slots = [self.new_slot(k) for k in range(a.streams)]
 
-    def new_slot(self):
+    def inputs_np(self, k):
+        """slot k's inputs on the host (seeds differ per slot; images b0.. of a batch are the first b0 rolled)"""
+        import numpy as np
+
+        from dynamicvectorquantization_amd import synth
+        B, H, W = self.B, self.H, self.W
+        off = self.rank * B
+        b0 = min(B, 128)
+
+        def tile(base):
+            if B <= b0:
+                return base[:B]
+            parts = [np.roll(base, 5 * j, axis=-1) for j in range((B + b0 - 1) // b0)]
+            return np.ascontiguousarray(np.concatenate(parts, 0)[:B])
+        hf = tile(synth.z_tokens(self.E_np, b0, H, W, 2903 + 100 * k, image_offset=off))
+        hc = tile(synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913 + 100 * k, image_offset=off))
+        ent = tile(synth.entropy_map(5903 + 100 * k, b0, H // 2, W // 2, image_offset=off))
+        return hf, hc, ent
+
+    def new_slot(self, k=0):
         import torch
         o = Slot()
-        B, H, W, dev = self.B, self.H, self.W, self.dev
-        o.h_dual = torch.empty_like(self.h_fine) if self.a.path == "select" else None
+        B, H, W, dev, K = self.B, self.H, self.W, self.dev, self.K
+        o.k = k
+        hf, hc, ent = self.inputs_np(k)
+        o.h_fine, o.h_coarse, o.ent = (torch.from_numpy(x).to(dev) for x in (hf, hc, ent))
+        o.h_dual = torch.empty_like(o.h_fine) if self.a.path == "select" else None
         o.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
         o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        o.zq = torch.empty_like(self.h_fine)
+        o.zq = torch.empty_like(o.h_fine) if self.a.path != "tokens" else None
         o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         o.loss = torch.empty(2, dtype=torch.float32, device=dev)
         o.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
+        if self.a.path == "model":
+            nch = max(1, self.a.model_chunks)
+            assert B % nch == 0, "--model-chunks must divide the batch"
+            o.h = torch.empty((B // nch,) + tuple(o.h_fine.shape[1:]), dtype=torch.float32, device=dev)   # reused by every chunk
+            o.h_full = torch.empty_like(o.h_fine) if nch == 1 else None
+            o.loss_chunks = torch.empty((nch, 2), dtype=torch.float32, device=dev)
+        if self.a.path == "tokens":
+            Lc, Lf = self.permuter.max_lengths()
+            o.seq = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
+                    [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]
         return o
 
     def describe(self):
-        return ("BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, entropy gate + "
-                "dual routing + VectorQuantize2 assign (quant_conv not in the path)" % (self.B, self.K))
+        tail = {"routed": "entropy gate + dual routing + VectorQuantize2 assign as one op (quant_conv not in the path)",
+                "select": "entropy gate + route-select kernel + VectorQuantize2 assign (quant_conv not in the path)",
+                "model": "entropy gate + dual routing + 1x1 quant_conv (one kernel) + VectorQuantize2 assign: the order a "
+                         "reference checkpoint runs, %d batch slice(s)" % max(1, self.a.model_chunks),
+                "tokens": "entropy gate + dual routing + VectorQuantize2 assign (codes only) + DualGrainSeperatePermuter: "
+                          "the tokenisation stage 2 consumes"}[self.a.path]
+        return "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, %s" % (self.B, self.K, tail)
 
     def step(self, o, ev=None):
+        from dynamicvectorquantization_amd import qconv
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
         from dynamicvectorquantization_amd.router import route_select_dual_entropy
-        if self.a.path == "select":
-            route_select_dual_entropy(self.ent, THR_R05, self.h_coarse, self.h_fine,
-                                      out=(o.h_dual, o.grain, o.cmask, o.gate))
-            if ev:
-                ev[0].record()
-            vq_assign(o.h_dual, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode,
-                      out=(o.zq, o.codes, o.loss))
+        path = self.a.path
+        if ev:
+            ev[0].record()
+        if path == "select":
+            route_select_dual_entropy(o.ent, THR_R05, o.h_coarse, o.h_fine, out=(o.h_dual, o.grain, o.cmask, o.gate))
+            vq_assign(o.h_dual, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss))
+        elif path == "model":
+            nch = max(1, self.a.model_chunks)
+            bs = self.B // nch
+            for c in range(nch):
+                sl = slice(c * bs, (c + 1) * bs)
+                h = o.h_full if nch == 1 else o.h
+                qconv.quant_conv_select(self.conv, o.h_coarse[sl], o.h_fine[sl], entropy=o.ent[sl], threshold=THR_R05,
+                                        out=(h, o.grain[sl], o.cmask[sl], o.gate[sl]))
+                vq_assign(h, self.E, self.prep, o.cmask[sl], beta=0.25, mode=self.mode,
+                          out=(o.zq[sl], o.codes[sl], o.loss_chunks[c]))
+        elif path == "tokens":
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05, beta=0.25,
+                                  mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate))
+            self.permuter(o.codes, o.grain, max_len=self.permuter.max_lengths(), out=o.seq)
         else:
-            if ev:
-                ev[0].record()
-            vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep, entropy=self.ent, threshold=THR_R05,
-                                  beta=0.25, mode=self.mode,
-                                  out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate))
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05,
+                                  beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate))
         if ev:
             ev[1].record()
-        return o.codes, o.grain, o.loss
+        return o.codes, o.grain, (o.loss if path != "model" else o.loss_chunks[0])
 
     def dominant(self, o, ev):
         """the dominant kernel alone (pass 1 of the assign), same launch geometry"""
         from dynamicvectorquantization_amd import _lib
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
+        path = self.a.path
         if self.a.mode == "exact":
             ev[0].record()
-            vq_assign(o.h_dual if o.h_dual is not None else self.h_fine, self.E, self.prep_dom, o.cmask,
+            vq_assign(o.h_dual if o.h_dual is not None else o.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT, out=(o.zq, o.codes, o.loss))
             ev[1].record()
-        elif self.a.path == "select":
+        elif path in ("select", "model"):
+            src = o.h_dual if path == "select" else (o.h_full if o.h_full is not None else o.h)
+            n = src.shape[0]
             ev[0].record()
-            vq_assign(o.h_dual, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                      out=(o.zq, o.codes, None))
+            vq_assign(src, self.E, self.prep_dom, o.cmask[:n], beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                      out=(o.zq[:n], o.codes[:n], None))
             ev[1].record()
         else:
             ev[0].record()
-            vq_assign_routed_dual(self.h_coarse, self.h_fine, self.E, self.prep_dom, entropy=self.ent,
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                                   out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate))
             ev[1].record()
 
+    def dominant_tokens(self):
+        """tokens one launch of `dominant` processes"""
+        if self.a.path == "model" and self.a.model_chunks > 1:
+            return self.B // self.a.model_chunks * self.H * self.W
+        return self.B * self.H * self.W
+
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256, 0, true>" if self.a.path == "select" else "vq_assign_filter_kernel<256, 1, true> (router select fused in)"
+        if self.a.path in ("select", "model"):
+            return "vq_assign_filter_kernel<256, 0> (dense pass 1)"
+        return "vq_assign_filter_kernel<256, 2> (pass 1, router select fused in, coarse branch staged through LDS)"
 
     def parity(self, slot):
-        """the step's outputs, still in HBM, against the oracle on ALL images of this rank"""
+        """the step's outputs, still in HBM, against the oracle on ALL images of this rank (the slot's own inputs)"""
         import numpy as np
 
         from oracle import oracle
         oracle.build()
-        ent, hc, hf = (x.cpu().numpy() for x in (self.ent, self.h_coarse, self.h_fine))
+        hf, hc, ent = self.inputs_np(slot.k)
+        assert np.array_equal(hf, slot.h_fine.cpu().numpy())
         t0 = time.perf_counter()
         og = oracle.entropy_gate(ent, THR_R05)
         osel = oracle.route_select_dual(og, hc, hf)
-        o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
+        res = {"images_checked": int(self.B),
+               "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
+               "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
+               "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum())}
+        if self.a.path == "model":
+            # h is a tolerance-level quantity (1e-5 * sum |w||x| vs the conv in float64, checked on 8 images); codes, z_q and
+            # the loss are exact GIVEN the kernel's h -- recomputed here slice by slice when the batch runs in slices
+            import torch
+
+            from dynamicvectorquantization_amd import qconv
+            nch = max(1, self.a.model_chunks)
+            bs = self.B // nch
+            hs = []
+            for c in range(nch):
+                sl = slice(c * bs, (c + 1) * bs)
+                hs.append(qconv.quant_conv_select(self.conv, slot.h_coarse[sl], slot.h_fine[sl], entropy=slot.ent[sl],
+                                                  threshold=THR_R05)["h"].cpu().numpy())
+            h = np.concatenate(hs, 0)
+            w64 = self.conv.weight.detach().double().cpu().numpy()[:, :, 0, 0]
+            x64 = osel["h_dual"][:8].astype(np.float64)
+            ref = np.einsum("ok,bkhw->bohw", w64, x64) + self.conv.bias.detach().double().cpu().numpy()[None, :, None, None]
+            bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64))
+            res["h_max_err_over_bound"] = float((np.abs(h[:8] - ref) / (1e-5 * bound + 1e-30)).max())
+            o = oracle.vq_assign_nchw(h, self.E_np, osel["codebook_mask"])
+            ref_fp64 = oracle.vq_assign_nchw(ref.astype(np.float32), self.E_np, osel["codebook_mask"][:8])
+            res["codes_match_rate_vs_fp64_conv"] = float((slot.codes.cpu().numpy()[:8].reshape(8, -1) == ref_fp64["codes"]).mean())
+            lsum, lerr = 0.0, 0.0
+            for c in range(nch):
+                oc = oracle.vq_assign_nchw(h[c * bs:(c + 1) * bs], self.E_np, osel["codebook_mask"][c * bs:(c + 1) * bs])
+                ol = float(oracle.vq_loss(oc["sqerr"], oc["numel"], 0.25))
+                lerr = max(lerr, abs(float(slot.loss_chunks[c, 1]) - ol) / abs(ol))
+            res["loss_rel_err"] = lerr
+        else:
+            o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
         self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
         codes = slot.codes.cpu().numpy().reshape(self.B, -1)
-        ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
-        return {"images_checked": int(self.B), "code_mismatches": int((codes != o["codes"]).sum()),
-                "zq_mismatches": int((slot.zq.cpu().numpy() != o["zq"]).sum()),
-                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
-                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
-                "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum()),
-                "loss_rel_err": abs(float(slot.loss[1]) - ol) / abs(ol)}
+        res["code_mismatches"] = int((codes != o["codes"]).sum())
+        if slot.zq is not None:
+            res["zq_mismatches"] = int((slot.zq.cpu().numpy() != o["zq"]).sum())
+        if self.a.path == "tokens":
+            from oracle import permuter as operm
+            ref = operm.forward(o["codes"].reshape(self.B, self.H, self.W), osel["indices"], coarse_hw=self.H // 2,
+                                fine_hw=self.H, content_pad=self.K, content_eos=self.K + 1)
+            names = ["coarse_content", "coarse_position", "coarse_segment", "fine_content", "fine_position", "fine_segment"]
+            pads = {"coarse_content": self.K, "fine_content": self.K, "coarse_position": 256, "fine_position": 1024,
+                    "coarse_segment": 0, "fine_segment": 1}
+            bad = 0
+            for nme, tns in zip(names, slot.seq):
+                got, want = tns.cpu().numpy(), ref[nme]
+                L = want.shape[1]
+                bad += int((got[:, :L] != want).sum()) + int((got[:, L:] != pads[nme]).sum())   # beyond the batch maximum: PAD
+            res["token_stream_mismatches"] = bad
+            res["loss_rel_err"] = 0.0
+        elif self.a.path != "model":
+            ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
+            res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol)
+        return res
 
 
 class StrongTriple:
@@ -353,34 +486,48 @@ class StrongTriple:
         self.K, self.D, self.H, self.W = K, D, H, W
         self.mode = _lib.MODE_EXACT if a.mode == "exact" else _lib.MODE_FILTER
         self.E_np = synth.codebook_trained(K, D)
-        b0 = min(B, 128)
-        t = lambda x: torch.from_numpy(x).to(dev)
-        self.h_fine = tile_images(t(synth.z_tokens(self.E_np, b0, 32, 32, 2104, image_offset=s)), B)
-        self.h_median = tile_images(t(synth.z_tokens(self.E_np, b0, 16, 16, 2114, image_offset=s)), B)
-        self.h_coarse = tile_images(t(synth.z_tokens(self.E_np, b0, 8, 8, 2124, image_offset=s)), B)
-        self.E = t(self.E_np)
+        self.s0 = s
+        self.E = torch.from_numpy(self.E_np).to(dev)
         self.router = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu")
         sd = {k: torch.from_numpy(synth.seeded_param(6104, i, k, tuple(v.shape)))
               for i, (k, v) in enumerate(self.router.state_dict().items())}
         self.router.load_state_dict(sd)
         self.router = self.router.to(dev).eval()
         self.prep = _CodebookPrep()
-        self.slots = [self.new_slot() for _ in range(a.streams)]
+        self.slots = [self.new_slot(k) for k in range(a.streams)]
 
-    def new_slot(self):
+    def inputs_np(self, k):
+        import numpy as np
+
+        from dynamicvectorquantization_amd import synth
+        B = self.B
+        b0 = min(B, 128)
+
+        def tile(base):
+            if B <= b0:
+                return base[:B]
+            return np.ascontiguousarray(np.concatenate([np.roll(base, 5 * j, axis=-1) for j in range((B + b0 - 1) // b0)], 0)[:B])
+        return (tile(synth.z_tokens(self.E_np, b0, 32, 32, 2104 + 100 * k, image_offset=self.s0)),
+                tile(synth.z_tokens(self.E_np, b0, 16, 16, 2114 + 100 * k, image_offset=self.s0)),
+                tile(synth.z_tokens(self.E_np, b0, 8, 8, 2124 + 100 * k, image_offset=self.s0)))
+
+    def new_slot(self, k=0):
         import torch
         o = Slot()
         B, H, W, dev = self.B, self.H, self.W, self.dev
-        o.h_triple = torch.empty_like(self.h_fine) if self.a.path == "select" else None
+        o.k = k
+        o.h_fine, o.h_median, o.h_coarse = (torch.from_numpy(x).to(dev) for x in self.inputs_np(k))
+        o.h_triple = torch.empty_like(o.h_fine) if self.a.path == "select" else None
         o.grain = torch.empty((B, 8, 8), dtype=torch.int64, device=dev)
         o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        o.zq = torch.empty_like(self.h_fine)
+        o.zq = torch.empty_like(o.h_fine)
         o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         o.loss = torch.empty(2, dtype=torch.float32, device=dev)
         o.logits = None
         return o
 
     def describe(self):
+        assert self.a.path in ("routed", "select"), "--scaling strong runs --path routed or select"
         return ("BASELINE configs[3]: triple granularity F=32/16/8, global B=%d split image-parallel (%d on this "
                 "rank), 32x32x256 latents, K=%d, fused feature-router gate + triple routing + VectorQuantize2 assign "
                 "(quant_conv not in the path)" % (self.Bglobal, self.B, self.K))
@@ -391,16 +538,16 @@ class StrongTriple:
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
         from dynamicvectorquantization_amd.router import route_select_triple
         with torch.no_grad():
-            o.logits = self.router(h_fine=self.h_fine, h_median=self.h_median, h_coarse=self.h_coarse)
+            o.logits = self.router(h_fine=o.h_fine, h_median=o.h_median, h_coarse=o.h_coarse)
             if ev:
                 ev[0].record()
             if self.a.path == "select":
-                route_select_triple(o.logits, self.h_coarse, self.h_median, self.h_fine,
+                route_select_triple(o.logits, o.h_coarse, o.h_median, o.h_fine,
                                     out=(o.h_triple, o.grain, o.cmask))
                 vq_assign(o.h_triple, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode,
                           out=(o.zq, o.codes, o.loss))
             else:
-                vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep, o.logits,
+                vq_assign_routed_triple(o.h_coarse, o.h_median, o.h_fine, self.E, self.prep, o.logits,
                                         beta=0.25, mode=self.mode,
                                         out=(o.zq, o.codes, o.loss, o.grain, o.cmask))
         if ev:
@@ -412,19 +559,23 @@ class StrongTriple:
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
         ev[0].record()
         if self.a.path == "select" or self.a.mode == "exact":
-            vq_assign(o.h_triple if o.h_triple is not None else self.h_fine, self.E, self.prep_dom, o.cmask,
+            vq_assign(o.h_triple if o.h_triple is not None else o.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT if self.a.mode == "exact" else _lib.MODE_FILTER_PASS1,
                       out=(o.zq, o.codes, o.loss if self.a.mode == "exact" else None))
         else:
-            vq_assign_routed_triple(self.h_coarse, self.h_median, self.h_fine, self.E, self.prep_dom, o.logits,
+            vq_assign_routed_triple(o.h_coarse, o.h_median, o.h_fine, self.E, self.prep_dom, o.logits,
                                     beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                                     out=(o.zq, o.codes, None, o.grain, o.cmask))
         ev[1].record()
 
+    def dominant_tokens(self):
+        return self.B * self.H * self.W
+
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256, 0, true>" if self.a.path == "select" else "vq_assign_filter_kernel<256, 1, true> (router select fused in)"
+        return "vq_assign_filter_kernel<256, 0> (dense pass 1)" if self.a.path == "select" else \
+            "vq_assign_filter_kernel<256, 2> (pass 1, router select fused in, median / coarse branches staged through LDS)"
 
     def parity(self, slot):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
@@ -432,7 +583,7 @@ class StrongTriple:
         from oracle import oracle
         oracle.build()
         lg = slot.logits.cpu().numpy()
-        hc, hm, hf = (x.cpu().numpy() for x in (self.h_coarse, self.h_median, self.h_fine))
+        hf, hm, hc = self.inputs_np(slot.k)
         osel = oracle.route_select_triple(lg, hc, hm, hf)
         o = oracle.vq_assign_nchw(osel["h_triple"], self.E_np, osel["codebook_mask"])
         codes = slot.codes.cpu().numpy().reshape(self.B, -1)
@@ -538,9 +689,15 @@ def run_rank(a):
             pass
         last = wl.slots[(nstep[0] - 1) % S]
         parity = wl.parity(last)
-        # the other stream slots ran the same batch: their outputs must be the same bits
-        parity["slot_mismatches"] = int(sum(1 for o in wl.slots if o is not last and nstep[0] > S and not (
-            torch.equal(o.codes, last.codes) and torch.equal(o.zq, last.zq) and torch.equal(o.grain, last.grain))))
+        # every stream slot ran its OWN batch (own seeds): each against the oracle on all of its images
+        nbad = 0
+        for o in wl.slots:
+            if o is last or nstep[0] <= S:
+                continue
+            po = wl.parity(o)
+            nbad += int(any(v for k_, v in po.items() if k_.endswith("_mismatches")) or po["loss_rel_err"] > 1e-5)
+            parity["images_checked"] += po["images_checked"]
+        parity["slot_mismatches"] = nbad
         if world > 1:
             keys = sorted(k for k in parity if k != "loss_rel_err")
             tot = torch.tensor([parity[k] for k in keys], dtype=torch.int64, device=dev)
@@ -555,7 +712,16 @@ def run_rank(a):
                 parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], last.codes) and
                                              torch.equal(g_grain[s0:s0 + B], last.grain))
 
-    # the assign op (all its kernels) and, below, its dominant kernel alone: HIP events on the launch stream, serial,
+    # the same K steps strictly serial (one stream, one slot's buffers): what a caller without stream slots gets
+    serial_ms = None
+    if S > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.step(wl.slots[0])
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / a.steps * 1e3
+    # the step's ops (all their kernels) and, below, the dominant kernel alone: HIP events on the launch stream, serial,
     # after the timed region (inside it the ops of consecutive steps overlap across the stream slots)
     nev = min(a.steps, 200)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
@@ -563,6 +729,8 @@ def run_rank(a):
         wl.step(wl.slots[0], ev[i] if i >= 0 else None)
     torch.cuda.synchronize()
     op_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    if serial_ms is None:
+        serial_ms = dt / a.steps * 1e3
     # the dominant kernel alone, HIP events on the launch stream, after the timed region
     dom_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -570,8 +738,9 @@ def run_rank(a):
         wl.dominant(wl.slots[0], dom_ev[i] if i >= 0 else scratch)
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
-    N = B * H * W
-    alg_bytes = N * (D * 4 * 2 + 8 + 4) + K * D * 4          # z read + z_q write + int64 code + mask, codebook once
+    N = wl.dominant_tokens()                                  # tokens per launch of the dominant kernel
+    per_token = D * 4 + 8 + 4 + (D * 4 if a.path != "tokens" else 0)   # z read + int64 code + mask (+ z_q write)
+    alg_bytes = N * per_token + K * D * 4                     # codebook once per launch
     alg_flops = 2.0 * K * D * N
     gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
     tfs = alg_flops / (dom_ms * 1e-3) / 1e12
@@ -580,10 +749,18 @@ def run_rank(a):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(a.mode if a.path == "select" else "routed", {}).get("hbm_bytes_per_launch")
+            traffic = tj.get(a.mode if a.path in ("select", "model") else "routed", {}).get("hbm_bytes_per_launch")
             tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected by tools/pmc_traffic.py; not re-measured in this run)"
         except Exception:
             traffic = None
+    # rocprofv3 --kernel-trace --stats duration of the same kernel, if a summary made from THESE sources is committed
+    rocprof_ms = None
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "bench_kernel_stats.meta.json")))
+        if meta.get("source_sha16") == source_sha16() and meta.get("path") == a.path and meta.get("scaling") == a.scaling:
+            rocprof_ms = meta.get("dominant_kernel_avg_ms")
+    except Exception:
+        pass
     if a.mode == "filter":
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}
@@ -595,19 +772,23 @@ def run_rank(a):
                  "counter-zero kernel precedes it in the same op and is inside the bracket), one launch at a time after "
                  "the timed region. Inside the timed region consecutive steps overlap on config.streams HIP streams, so a "
                  "kernel trace of THIS command shows stretched, overlapping per-kernel durations; the trace of the same "
-                 "command with --streams 1 (profiles/r02_bench_kernel_stats.csv) is the one this figure agrees with",
+                 "command with --streams 1 (profiles/r03_bench_kernel_stats.csv) is the one this figure agrees with "
+                 "(kernel_ms_rocprof, when that summary was made from these sources)",
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
-                 "algorithmic_note": "SURVEY.md 8d count of the VQ forward: every one of the B*H*W positions read once "
-                                     "(1 KiB), z_q written once (1 KiB), int64 code, mask",
+                 "algorithmic_note": "SURVEY.md 8d count of the VQ forward per launch of this kernel: every position read once "
+                                     "(1 KiB), z_q written once (1 KiB; not in --path tokens: 1032 + 4 B per token), int64 "
+                                     "code, mask; codebook once",
                  "hbm_gbps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_tflops_equiv": tfs,
-                 "whole_op_ms": op_ms, "whole_op_hbm_gbps": alg_bytes / (op_ms * 1e-3) / 1e9})
+                 "kernel_ms_rocprof": rocprof_ms, "whole_op_ms": op_ms})
     if rank == 0:
         out = {
             "metric": "images encoded/sec (VQ hot path: gate + routing + VQ assign), 256x256 inputs, K=%d" % K,
             "value": wl.Bglobal * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "serial_ms_per_step": serial_ms,
+            "serial_value": wl.Bglobal / (serial_ms * 1e-3) if world == 1 else None, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
+                       "source_sha16": source_sha16(), "inputs": "one input set per stream slot (seeds differ)",
                        "spinup_steps": a.spinup, "streams": S, "host_issue_ms_per_step": t_issue / a.steps * 1e3,
                        "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
                                       "per step" % world},

@@ -213,10 +213,6 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 //          into ring slots the code loop does not need yet and read back with ds_read_b32; the fine branch
 //          is read by every lane with the dense kernel's load pattern.  With the per-lane form (SEL = 1) the
 //          two / four waves that share a coarse line each fetched it (PMC: 2.1x the coarse bytes).
-// Anti-phase (cu_lock != null): the two workgroups a CU holds take turns in the code loop (a lock word per
-// CU, keyed by XCC_ID / HW_ID), so that one workgroup's HBM phases (epilogue, and the prologue of the
-// workgroup dispatched into the freed slot) run beside the other's matrix phase in EVERY generation
-// instead of all resident workgroups moving through the three phases in lockstep.
 // ---------------------------------------------------------------------------------------------
 #ifdef DVQ_TUNING
 // diagnostics of the tuning build only: per-workgroup clock stamps around the code loop (s_memtime / s_memrealtime,
@@ -471,11 +467,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         asm volatile("" ::: "memory");
     }
     for (int t = pre; t < 3; ++t) issue(t);                  // (SEL == 2) the code tiles that waited for those slots
-    // anti-phase: this CU's other workgroup may be in its code loop; wait for it (bounded: a lost lock costs
-    // overlap, never progress).  Lane 0 of wave 0 spins; the other waves wait at the loop's first barrier.
 #ifdef DVQ_TUNING
     if (g_dvq_stamps != nullptr && tid == 0) st_pro = __builtin_amdgcn_s_memrealtime();
-#endif
+    // anti-phase experiment (tuning build only, measured and NOT adopted: profiles/r03_pass1_antiphase_ab.json): the two
+    // workgroups a CU holds take turns in the code loop through a lock word per CU.  A lone workgroup's loop takes as long
+    // as two sharing the matrix cores (the loop is bound by each wave's own instruction stream, not by the pipe), so
+    // serialising the loops only adds the lock wait.  (Lane 0 of wave 0 spins, bounded; the other waves wait at the
+    // loop's first barrier.)
     int lock_slot = 0;
     if (cu_lock != nullptr) {
         lock_slot = dvq_cu_slot();
@@ -488,7 +486,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             }
         }
     }
-#ifdef DVQ_TUNING
     if (g_dvq_stamps != nullptr && tid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
@@ -576,10 +573,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         }
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
+#ifdef DVQ_TUNING
         if (cu_lock != nullptr) {
             __builtin_amdgcn_s_barrier();                    // every wave is out of the loop: hand the matrix cores over
             if (tid == 0) __hip_atomic_store(&cu_lock[lock_slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
         // merge the four lane groups of a token column (lower lane wins ties), then hand the results to the lanes
         // that own the token in the (c, h) layout of the prologue / epilogue
         float rb[2], rs[2];
@@ -1483,12 +1482,12 @@ int dvq_launch_exact_list(const float *z, const float *prep, const float *E, con
 // Launch-time choices of the filter path.  They are compile-time constants of the production library; only the
 // tuning build (-DDVQ_TUNING: libdvq_tuning.so, tools/) can change them, through dvq_tuning_set().
 struct DvqTune {
-    int antiphase;       // pass 1: the two workgroups of a CU take turns in the code loop (per-CU lock)
+    int antiphase;       // pass 1, tuning build only: the two workgroups of a CU take turns in the code loop (per-CU lock)
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
 };
 #ifndef DVQ_ANTIPHASE_DEFAULT
-#define DVQ_ANTIPHASE_DEFAULT 1
+#define DVQ_ANTIPHASE_DEFAULT 0
 #endif
 #ifdef DVQ_TUNING
 static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0};

@@ -24,14 +24,21 @@ from .router import DualGrainFixedEntropyRouter, route_select_dual, route_select
 
 def _can_route(quantize, quant_conv, *feats):
     """the fused routed assign applies when nothing sits between select and quantizer and nothing needs a
-    gradient (inference / frozen stage 1): an eval-mode VectorQuantize2 on NCHW feature maps"""
+    gradient (inference / frozen stage 1): an eval-mode VectorQuantize2 on NCHW feature maps, within the kernel's own
+    preconditions (dvq_abi.hip: routed_common) -- D in (64, 128, 256), at most 1024 coarse cells per image, K < 2^20,
+    assign mode EXACT or FILTER; any grid width (odd ones included).  Anything else takes select + dense assign."""
     if quant_conv is not None or not isinstance(quantize, VectorQuantize2):
         return False
     if quantize.training or not quantize.accept_image_fmap:
         return False
     if torch.is_grad_enabled() and any(t.requires_grad for t in feats):
         return False
-    return all(t.is_cuda and t.dtype == torch.float32 for t in feats) and feats[0].shape[2] * feats[0].shape[3] <= 1024
+    coarse = feats[0]
+    if coarse.dim() != 4 or coarse.shape[1] not in (64, 128, 256) or coarse.shape[2] * coarse.shape[3] > 1024:
+        return False
+    if quantize.assign_mode not in (_lib.MODE_EXACT, _lib.MODE_FILTER) or quantize.codebook.n_embed >= (1 << 20):
+        return False
+    return all(t.is_cuda and t.dtype == torch.float32 for t in feats)
 
 
 def _can_fuse_conv(quantize, quant_conv, *feats):
@@ -107,6 +114,28 @@ def encode_fixed(quantize, h, quant_conv=None):
     if quant_conv is not None:
         h = qconv.quant_conv(quant_conv, h) if _can_fuse_conv(quantize, quant_conv, h) else quant_conv(h)
     return quantize(h)
+
+
+def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None, max_len=None, out=None):
+    """Codes-only tokenisation for stage 2 (reference models/stage2_dynamic/dqtransformer_uncond_entropy.py:166-171,182:
+    `_, z_out = self.encode_to_z(x)` keeps only `permuter(indices, grain_indices)` and discards quant): the routed assign
+    with want_zq = False / want_loss = False (pass 1 writes no z_q: 1032 B per token instead of 2060) followed by the
+    permuter on the same stream.  With `max_len` (see DualGrainSeperatePermuter.forward; `permuter.max_lengths()`) nothing
+    is read back to the host: three kernels (counter zero, pass 1, resolver + list) and one permuter kernel, all queued.
+    -> (permuter dict, grain_indices [B, hc, wc] int64, codes [B, 2hc, 2wc] int64).
+    Needs the fused routed op's preconditions (eval-mode VectorQuantize2, no quant_conv, no autograd)."""
+    if not _can_route(quantize, None, h_coarse, h_fine):
+        raise _lib.DvqError("encode_to_tokens: needs an eval-mode VectorQuantize2 on fp32 GPU feature maps without autograd")
+    cb = quantize.codebook
+    kw = dict(beta=quantize.beta, mode=quantize.assign_mode, want_zq=False, want_loss=False)
+    if isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda:
+        r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
+                                  threshold=router.fine_grain_threshold, **kw)
+    else:
+        r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep,
+                                  gate=router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy), **kw)
+    seqs = permuter(r["codes"], r["indices"], max_len=max_len, out=out)
+    return seqs, r["indices"], r["codes"]
 
 
 def shard_slice(global_batch, rank, world_size):

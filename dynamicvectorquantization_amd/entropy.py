@@ -6,8 +6,10 @@ non-overlapping 16x16 patches, 32-bin Gaussian-KDE histogram over [0, 1] with si
 is PyTorch-ROCm's and hipcc's default).  The forward is ONE fused kernel, `dvq_entropy_map_f32`
 (SURVEY.md section 8 row f3): the image is read once, the reference's [B*P, 256, 32] intermediate (2.1 GB
 at B = 256) never exists.  Transcendental fp32 math: parity to 1e-5, grain maps equal away from the
-threshold.  GPU only (CPU tensors raise); patch size 16 only, the size every reference config uses.
-The reference's tensor-op sequence, used as the comparator in tests, lives in oracle/entropy_torch.py.
+threshold.  GPU only (CPU tensors raise: the package has no CPU path).  The fused kernel covers patch size 16, the
+size every reference config uses; any other patch size (scripts/tools/calculate_entropy_thresholds.py takes
+--patch_size) runs the same arithmetic as chunked torch ops ON THE GPU.
+The reference's tensor-op sequence used as the comparator in tests lives in oracle/entropy_torch.py.
 """
 import torch
 from torch import nn
@@ -18,8 +20,6 @@ from . import _lib
 class Entropy(nn.Sequential):
     def __init__(self, patch_size, image_width, image_height):
         super().__init__()
-        if patch_size != 16:
-            raise NotImplementedError("Entropy: the fused kernel implements patch_size 16 (every reference config)")
         self.width = image_width
         self.height = image_height
         self.psize = patch_size
@@ -31,6 +31,8 @@ class Entropy(nn.Sequential):
         B, C, H, W = x.shape
         if C != 3:
             raise ValueError("Entropy expects RGB images [B, 3, H, W]")
+        if self.psize != 16:
+            return _entropy_ops(x, self.psize)
         out = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device)
         if B == 0:
             return out
@@ -38,6 +40,23 @@ class Entropy(nn.Sequential):
             _lib.check(_lib.lib.dvq_entropy_map_f32(x.data_ptr(), B, H, W, 16, out.data_ptr(),
                                                     _lib.stream_ptr(x.device)), "dvq_entropy_map_f32")
         return out
+
+
+def _entropy_ops(x, patch, chunk=8):
+    """patch sizes the fused kernel does not cover: gray -> patches -> 32-bin Gaussian KDE -> entropy as device tensor
+    ops, a few images at a time (the [b*P, patch^2, 32] intermediate is what the fused kernel avoids)"""
+    B, _, H, W = x.shape
+    bins = torch.linspace(0, 1, 32, device=x.device)
+    outs = []
+    for s in range(0, B, chunk):
+        xs = x[s:s + chunk]
+        gray = 0.2989 * xs[:, 0] + 0.5870 * xs[:, 1] + 0.1140 * xs[:, 2]
+        b = gray.shape[0]
+        p = gray.reshape(b, H // patch, patch, W // patch, patch).permute(0, 1, 3, 2, 4).reshape(-1, patch * patch)
+        pdf = torch.exp(-0.5 * ((p.unsqueeze(2) - bins) / 0.01) ** 2).mean(1)
+        pdf = pdf / (pdf.sum(1, keepdim=True) + 1e-40) + 1e-40
+        outs.append((-(pdf * torch.log(pdf)).sum(1)).reshape(b, H // patch, W // patch))
+    return torch.cat(outs, 0) if outs else x.new_empty((0, H // patch, W // patch))
 
 
 def calibrate_thresholds(batches, patch_size=16):

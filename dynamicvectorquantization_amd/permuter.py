@@ -3,7 +3,8 @@ name keeps the reference's spelling) backed by the stream-compaction kernels of 
 
 forward(indices [B, fine_hw, fine_hw], grain_indices [B, coarse_hw, coarse_hw]) -> dict of
 coarse/fine content, position and segment sequences (int64, EOS-terminated, PAD-filled to the
-longest sequence of the batch -- the one device->host read `pad_sequence` implies);
+longest sequence of the batch -- the one device->host read `pad_sequence` implies; with `max_len=(Lc, Lf)`
+the sequences are padded to those lengths instead and nothing is read back: ONE kernel, no host sync);
 forward_back(...) -> dense [B, fine_hw, fine_hw] codes.  Pure integer work, bit-exact.
 """
 import ctypes
@@ -47,7 +48,15 @@ class DualGrainSeperatePermuter(nn.Module):
         self._special = (ctypes.c_int64 * 6)(content_pad_code, content_eos_code, coarse_position_pad_code,
                                             coarse_position_eos_code, fine_position_pad_code, fine_position_eos_code)
 
-    def forward(self, indices, grain_indices):
+    def max_lengths(self):
+        """(Lc, Lf) that hold any grain map: every cell coarse / every cell fine, plus the EOS"""
+        return self.hw1 * self.hw1 + 1, self.hw2_square * self.hw1 * self.hw1 + 1
+
+    def forward(self, indices, grain_indices, max_len=None, out=None):
+        """max_len = (Lc, Lf): pad to these lengths (>= the batch maxima + 1; `max_lengths()` always suffices) instead of
+        reading the batch maxima back -- the extra columns hold PAD, exactly what pad_sequence would put there in a longer
+        batch.  out: six preallocated [B, Lc] / [B, Lf] int64 tensors in the order coarse content / position / segment,
+        fine content / position / segment (benchmark / graph capture)."""
         indices = _i64_cuda(indices, "indices")
         grain = _i64_cuda(grain_indices, "grain_indices")
         B = indices.shape[0]
@@ -58,14 +67,22 @@ class DualGrainSeperatePermuter(nn.Module):
         dev = indices.device
         with torch.cuda.device(dev):
             st = _lib.stream_ptr(dev)
-            counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
-            maxes = torch.empty(2, dtype=torch.int32, device=dev)
-            _lib.check(_L.dvq_permute_dual_count_i64(grain.data_ptr(), B, hc, hc, counts.data_ptr(), maxes.data_ptr(), st),
-                       "dvq_permute_dual_count_i64")
-            mc, mf = maxes.tolist()                                   # the sync pad_sequence implies
-            Lc, Lf = mc + 1, 4 * mf + 1
-            outs = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
-                   [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]
+            if max_len is not None:
+                Lc, Lf = int(max_len[0]), int(max_len[1])
+            else:
+                counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+                maxes = torch.empty(2, dtype=torch.int32, device=dev)
+                _lib.check(_L.dvq_permute_dual_count_i64(grain.data_ptr(), B, hc, hc, counts.data_ptr(), maxes.data_ptr(), st),
+                           "dvq_permute_dual_count_i64")
+                mc, mf = maxes.tolist()                               # the sync pad_sequence implies
+                Lc, Lf = mc + 1, 4 * mf + 1
+            if out is not None:
+                outs = list(out)
+                if [tuple(o.shape) for o in outs] != [(B, Lc)] * 3 + [(B, Lf)] * 3:
+                    raise ValueError("out tensors must be 3 x [B, Lc] and 3 x [B, Lf] int64")
+            else:
+                outs = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
+                       [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]
             order = 0 if self.fine_position_order == "region-first" else 1
             _lib.check(_L.dvq_permute_dual_forward_i64(indices.data_ptr(), grain.data_ptr(), B, hc, hc, order, Lc, Lf,
                                                        self._special, *[o.data_ptr() for o in outs], st),

@@ -96,11 +96,12 @@ def quant_conv(conv, x):
     return h
 
 
-def quant_conv_select(conv, h_coarse, h_fine, h_median=None, gate=None, entropy=None, threshold=None):
+def quant_conv_select(conv, h_coarse, h_fine, h_median=None, gate=None, entropy=None, threshold=None, out=None):
     """route select + quant_conv as ONE kernel (`dvq_qconv_select_f32`).
     dual: h_coarse [B, D, hc, wc], h_fine [B, D, 2hc, 2wc], `gate` [B, hc, wc, 2] or `entropy` [B, hc, wc] + threshold;
     triple: plus h_median [B, D, 2hc, 2wc], h_fine [B, D, 4hc, 4wc], gate [B, hc, wc, 3].
-    -> dict(h [B, D, S hc, S wc], indices [B, hc, wc] i64, codebook_mask [B, 1, S hc, S wc], gate)."""
+    -> dict(h [B, D, S hc, S wc], indices [B, hc, wc] i64, codebook_mask [B, 1, S hc, S wc], gate).
+    `out` = (h, indices, codebook_mask, gate_out) preallocated (benchmark / graph capture)."""
     if not usable(conv):
         raise _lib.DvqError("quant_conv_select: the module is not a 1x1 nn.Conv2d(D, D) on the GPU")
     nb = 2 if h_median is None else 3
@@ -123,16 +124,21 @@ def quant_conv_select(conv, h_coarse, h_fine, h_median=None, gate=None, entropy=
         g, kind, thr = _lib.require_cuda_f32(entropy, "entropy"), _lib.GATE_ENTROPY, float(threshold)
         if tuple(g.shape) != (B, hc, wc):
             raise ValueError("entropy must be [B, hc, wc]")
-        gate_out = torch.empty((B, hc, wc, 2), dtype=torch.int64, device=dev)
+        gate_out = out[3] if out is not None else torch.empty((B, hc, wc, 2), dtype=torch.int64, device=dev)
     else:
         if gate.dim() != 4 or tuple(gate.shape) != (B, hc, wc, nb) or not gate.is_cuda:
             raise ValueError("gate must be a GPU tensor [B, hc, wc, %d]" % nb)
         kind = _lib.GATE_I64 if gate.dtype == torch.int64 else _lib.GATE_F32
         g = gate.contiguous() if gate.dtype in (torch.int64, torch.float32) else gate.float().contiguous()
         thr = 0.0
-    h = torch.empty_like(h_fine)
-    indices = torch.empty((B, hc, wc), dtype=torch.int64, device=dev)
-    cmask = torch.empty((B, 1, S * hc, S * wc), dtype=torch.float32, device=dev)
+    if out is not None:
+        h, indices, cmask = out[0], out[1], out[2]
+        if tuple(h.shape) != tuple(h_fine.shape) or not (h.is_contiguous() and indices.is_contiguous() and cmask.is_contiguous()):
+            raise ValueError("out tensors must be contiguous and shaped like the op's outputs")
+    else:
+        h = torch.empty_like(h_fine)
+        indices = torch.empty((B, hc, wc), dtype=torch.int64, device=dev)
+        cmask = torch.empty((B, 1, S * hc, S * wc), dtype=torch.float32, device=dev)
     if h.numel() > 0:
         with torch.cuda.device(dev):
             pbuf = _prep_of(conv).get(conv)

@@ -33,11 +33,17 @@ class _CodebookPrep:
     other `.data` writer must call `module.invalidate_codebook_cache()` itself.
 
     Workspaces (queue counters, records, loss partials) are kept PER STREAM, so two streams driving
-    the same quantizer never share a queue."""
+    the same quantizer never share a queue.  The image itself is ONE buffer: the stream that (re)builds it records an
+    event, every other stream waits for that event before its next use, and a rebuild first waits for the uses other
+    streams have queued (encode.StreamSlots with a training-mode quantizer therefore serialises on the rebuild --
+    correct, not fast; inference builds the image once)."""
 
     def __init__(self):
         self.key = None
         self.buf = None
+        self._built = None       # (stream handle, event) of the last build
+        self.track_users = False # set by training-mode forwards: the image may be rebuilt while other streams read it
+        self._users = {}         # stream handle -> event after that stream's last use
         self._ws = {}            # (B, D, HW, K, mode, device, stream) -> uint8 tensor
         self._last_ws = None
 
@@ -47,17 +53,41 @@ class _CodebookPrep:
     def get(self, codebook):
         K, D = codebook.shape
         key = (codebook.data_ptr(), codebook._version, K, D, codebook.device)
+        cur = torch.cuda.current_stream(codebook.device)
         if key != self.key:
             nbytes = _lib_handle.dvq_codebook_prep_bytes(K, D)
             if nbytes == 0:
                 raise _lib.DvqError("unsupported codebook shape K=%d D=%d" % (K, D))
             if self.buf is None or self.buf.numel() < nbytes or self.buf.device != codebook.device:
                 self.buf = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
+            for h, ev in self._users.items():        # other streams may still be reading the old image
+                if h != cur.cuda_stream:
+                    cur.wait_event(ev)
+            self._users.clear()
             _lib.check(_lib_handle.dvq_codebook_prepare_f32(
                 codebook.data_ptr(), K, D, self.buf.data_ptr(), self.buf.numel(),
-                _lib.stream_ptr(codebook.device)), "dvq_codebook_prepare_f32")
+                cur.cuda_stream), "dvq_codebook_prepare_f32")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._built = (cur.cuda_stream, ev)
             self.key = key
+        elif self._built is not None and self._built[0] != cur.cuda_stream:
+            if self._built[1].query():
+                self._built = None               # long done: nothing to order any more
+            else:
+                cur.wait_event(self._built[1])
         return self.buf
+
+    def used(self, device):
+        """called after an op that read the image was queued on the current stream (only needed while the codebook can
+        still change: training-mode quantizers)"""
+        cur = torch.cuda.current_stream(device)
+        ev = self._users.get(cur.cuda_stream)
+        if ev is None:
+            if len(self._users) >= 16:
+                self._users.clear()
+            ev = self._users[cur.cuda_stream] = torch.cuda.Event()
+        ev.record(cur)
 
     def workspace(self, B, D, HW, K, mode, device, nbytes=None):
         key = (B, D, HW, K, mode, device, _lib.stream_ptr(device))
@@ -276,6 +306,8 @@ class _VQStraightThrough(torch.autograd.Function):
         codebook = weight[:K]
         # beta*mean + mean is the same fp32 number whichever addend carries beta (legacy or not)
         zq, codes, loss = vq_assign(z, codebook, prep, mask, beta=(coef_z if coef_e == 1.0 else coef_e), mode=mode)
+        if prep.track_users:
+            prep.used(z.device)
         need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_z or need_w:
             e = embed_gather(codebook, codes.reshape(z.shape[0], -1))          # [B, HW, D], forward-time rows
@@ -488,6 +520,7 @@ class VectorQuantize2(nn.Module):
                 mask = mask.float()
         if self.training:
             self.codebook._prep.invalidate()             # training: optimizers / EMA may write through .data
+        self.codebook._prep.track_users = self.training
         zq, loss, codes = _VQStraightThrough.apply(z, self.codebook.weight, mask, self.codebook._prep, K,
                                                    float(self.beta), 1.0, self.assign_mode)
         if self.training and self.codebook.ema:
@@ -573,6 +606,7 @@ class VectorQuantize2List(nn.Module):
             z = x.reshape(-1, D)
             if self.training:
                 self.codebook._prep.invalidate()
+            self.codebook._prep.track_users = self.training
             zq, l_i, codes = _VQStraightThrough.apply(z, self.codebook.weight, None, self.codebook._prep, K,
                                                       float(self.beta), 1.0, self.assign_mode)
             if self.training and self.codebook.ema:
@@ -680,6 +714,7 @@ class VectorQuantizer2(nn.Module):
         coef_z, coef_e = (1.0, float(self.beta)) if self.legacy else (float(self.beta), 1.0)
         if self.training:
             self._prep.invalidate()                      # the optimizer may have stepped through .data
+        self._prep.track_users = self.training
         z_q, loss, codes = _VQStraightThrough.apply(z, self.embedding.weight, None, self._prep, self.n_e,
                                                     coef_z, coef_e, self.assign_mode)
         min_encoding_indices = codes.reshape(-1)

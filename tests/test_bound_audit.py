@@ -22,3 +22,23 @@ def test_bound_holds_with_margin(dev):
         assert r["decided_but_wrong"] == 0, r
         assert r["decided"] + r["skipped_unscorable"] > 0 or "default-init" in r["case"] or "duplicate" in r["case"], r
     print("max |G - truth| / W over all cases: %.4f" % max(r["max_err_over_W"] for r in res))
+
+
+def test_bound_holds_on_the_production_kernel(dev):
+    """the same claim on what vq_assign_filter_kernel itself computed (best / runner-up / 2W / code per token, stored by the
+    tuning build of the library): its seeds, fragment layout and top-2 merge are under test here, not a restatement.
+    Runs tools/bound_audit.py --production in a child process with DVQ_LIBRARY = libdvq_tuning.so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune = os.path.join(root, "dynamicvectorquantization_amd", "csrc", "libdvq_tuning.so")
+    if not os.path.exists(tune):
+        pytest.skip("libdvq_tuning.so not built (make -C dynamicvectorquantization_amd/csrc tuning)")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bound_audit.py"), "64", "--production"],
+                       env=dict(os.environ, DVQ_LIBRARY=tune), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and '"case"' in l]
+    assert len(rows) >= 8
+    for x in rows:
+        assert x["max_err_over_W"] <= 1.0 and x["decided_but_wrong"] == 0, x

@@ -45,8 +45,8 @@ def test_fused_entropy_refuses_cpu_tensors():
     from dynamicvectorquantization_amd.entropy import Entropy
     with pytest.raises(_lib.DvqError):
         Entropy(16, 256, 256)(torch.zeros(1, 3, 256, 256))
-    with pytest.raises(NotImplementedError):
-        Entropy(8, 256, 256)
+    with pytest.raises(_lib.DvqError):                            # other patch sizes run as GPU tensor ops: still no CPU path
+        Entropy(8, 256, 256)(torch.zeros(1, 3, 256, 256))
 
 
 @pytest.mark.gpu
@@ -127,3 +127,19 @@ def test_fused_entropy_value_sweep_and_special_pixels(dev):
     ok = ~nan_b
     assert np.all(np.abs(a[ok] - b[ok]) <= 1e-5 * np.maximum(1.0, np.abs(b[ok]))), float(np.abs(a[ok] - b[ok]).max())
 
+
+
+@pytest.mark.gpu
+def test_entropy_other_patch_sizes(dev):
+    """patch sizes the fused kernel does not cover (the reference's calculate_entropy_thresholds.py takes --patch_size)
+    run as tensor ops on the GPU: same values as the comparator ops, and patch 16 through both routes agrees"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.entropy import Entropy, _entropy_ops
+    from oracle.entropy_torch import entropy_map
+    x, _ = synth.images_flat_noise(5103, 3, size=128, patch=8)
+    xt = torch.from_numpy(x).to(dev)
+    for p in (8, 32):
+        got = Entropy(p, 128, 128)(xt)
+        assert tuple(got.shape) == (3, 128 // p, 128 // p)
+        assert torch.allclose(got, entropy_map(xt, patch=p), rtol=0, atol=1e-6)
+    assert torch.allclose(Entropy(16, 128, 128)(xt), _entropy_ops(xt, 16), rtol=0, atol=2e-5)

@@ -88,3 +88,68 @@ def test_hip_round_trip_full_batch(dev):
             got = out[k][:8].cpu().numpy()
             assert np.array_equal(got[:, :L][o[k] != (1024 if "content" in k or "fine" in k else 256)],
                                   o[k][o[k] != (1024 if "content" in k or "fine" in k else 256)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["region-first", "row-first"])
+def test_hip_max_len_no_host_sync(dev, order):
+    """max_len: padded to caller-given lengths, no read-back; the reference's self-test fixture fills the leading
+    columns exactly as the synced call does, the rest is PAD; preallocated outputs are used in place"""
+    from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+    g = C.load("permuter_reference_selftest")
+    tag = order.split("-")[0]
+    perm = DualGrainSeperatePermuter(fine_position_order=order)
+    idx = torch.from_numpy(g["indices"].astype(np.int64)).to(dev)
+    grain = torch.from_numpy(g["grain"].astype(np.int64)).to(dev)
+    Lc, Lf = perm.max_lengths()
+    assert (Lc, Lf) == (257, 1025)
+    pre = [torch.full((2, Lc), -7, dtype=torch.int64, device=dev) for _ in range(3)] + \
+          [torch.full((2, Lf), -7, dtype=torch.int64, device=dev) for _ in range(3)]
+    out = perm(idx, grain, max_len=(Lc, Lf), out=pre)
+    assert out["coarse_content"].data_ptr() == pre[0].data_ptr() and out["fine_segment"].data_ptr() == pre[5].data_ptr()
+    pads = {"coarse_content": 1024, "fine_content": 1024, "coarse_position": 256, "fine_position": 1024,
+            "coarse_segment": 0, "fine_segment": 1}
+    for k in KEYS:
+        want = g["%s_%s" % (tag, k)].astype(np.int64)
+        got = out[k].cpu().numpy()
+        L = want.shape[1]
+        assert np.array_equal(got[:, :L], want), k
+        assert np.all(got[:, L:] == pads[k]), k
+    back = perm.forward_back(out["coarse_content"], out["fine_content"], out["coarse_position"], out["fine_position"])
+    assert torch.equal(back, idx)
+
+
+@pytest.mark.gpu
+def test_encode_to_tokens_vs_oracle(dev, oracle_mod, golden_dir):
+    """the codes-only tokenisation stage 2 consumes (dqtransformer_uncond_entropy.py:166-171,182): routed assign without
+    z_q + permuter, no host sync, against oracle gate -> select -> assign -> oracle permuter; B = 64"""
+    import os
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_to_tokens
+    from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    from oracle import permuter as P
+    B, K, D = 64, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hc = synth.z_tokens(E, B, 32, 32, 7301), synth.z_tokens(E, B, 16, 16, 7302)
+    ent = synth.entropy_map(7303, B, 16, 16)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    router = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    for order in ("region-first", "row-first"):
+        perm = DualGrainSeperatePermuter(fine_position_order=order)
+        with torch.no_grad():
+            seqs, grain, codes = encode_to_tokens(router, vq, perm, t(hf), t(hc), entropy=t(ent), max_len=perm.max_lengths())
+            seqs2, _, _ = encode_to_tokens(router, vq, perm, t(hf), t(hc), entropy=t(ent))          # synced lengths
+        og = oracle_mod.entropy_gate(ent, router.fine_grain_threshold)
+        o_sel = oracle_mod.route_select_dual(og, hc, hf)
+        o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+        assert np.array_equal(grain.cpu().numpy(), o_sel["indices"])
+        assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"])
+        ref = P.forward(o["codes"].reshape(B, 32, 32), o_sel["indices"], order=order)
+        for k in KEYS:
+            L = ref[k].shape[1]
+            assert np.array_equal(seqs2[k].cpu().numpy(), ref[k]), k
+            assert np.array_equal(seqs[k].cpu().numpy()[:, :L], ref[k]), k

@@ -330,9 +330,9 @@ def test_dual_feature_router_config_end_to_end(dev, oracle_mod):
     assert np.array_equal(q2.cpu().numpy(), o2["zq"])
     assert C.loss_close(float(l2), oracle_mod.vq_loss(o2["sqerr"], o2["numel"], 0.25))
     # and h itself against the conv in float64 (contract 1e-5 * sum |w||x|)
-    w64 = conv.weight.double().cpu().numpy()[:, :, 0, 0]
+    w64 = conv.weight.detach().double().cpu().numpy()[:, :, 0, 0]
     x64 = o_sel["h_dual"].astype(np.float64)[:4]
-    ref = np.einsum("ok,bkhw->bohw", w64, x64) + conv.bias.double().cpu().numpy()[None, :, None, None]
+    ref = np.einsum("ok,bkhw->bohw", w64, x64) + conv.bias.detach().double().cpu().numpy()[None, :, None, None]
     bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64))
     assert np.all(np.abs(h[:4] - ref) <= 1e-5 * bound + 1e-30)
 
@@ -397,6 +397,16 @@ def test_encode_dual_uses_routed_op_and_matches_select_path(dev, oracle_mod, gol
         assert torch.equal(a[0], b[0]) and torch.equal(a[2][2], b[2][2]) and torch.equal(a[3], b[3])
         assert torch.equal(a[4], b[4]) and a[4].shape == (B, 2, 16, 16)
         assert abs(float(a[1]) - float(b[1])) <= 1e-6 * abs(float(b[1]))
+    # odd grid widths (240-px images: 15 x 15 cells) go through the routed op too
+    hf15, hc15 = t(synth.z_tokens(E, 2, 30, 30, 2223)), t(synth.z_tokens(E, 2, 15, 15, 2233))
+    ent15 = t(synth.entropy_map(5213, 2, 15, 15))
+    with torch.no_grad():
+        a = encode_dual(r_ent, vq, hf15, hc15, entropy=ent15)
+    og = oracle_mod.entropy_gate(ent15.cpu().numpy(), r_ent.fine_grain_threshold)
+    o_sel = oracle_mod.route_select_dual(og, hc15.cpu().numpy(), hf15.cpu().numpy())
+    o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+    assert np.array_equal(a[2][2].cpu().numpy().reshape(2, -1), o["codes"]) and np.array_equal(a[0].cpu().numpy(), o["zq"])
+    assert np.array_equal(a[3].cpu().numpy(), o_sel["indices"])
     hf_g = hf.clone().requires_grad_(True)
     q, loss, _, _, _ = encode_dual(r_ent, vq, hf_g, hc, entropy=ent)          # autograd -> differentiable path
     (q.sum() + loss).backward()

@@ -151,3 +151,39 @@ def test_bench_launcher_spawns_ranks_and_exchanges_on_device():
         assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == ("strong" if "strong" in extra else "weak")
         assert d["parity_checked"] is True and d["code_mismatches"] == 0 and d["parity"]["exchange_ok"] is True
         assert d["parity"]["images_checked"] == (12 if "strong" in extra else 16)
+
+
+@pytest.mark.gpu
+def test_code_exchange_rccl_world1(dev):
+    """the REAL nccl (= RCCL) backend through CodeExchange at world size 1 (what a 1-GPU box can run): pack kernel ->
+    ncclAllGather -> unpack kernel on the device, two exchanges in flight, against the local tensors.  In a child
+    process: the process group must be created before anything else touches the GPU state it binds."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%d), HSA_ENABLE_IPC_MODE_LEGACY="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from dynamicvectorquantization_amd.encode import CodeExchange
+B, K = 8, 1024
+g = torch.Generator().manual_seed(3)
+codes = torch.randint(0, K, (B, 32, 32), generator=g).to(dev)
+grain = torch.randint(0, 2, (B, 16, 16), generator=g).to(dev)
+loss = torch.tensor([0.125, 0.15625], device=dev)
+xs = [CodeExchange(codes, grain, K, B, numel_per_image=32 * 32 * 256) for _ in range(2)]
+assert xs[0].on_gpu and xs[0].world == 1
+xs[0].start(codes, grain, loss)
+xs[1].start(codes + 1 - 2 * (codes == K - 1).long(), grain, None)
+c0, g0, m0 = xs[0].finish()
+c1, g1, m1 = xs[1].finish()
+torch.cuda.synchronize()
+assert torch.equal(c0, codes) and torch.equal(g0, grain) and abs(float(m0) - 0.125) < 1e-7
+assert torch.equal(c1, codes + 1 - 2 * (codes == K - 1).long()) and torch.equal(g1, grain)
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -9,6 +9,11 @@ and the claim under audit is |G_j - truth_j| <= W for every (token, code) -- whi
 Prints the largest observed ratio |G - truth| / W (1.0 would be the edge of the bound).
 
 Usage (GPU box): python tools/bound_audit.py [n_tokens_per_case]
+       DVQ_LIBRARY=<...>/libdvq_tuning.so python tools/bound_audit.py [n] --production
+--production audits the PRODUCTION pass-1 kernel instead of the restatement kernel: the tuning build stores, per token,
+the best score, the runner-up, 2W and the provisional code exactly as vq_assign_filter_kernel computed them (its seeds,
+its fragment layout, its top-2 merge); checked are |best - truth(code)| <= W and |second - max_{j != code} truth_j| <= W,
+and that no provably-decided token disagrees with the reference argmin.
 """
 import json
 import os
@@ -62,6 +67,44 @@ def audit_case(name, tokens, E, dev):
             "decided_but_wrong": wrong, "skipped_unscorable": skipped}
 
 
+def audit_case_production(name, tokens, E, dev):
+    """the production kernel's own (best, second, 2W, code) per token, through the tuning build's debug store"""
+    from oracle import oracle
+    from dynamicvectorquantization_amd.quantize import vq_assign
+    n, D = tokens.shape
+    K = E.shape[0]
+    z = torch.from_numpy(np.ascontiguousarray(tokens.T[None])).to(dev)            # [1, D, n]: NCHW with HW = n
+    Et = torch.from_numpy(E).to(dev)
+    dbg = torch.full((n, 4), float("nan"), dtype=torch.float32, device=dev)
+    prep = _CodebookPrep()
+    assert _lib.lib.dvq_tuning_buffers(0, dbg.data_ptr()) == 0
+    try:
+        vq_assign(z, Et, prep, None, want_zq=False, want_loss=False, mode=_lib.MODE_FILTER_PASS1)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.dvq_tuning_buffers(0, 0)
+    # scale 2^b and xn as the kernel has them: from the restatement ABI (same prep arithmetic)
+    _, W, xn, sB = scores(tokens, E, dev)
+    d4 = dbg.cpu().numpy().astype(np.float64)
+    worst, decided, wrong, skipped = 0.0, 0, 0, 0
+    for i in range(n):
+        best, second, thr2W, code = d4[i]
+        if not np.isfinite(thr2W) or not np.isfinite(W[i]):
+            skipped += 1
+            continue
+        assert abs(thr2W / 2.0 - W[i]) <= 1e-6 * W[i], "production 2W differs from the restatement's"
+        code = int(code)
+        d = oracle.token_distances(tokens[i], E).astype(np.float64)
+        truth = -0.5 * sB * (d - np.float64(xn[i]))
+        others = np.delete(truth, code)
+        worst = max(worst, abs(best - truth[code]) / W[i], abs(second - others.max()) / W[i] if K > 1 else 0.0)
+        if best - second > 2 * W[i]:
+            decided += 1
+            wrong += int(code != int(np.argmin(d)))
+    return {"case": name, "kernel": "production pass 1", "tokens": n, "codes": K, "scale_b": sB, "max_err_over_W": worst,
+            "decided": decided, "decided_but_wrong": wrong, "skipped_unscorable": skipped}
+
+
 def cases(n):
     """(name, tokens [n, D], codebook) -- trained-like data, the tie-stress default init, large / tiny magnitudes,
     fp16-subnormal territory, near-duplicate codes, K = 16384, D = 64"""
@@ -86,9 +129,12 @@ def cases(n):
     return out
 
 
-def run(n=96, verbose=True):
+def run(n=96, verbose=True, production=False):
     dev = torch.device("cuda:0")
-    res = [audit_case(name, t, E, dev) for name, t, E in cases(n)]
+    if production:
+        assert hasattr(_lib.lib, "dvq_tuning_buffers"), "--production needs DVQ_LIBRARY=<...>/libdvq_tuning.so"
+    fn = audit_case_production if production else audit_case
+    res = [fn(name, t, E, dev) for name, t, E in cases(n)]
     if verbose:
         for r in res:
             print(json.dumps(r))
@@ -96,6 +142,7 @@ def run(n=96, verbose=True):
 
 
 if __name__ == "__main__":
-    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    r = run(int(args[0]) if args else 256, production="--production" in sys.argv)
     print(json.dumps({"max_err_over_W": max(x["max_err_over_W"] for x in r),
                       "decided_but_wrong": sum(x["decided_but_wrong"] for x in r)}))

@@ -26,8 +26,8 @@ kernels = {}
 def find(per, prefix):
     ks = [k for k in per if k.startswith(prefix)]
     return ks[0] if ks else None
-for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0"), ("fused_pass1", "vq_assign_filter_kernel<256, 1"),
-                      ("resolver", "vq_resolve_kernel<256>")):
+for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0"), ("fused_pass1", "vq_assign_filter_kernel<256, 2"),
+                      ("fused_pass1_per_lane_select", "vq_assign_filter_kernel<256, 1"), ("resolver", "vq_resolve_kernel<256>")):
     kf, kw = find(fetch, prefix), find(write, prefix)
     if kf is None or kw is None:
         continue
@@ -40,9 +40,15 @@ if "dense_pass1" in kernels:
     out["filter"] = {"hbm_bytes_per_launch": kernels["dense_pass1"]["hbm_bytes_per_launch"], "algorithmic_bytes": alg,
                      "ratio_dominant_kernel_to_algorithmic": kernels["dense_pass1"]["hbm_bytes_per_launch"] / alg}
 if "fused_pass1" in kernels:
-    # the fused kernel reads each position's source vector (h_fine or h_coarse) once and writes z_q once
+    # the fused kernel reads every line of h_fine and of h_coarse once (a 128-B line of h_fine holds 16 cells: all of them are
+    # needed) and writes z_q once: line-granular floor = N*1024 (fine) + N*256 (coarse) + z_q + codes + mask + gate + codebook
+    floor = N * (D * 4 + D + D * 4 + 8 + 4) + N // 4 * 4 + 1024 * D * 4
     out["routed"] = {"hbm_bytes_per_launch": kernels["fused_pass1"]["hbm_bytes_per_launch"], "algorithmic_bytes": alg,
                      "ratio_dominant_kernel_to_algorithmic": kernels["fused_pass1"]["hbm_bytes_per_launch"] / alg,
+                     "line_granular_floor_bytes": floor,
+                     "ratio_to_line_granular_floor": kernels["fused_pass1"]["hbm_bytes_per_launch"] / floor,
                      "note": "resolver kernels of both ops are averaged together under 'resolver'"}
+    if "fused_pass1_per_lane_select" in kernels:
+        out["routed"]["per_lane_select_form_bytes"] = kernels["fused_pass1_per_lane_select"]["hbm_bytes_per_launch"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: out.get(k) for k in ("filter", "routed")}), "factor", factor)

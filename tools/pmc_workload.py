@@ -3,7 +3,9 @@
 It launches (1) a calibration kernel with a KNOWN byte count in the same access pattern as the
 filter kernel's z read (vq_assign_exact, K=32, codes only: reads N*D*4 bytes with 4-B-per-lane
 loads, writes 8 B per token), then (2) the dense filter path on BASELINE configs[2] (B=256, K=1024),
-then (3) the routed op (select fused into pass 1) exactly as bench.py runs it."""
+then (3) the routed op (select fused into pass 1, coarse branch staged through LDS) exactly as bench.py runs it, and
+(4) -- tuning build only (DVQ_LIBRARY=.../libdvq_tuning.so) -- the routed op with the per-lane select form (round 2's),
+whose coarse lines are fetched by every wave that shares them."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,4 +33,10 @@ torch.cuda.synchronize()
 for _ in range(4):
     vq_assign_routed_dual(hc, z, Et, pr, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER)
 torch.cuda.synchronize()
+if hasattr(_lib.lib, "dvq_tuning_set"):
+    _lib.lib.dvq_tuning_set(b"sel_staged", 0)
+    for _ in range(4):
+        vq_assign_routed_dual(hc, z, Et, pr, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER)
+    torch.cuda.synchronize()
+    _lib.lib.dvq_tuning_set(b"sel_staged", 1)
 print("queued/exact dense", p.fallback_count(), "routed", pr.fallback_count())

@@ -60,10 +60,10 @@ for _ in range(300):                          # bring the part out of its idle p
 torch.cuda.synchronize()
 s = timeit(lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1,
                                          out=(zq, codes, None, grain, cmask, gate)))
-row("vq_assign_filter_kernel<256,1,true> (pass 1, select fused in)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
+row("vq_assign_filter_kernel<256,2> (pass 1, select fused in, coarse branch through LDS)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
     "bracket includes the 4.6-us counter-zero kernel; VQ-forward byte count (the kernel also does the select's work); socket power cap binds (DESIGN 5)")
 s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)))
-row("vq_assign_filter_kernel<256,0,true> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "bracket includes the counter-zero kernel")
+row("vq_assign_filter_kernel<256,0> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "bracket includes the counter-zero kernel")
 s_full = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER, out=(zq, codes, loss)))
 row("dense filter op (zero + pass 1 + resolver + list/finalize)", "B=256 K=1024", s_full, vq_bytes, vq_flops, F16)
 s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_EXACT, out=(zq, codes, loss)), n=10, warm=3)
@@ -76,7 +76,7 @@ E16 = t(E16n)
 zb = t(synth.z_tokens(E16n, 64, 32, 32, 2005)).repeat(8, 1, 1, 1)
 p16 = _CodebookPrep()
 s = timeit(lambda: vq_assign(zb, E16, p16, None, mode=_lib.MODE_FILTER_PASS1), n=5, warm=2)
-row("vq_assign_filter_wide_kernel<256,true> (pass 1, K=16384)", "configs[4] B=512", s, 512 * 1024 * 2060 + 16384 * 1024, 2.0 * 16384 * 256 * 512 * 1024, F16,
+row("vq_assign_filter_wide_kernel<256> (pass 1, K=16384)", "configs[4] B=512", s, 512 * 1024 * 2060 + 16384 * 1024, 2.0 * 16384 * 256 * 512 * 1024, F16,
     "matrix-bound config; runs power-limited like the K=1024 loop")
 del zb, E16, p16
 # feature-router gate, triple B=128 and dual B=64: rocprof splits pool / MLP (profiles/r02_gate_kernels_*.txt); here the op
