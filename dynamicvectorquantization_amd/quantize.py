@@ -71,7 +71,8 @@ class _CodebookPrep:
             ev.record(cur)
             self._built = (cur.cuda_stream, ev)
             self.key = key
-        elif self._built is not None and self._built[0] != cur.cuda_stream:
+        elif self._built is not None and self._built[0] != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
+            # (a capture is always preceded by uncaptured warm-up calls on the capturing stream: ordered there)
             if self._built[1].query():
                 self._built = None               # long done: nothing to order any more
             else:
@@ -81,6 +82,8 @@ class _CodebookPrep:
     def used(self, device):
         """called after an op that read the image was queued on the current stream (only needed while the codebook can
         still change: training-mode quantizers)"""
+        if torch.cuda.is_current_stream_capturing():
+            return
         cur = torch.cuda.current_stream(device)
         ev = self._users.get(cur.cuda_stream)
         if ev is None:
