@@ -690,13 +690,14 @@ def run_rank(a):
         last = wl.slots[(nstep[0] - 1) % S]
         parity = wl.parity(last)
         # every stream slot ran its OWN batch (own seeds): each against the oracle on all of its images
-        nbad = 0
+        nbad, nslots = 0, 1
         for o in wl.slots:
             if o is last or nstep[0] <= S:
                 continue
             po = wl.parity(o)
             nbad += int(any(v for k_, v in po.items() if k_.endswith("_mismatches")) or po["loss_rel_err"] > 1e-5)
-            parity["images_checked"] += po["images_checked"]
+            nslots += 1
+        parity["slots_checked"] = nslots                      # stream slots (own inputs each) checked in full on this rank
         parity["slot_mismatches"] = nbad
         if world > 1:
             keys = sorted(k for k in parity if k != "loss_rel_err")
