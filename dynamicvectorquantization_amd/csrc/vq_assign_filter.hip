@@ -43,6 +43,12 @@
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
+#ifndef DVQ_DMA_EARLY
+#define DVQ_DMA_EARLY 0          // 1: the next ring tile's DMA pieces are issued in one run before the MFMA chain instead of between its MFMAs
+#endif
+#ifndef DVQ_ABLATE
+#define DVQ_ABLATE 0             // timing experiments of the tuning build only (results are WRONG): 1 no top-2 update, 2 no ring DMA in the
+#endif                           // loop, 4 no per-tile barrier, 8 no MFMAs, 16 no A-fragment reads, 32 no seed reads
 #ifndef DVQ_LOCK_MAX_SPINS
 #define DVQ_LOCK_MAX_SPINS 4000  // anti-phase lock: give up waiting after about 3 ms
 #endif
@@ -497,57 +503,12 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         const int q16 = lane >> 4;
         float b1[2] = {-__builtin_inff(), -__builtin_inff()}, b2[2] = {-__builtin_inff(), -__builtin_inff()};
         int bt[2] = {0, 0};
-        for (int t = 0; t < T; ++t) {
-            // accumulator seeds of tile t: this wave's own DMA copy, landed by the previous step's wait (tile 0: before
-            // the prologue's loads) -> no barrier needed
-            const float *seeds = enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16;
-            f32x4 acc16[2][2];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const f32x4 e4 = *(const f32x4 *)(seeds + 16 * c2);
-                acc16[c2][0] = e4;
-                acc16[c2][1] = e4;
-            }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // all but the youngest tile's DMA: tiles <= t + 1 landed
-            __builtin_amdgcn_s_barrier();                    // tile t (everybody's DMA) landed; t-1 consumed
-            asm volatile("" ::: "memory");
-            if (S16 != 16) issue(t + 3);                     // D = 256: pieces ride between the MFMAs below
-            // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
-            // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
-            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
-                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
-            f16x8 a0, a1, a2, a3;
-            // make the compiler wait for the seed reads HERE (an opaque use of the accumulators); otherwise its own
-            // lgkmcnt(0) lands in front of the first MFMA and drains the four fragment reads below
-            asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][1]), "+v"(acc16[1][0]), "+v"(acc16[1][1]));
-            __builtin_amdgcn_sched_barrier(0);
-#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-#define DVQ_MM(src, F, WAIT, NEXT)                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            acc16[(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][(F) % S32], acc16[(F) / S32][0], 0, 0, 0); \
-            acc16[(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][(F) % S32], acc16[(F) / S32][1], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if ((F) + 4 < S16) { DVQ_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                  \
-            NEXT
-            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
-            __builtin_amdgcn_s_setprio(1);
-            if (S16 == 16) {
-                // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
-                // then overlaps the MFMA already in the pipe instead of preceding the whole chain
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, issue_piece(t + 3, 0);) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-                DVQ_MM(a0, 4, 3, issue_piece(t + 3, 1);) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, issue_piece(t + 3, 2);)
-                DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, issue_piece(t + 3, 3);) DVQ_MM(a3, 11, 3, )
-                DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, issue_piece(t + 3, 4);) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
-            } else if (S16 == 8) {
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 3, ) DVQ_MM(a2, 2, 3, ) DVQ_MM(a3, 3, 3, )
-                DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
-            } else {
-                DVQ_MM(a0, 0, 3, ) DVQ_MM(a1, 1, 2, ) DVQ_MM(a2, 2, 1, ) DVQ_MM(a3, 3, 0, )
-            }
-#undef DVQ_MM
-#undef DVQ_RD
-            __builtin_amdgcn_s_setprio(0);
+        // Per tile: barrier -> the first four A-fragment reads are issued -> the running top-2 is updated with the PREVIOUS
+        // tile's scores (plain VALU work that hides the LDS latency of those reads) -> the accumulators are re-seeded ->
+        // MFMA chain.  A wave's instruction stream, not the matrix pipe, bounds this loop (a workgroup alone on a CU takes as
+        // long as two sharing it: profiles/r03_pass1_antiphase_ab.json), so what matters is the length of that stream.
+        f32x4 acc16[2][2];
+        auto top2 = [&](int tt) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 const float om = b1[t2];
@@ -562,9 +523,84 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                     b1[t2] = vmax3_raw(b1[t2], g0, g1);
                     b2[t2] = vmax_raw(b2[t2], md);
                 }
-                bt[t2] = (b1[t2] != om) ? t : bt[t2];
+                bt[t2] = (b1[t2] != om) ? tt : bt[t2];
             }
+        };
+        for (int t = 0; t < T; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // all but the youngest tile's DMA: tiles <= t + 1 landed
+            if (!(DVQ_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // tile t (everybody's DMA) landed; t-1 consumed
+            asm volatile("" ::: "memory");
+            if (S16 != 16 && !(DVQ_ABLATE & 2)) issue(t + 3);      // D = 256: pieces ride between the MFMAs below
+            // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
+            // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
+            const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                        lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
+            f16x8 a0, a1, a2, a3;
+#if DVQ_ABLATE & 16
+#define DVQ_RD(dst, S) asm volatile("" : "=v"(dst) : "v"(tile_a))
+#else
+#define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
+#endif
+            DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0 && !(DVQ_ABLATE & 1)) top2(t - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // accumulator seeds of tile t: this wave's own DMA copy (landed by the wait above), read behind the fragments
+                const unsigned seed_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
+                                            enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16);
+                f32x4 e0, e1;
+#if DVQ_ABLATE & 32
+                asm volatile("" : "=v"(e0), "=v"(e1) : "v"(seed_a));
+#else
+                asm volatile("ds_read_b128 %0, %1" : "=v"(e0) : "v"(seed_a));
+                asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(e1) : "v"(seed_a));
+#endif
+#if DVQ_DMA_EARLY
+                if (S16 == 16 && !(DVQ_ABLATE & 2)) {
+#pragma unroll
+                    for (int q = 0; q < PER_TILE; ++q) issue_piece(t + 3, q);
+                }
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
+                acc16[0][0] = e0; acc16[0][1] = e0; acc16[1][0] = e1; acc16[1][1] = e1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if DVQ_DMA_EARLY || (DVQ_ABLATE & 2)
+#define DVQ_PIECE(Q)
+#else
+#define DVQ_PIECE(Q) issue_piece(t + 3, Q);
+#endif
+#define DVQ_MM(src, F, WAIT, NEXT)                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (!(DVQ_ABLATE & 8)) {                                                                              \
+            acc16[(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][(F) % S32], acc16[(F) / S32][0], 0, 0, 0); \
+            acc16[(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][(F) % S32], acc16[(F) / S32][1], 0, 0, 0); \
+            } else { asm volatile("" : "+v"(acc16[(F) / S32][0]), "+v"(acc16[(F) / S32][1]) : "v"(src), "v"(zb[0][(F) % S32]), "v"(zb[1][(F) % S32])); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if ((F) + 4 < S16) { DVQ_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                  \
+            NEXT
+            __builtin_amdgcn_s_setprio(1);
+            if (S16 == 16) {
+                // the next ring tile's DMA pieces are issued between MFMAs: each ~100-cycle issue stall
+                // then overlaps the MFMA already in the pipe instead of preceding the whole chain
+                DVQ_MM(a0, 0, 0, ) DVQ_MM(a1, 1, 1, DVQ_PIECE(0)) DVQ_MM(a2, 2, 2, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, DVQ_PIECE(1)) DVQ_MM(a1, 5, 3, ) DVQ_MM(a2, 6, 3, ) DVQ_MM(a3, 7, 3, DVQ_PIECE(2))
+                DVQ_MM(a0, 8, 3, ) DVQ_MM(a1, 9, 3, ) DVQ_MM(a2, 10, 3, DVQ_PIECE(3)) DVQ_MM(a3, 11, 3, )
+                DVQ_MM(a0, 12, 3, ) DVQ_MM(a1, 13, 2, DVQ_PIECE(4)) DVQ_MM(a2, 14, 1, ) DVQ_MM(a3, 15, 0, )
+            } else if (S16 == 8) {
+                DVQ_MM(a0, 0, 0, ) DVQ_MM(a1, 1, 1, ) DVQ_MM(a2, 2, 2, ) DVQ_MM(a3, 3, 3, )
+                DVQ_MM(a0, 4, 3, ) DVQ_MM(a1, 5, 2, ) DVQ_MM(a2, 6, 1, ) DVQ_MM(a3, 7, 0, )
+            } else {
+                DVQ_MM(a0, 0, 0, ) DVQ_MM(a1, 1, 0, ) DVQ_MM(a2, 2, 0, ) DVQ_MM(a3, 3, 0, )
+            }
+#undef DVQ_MM
+#undef DVQ_RD
+#undef DVQ_PIECE
+            __builtin_amdgcn_s_setprio(0);
         }
+        if (!(DVQ_ABLATE & 1)) top2(T - 1);
 #ifdef DVQ_TUNING
         if (g_dvq_stamps != nullptr && tid == 0) {
             unsigned long long *sp = g_dvq_stamps + 8 * (size_t)blockIdx.x;

@@ -106,9 +106,12 @@ def stamp_stats():
 res = {"B": B, "K": K, "variants": []}
 ref = {}
 variants = [("dense", 0, 1), ("dense", 1, 1), ("routed", 0, 1), ("routed", 1, 1), ("routed", 0, 0), ("routed", 1, 0)]
+if os.environ.get("AB_VARIANTS"):                      # e.g. "dense:0:1,routed:0:1" = kind:antiphase:sel_staged
+    variants = [(k, int(a), int(g)) for k, a, g in (v.split(":") for v in os.environ["AB_VARIANTS"].split(","))]
+datas = os.environ.get("AB_DATA", "random,zeros").split(",")
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for kind, anti, staged in variants:
-        for data in ("random", "zeros"):
+        for data in datas:
             tune(antiphase=anti, sel_staged=staged)
             _lib.lib.dvq_tuning_buffers(0, 0)
             us_p1, w_p1 = measure(lambda: launch(kind, data, _lib.MODE_FILTER_PASS1))
