@@ -99,6 +99,8 @@ def _load():
         lib.dvq_tuning_set.argtypes = [ctypes.c_char_p, i32]
         lib.dvq_tuning_buffers.restype = i32
         lib.dvq_tuning_buffers.argtypes = [vp, vp]
+        lib.dvq_tuning_pipe_stamps.restype = i32
+        lib.dvq_tuning_pipe_stamps.argtypes = [vp]
     lib.dvq_debug_filter_scores_f32.restype = i32
     lib.dvq_debug_filter_scores_f32.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.dvq_exchange_bytes.restype = sz

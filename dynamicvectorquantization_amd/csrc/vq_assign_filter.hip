@@ -1521,17 +1521,26 @@ struct DvqTune {
     int antiphase;       // pass 1, tuning build only: the two workgroups of a CU take turns in the code loop (per-CU lock)
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
+    int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
 };
 #ifndef DVQ_ANTIPHASE_DEFAULT
 #define DVQ_ANTIPHASE_DEFAULT 0
 #endif
+#ifndef DVQ_PIPE_DEFAULT
+#define DVQ_PIPE_DEFAULT 0
+#endif
+bool dvq_pipe_supported(int D, int HW, int K, long N, const DvqRouted *rv);
+int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, const float *E, const float *mask,
+                    int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
+                    int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0};
+static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0, DVQ_PIPE_DEFAULT};
 extern "C" int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "antiphase")) g_tune.antiphase = value;
     else if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
+    else if (!strcmp(key, "pipe")) g_tune.pipe = value;
     else return -1;
     return 0;
 }
@@ -1544,7 +1553,7 @@ extern "C" int dvq_tuning_buffers(void *stamps, void *tokdbg)
     return (int)rc;
 }
 #else
-static constexpr DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0};
+static constexpr DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0, DVQ_PIPE_DEFAULT};
 #endif
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
@@ -1666,6 +1675,12 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
 {
     const int nb1 = (int)((N + 127) / 128);
     const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
+#ifdef DVQ_TUNING
+    // tuning build: the persistent role-alternating form (vq_assign_pipe.hip; measured slower so far, see its header)
+    if (g_tune.pipe && !force_wide && dvq_pipe_supported(D, HW, K, N, rv) && (rv == nullptr || staged_select_ok(*rv)))
+        return dvq_launch_pipe(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, nb1, w.counters, w.exact_list,
+                               w.records, w.cap / DVQ_QSHARDS, rv, st);
+#endif
     if (rv != nullptr) {                                     // select fused in
         if (staged_select_ok(*rv))
             return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);

@@ -84,6 +84,8 @@ def measure(fn, spin_s=2.0, n=200):
 
 def stamp_stats():
     st = stamps.cpu().numpy().astype(np.int64)
+    if not ((st[:, 5] > st[:, 3]) & (st[:, 7] >= st[:, 5])).any():
+        return {"wg_stamped": 0}                              # (the persistent pipe form carries no stamps)
     slot, r_in, r_pro, r_l0, c_l0, r_l1, c_l1, r_out = (st[:, i] for i in range(8))
     ok = (r_l1 > r_l0) & (r_out >= r_l1)
     us = lambda d: float(np.median(d[ok])) / 100.0            # 100 MHz ticks -> us
@@ -112,7 +114,7 @@ datas = os.environ.get("AB_DATA", "random,zeros").split(",")
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for kind, anti, staged in variants:
         for data in datas:
-            tune(antiphase=anti, sel_staged=staged)
+            tune(antiphase=anti, sel_staged=staged, pipe=int(os.environ.get("AB_PIPE", "0")))
             _lib.lib.dvq_tuning_buffers(0, 0)
             us_p1, w_p1 = measure(lambda: launch(kind, data, _lib.MODE_FILTER_PASS1))
             row = {"kind": kind, "antiphase": anti, "sel_staged": staged, "data": data, "rep": rep, "pass1_us": round(us_p1, 1), "pass1_socket_W": w_p1}
@@ -140,7 +142,7 @@ for rep in range(int(os.environ.get("AB_REPS", "2"))):
             res["variants"].append(row)
             print(json.dumps(row), flush=True)
 # dense == routed on the routed batch is not expected (different inputs); exact mode agrees with the filter
-tune(antiphase=1, sel_staged=1)
+tune(antiphase=0, sel_staged=1)
 launch("routed", "random", _lib.MODE_EXACT)
 torch.cuda.synchronize()
 res["routed_exact_equals_filter"] = bool(torch.equal(codes, ref["routed"][0]) and torch.equal(zq, ref["routed"][1]))
