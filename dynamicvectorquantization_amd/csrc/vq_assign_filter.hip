@@ -505,8 +505,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         int bt[2] = {0, 0};
         // Per tile: barrier -> the first four A-fragment reads are issued -> the running top-2 is updated with the PREVIOUS
         // tile's scores (plain VALU work that hides the LDS latency of those reads) -> the accumulators are re-seeded ->
-        // MFMA chain.  A wave's instruction stream, not the matrix pipe, bounds this loop (a workgroup alone on a CU takes as
-        // long as two sharing it: profiles/r03_pass1_antiphase_ab.json), so what matters is the length of that stream.
+        // MFMA chain.  A wave's instruction ISSUE, not the matrix pipe, bounds this loop: about 1330 cycles per tile, of which
+        // the pipe is busy 512; a workgroup alone on a CU takes as long as two sharing it (profiles/r03_pass1_antiphase_ab.json,
+        // r03_pass1_loop_ablation.json).  Moving the top-2 update into the shadow of the MFMAs (one code half behind them, no
+        // second accumulator set) changed nothing, as that model predicts: 42.7k vs 42.6k cycles per loop
+        // (profiles/r03_pass1_half_tile_pipelining.json; git history has the code).
         f32x4 acc16[2][2];
         auto top2 = [&](int tt) {
 #pragma unroll
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 bt[t2] = (b1[t2] != om) ? tt : bt[t2];
             }
         };
-        for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T; ++t) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // all but the youngest tile's DMA: tiles <= t + 1 landed
             if (!(DVQ_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // tile t (everybody's DMA) landed; t-1 consumed
             asm volatile("" ::: "memory");
