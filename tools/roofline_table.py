@@ -61,7 +61,7 @@ torch.cuda.synchronize()
 s = timeit(lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1,
                                          out=(zq, codes, None, grain, cmask, gate)))
 row("vq_assign_filter_kernel<256,2> (pass 1, select fused in, coarse branch through LDS)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
-    "bracket includes the 4.6-us counter-zero kernel; VQ-forward byte count (the kernel also does the select's work); socket power cap binds (DESIGN 5)")
+    "bracket includes the 4.6-us counter-zero kernel; VQ-forward byte count (the kernel also does the select's work); issue-bound code loop between two HBM-bound phases (DESIGN 5.1)")
 s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)))
 row("vq_assign_filter_kernel<256,0> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "bracket includes the counter-zero kernel")
 s_full = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER, out=(zq, codes, loss)))
@@ -77,7 +77,7 @@ zb = t(synth.z_tokens(E16n, 64, 32, 32, 2005)).repeat(8, 1, 1, 1)
 p16 = _CodebookPrep()
 s = timeit(lambda: vq_assign(zb, E16, p16, None, mode=_lib.MODE_FILTER_PASS1), n=5, warm=2)
 row("vq_assign_filter_wide_kernel<256> (pass 1, K=16384)", "configs[4] B=512", s, 512 * 1024 * 2060 + 16384 * 1024, 2.0 * 16384 * 256 * 512 * 1024, F16,
-    "matrix-bound config; runs power-limited like the K=1024 loop")
+    "matrix-bound config")
 del zb, E16, p16
 # feature-router gate, triple B=128 and dual B=64: rocprof splits pool / MLP (profiles/r02_gate_kernels_*.txt); here the op
 r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
