@@ -9,7 +9,9 @@
 //     waves that take turns: while group A runs the code loop of its block, group B writes the z_q of its previous block
 //     and loads / converts its next one -- the HBM phases of one block run beside the matrix phase of another in EVERY
 //     phase, by construction;
-//   * the group in the memory role also issues ALL the ring DMA, so the computing waves' stream carries no DMA at all;
+//   * the computing group feeds the codebook ring itself (five LDS-DMA pieces per wave and tile, between its MFMAs; the
+//     last three tiles it issues in a phase are the first three of the OTHER group's next phase), so the memory role has no
+//     ring duty.  (First form of round 3: the memory role issued all ring DMA -- same time, see STATUS.)
 //   * the two groups meet at one s_barrier per code tile (32 per phase), which is also the ring's hand-shake.
 // Same per-token arithmetic as vq_assign_filter_kernel (same fp16 conversion, same seeds, same 16x16x32 MFMA chain, same
 // top-2 and bound, same queue / records / exact list), hence the same bits out; resolver and list kernel are unchanged.
@@ -18,23 +20,28 @@
 // select fused in on a 32-wide output grid (SEL 2 dual, SEL 3 triple; coarser branches staged through LDS as in
 // vq_assign_filter_kernel<D, 2>).  Everything else takes vq_assign_filter_kernel.
 //
-// Memory-role bookkeeping: a wave in the memory role has ring DMA, loads and stores in flight at once and must know when ITS
-// pieces of a ring tile have landed before it may arrive at the barrier that hands the tile over.  Vector-memory operations
-// retire in issue order (one counter, vmcnt), so "wait until at most n younger operations are outstanding" does it -- but
-// only if n is exact: every vector-memory instruction of the memory role is therefore issued unconditionally for the wave
-// (asm volatile, never inside a lane-dependent branch), in a fixed per-step pattern per (EPI, PRO, STORE, SEL) variant, and
-// the counts are computed at compile time from that pattern (struct Pat).  hipcc would otherwise wait vmcnt(0) at the first
-// use of any ordinary load while an LDS-DMA is in flight; the z loads and codebook-row gathers are inline asm for that
-// reason, and the few ordinary loads (gate, queue-slot atomic) sit at the start of a phase, where nothing is in flight.
-// STATUS (round 3): bit-exact (tests/test_pipe_form.py), but NOT faster than vq_assign_filter_kernel yet -- 237 vs 203 us
-// (dense) and 272 vs 220 us (select fused) at B = 256 (profiles/r03_pipe_form.json): a memory-role wave can keep at most 63
-// vector-memory operations in flight and retires them in order, so its 16 z loads per step tie the ring hand-over to the HBM
-// latency (0.8-0.9 us per load step instead of 0.55), and the one barrier per step passes that stall on to the computing
-// group; fill and drain cost two more phases per workgroup.  Kept in the TUNING build only (dvq_tuning_set("pipe", 1)); what
-// it needs next is in DESIGN.md section 7.
+// Memory-role bookkeeping: the z loads, codebook-row gathers and z_q stores of the memory role are inline asm, issued
+// unconditionally for the wave (never inside a lane-dependent branch) in a fixed per-step pattern per (EPI, PRO, STORE, SEL)
+// variant, and waited for with counts computed at compile time from that pattern (struct Pat): vector-memory operations
+// retire in issue order (one counter, vmcnt), so "wait until at most n younger operations are outstanding" is exact.  hipcc
+// would otherwise wait vmcnt(0) at the first use of any ordinary load while an LDS-DMA is in flight; the few ordinary loads
+// (gate, queue-slot atomic) sit at the start of a phase.
+// STATUS (round 3): bit-exact (tests/test_pipe_form.py), NOT faster than vq_assign_filter_kernel -- 220 vs 203 us (dense)
+// and 248 vs 220 us (select fused) at B = 256, in both forms (ring DMA by the memory role: 217-237 / 272).  The ablations
+// and cycle accumulators below (DVQ_ABLATE, tools/pipe_probe.py, profiles/r03_pipe_form_ablation.json) show why: the two
+// waves of a SIMD share ONE issue stream (one instruction per four cycles), so a phase costs the SUM of the computing wave's
+// instructions (12.4 us), the ring DMA issues (6.4 us wherever they sit) and the memory role's (6.6 us) = 25 us -- the time
+// the product kernel needs for the same work; counted memory waits are < 2 % of a phase.  Kept in the TUNING build only
+// (dvq_tuning_set("pipe", 1)) as the measured negative result DESIGN.md section 5.1 cites.
 #include "dvq_filter.h"
 #ifdef DVQ_TUNING
 #include <type_traits>
+#ifndef DVQ_PIPE_PRIO
+#define DVQ_PIPE_PRIO 1   // 1: the computing waves raise their priority over the MFMA section; 0: no priorities; 2: the memory role is the high-priority one
+#endif
+#ifndef DVQ_ABLATE
+#define DVQ_ABLATE 0   // timing experiments (WRONG results except 1024): 128 z loads hit one cached line; 256 z_q stores hit one line; 512 no
+#endif                 // conversion arithmetic; 1024 cycle accumulators -> stamp slot 4p + 3; 2048 no gathers; 4096 no stores; 8192 no loss math
 
 namespace {
 
@@ -59,22 +66,24 @@ struct Pat {
     static constexpr int stores(int t) { return (EPI && STORE && t < 16) ? 8 : 0; }
     static constexpr int loads(int t) { return (PRO && t >= 16 && t < 24) ? 16 : 0; }
     static constexpr int stage(int t) { return (PRO && t == 16) ? NSTAGE : 0; }
-    // order inside a step: ring DMA (5), gathers, stores | staging DMA, loads
-    static constexpr int ops(int t) { return 5 + gathers(t) + stores(t) + stage(t) + loads(t); }
+    // order inside a step: gathers, stores | staging DMA, loads   (the ring DMA is the COMPUTING group's: see compute_phase)
+    static constexpr int ops(int t) { return gathers(t) + stores(t) + stage(t) + loads(t); }
     static constexpr int base(int t) { int n = pre(); for (int i = 0; i < t; ++i) n += ops(i); return n; }   // ops issued before step t
     static constexpr int cap(int n) { return n > 63 ? 63 : (n < 0 ? 0 : n); }
-    // before arriving at barrier t + 1: this wave's pieces of tile t + 1 (issued first thing in step t - 2) have landed
-    static constexpr int ring_wait(int t) { return cap(base(t + 1) - (base(t - 2) + 5)); }
+    // steps 0 and 1 of a memory phase that follows this wave's compute phase: the ring pieces it issued in the last two steps
+    // of that phase (tiles 1 and 2 of THIS phase; tile 2's five pieces are younger than tile 1's) must have landed before it
+    // arrives at barriers 1 and 2
+    static constexpr int lead_wait(int t) { return cap((t == 0 ? 5 : 0) + base(t + 1)); }
     // step u, before using the gathers of k-step u (issued in step u - 2 right after its DMA; k-steps 0, 1 in the pre-step);
     // the wait sits after step u's DMA and gathers
     static constexpr int gather_wait(int u)
     {
-        const int issued_before_wait = base(u) + 5 + gathers(u);
-        const int last = (u < 2) ? (2 * u + 2) : (base(u - 2) + 5 + 2);       // index after the last gather of k-step u
+        const int issued_before_wait = base(u) + gathers(u);
+        const int last = (u < 2) ? (2 * u + 2) : (base(u - 2) + 2);           // index after the last gather of k-step u
         return cap(issued_before_wait - last);
     }
-    // step 24 + j, before converting k-steps 2j, 2j + 1 (loaded in step 16 + j); the wait sits after step 24 + j's DMA
-    static constexpr int load_wait(int j) { return cap(base(24 + j) + 5 - base(17 + j)); }
+    // step 24 + j, before converting k-steps 2j, 2j + 1 (loaded in step 16 + j)
+    static constexpr int load_wait(int j) { return cap(base(24 + j) - base(17 + j)); }
 };
 
 struct PipeArgs {
@@ -105,8 +114,11 @@ __device__ unsigned long long *g_pipe_stamps = nullptr;
 extern "C" int dvq_tuning_pipe_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_stamps), &p, sizeof(void *)); }
 #define PIPE_STAMP(SLOT) do { if (g_pipe_stamps != nullptr && w4 == 0 && lane == 0 && (SLOT) < 64) \
     g_pipe_stamps[((size_t)blockIdx.x * 2 + g) * 64 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PIPE_STAMPV(SLOT, V) do { if (g_pipe_stamps != nullptr && w4 == 0 && lane == 0 && (SLOT) < 64) \
+    g_pipe_stamps[((size_t)blockIdx.x * 2 + g) * 64 + (SLOT)] = (long long)(V); } while (0)
 #else
 #define PIPE_STAMP(SLOT) do { } while (0)
+#define PIPE_STAMPV(SLOT, V) do { } while (0)
 #endif
 
 template <int SEL, bool STORE>
@@ -141,20 +153,18 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
     int tok_n = 0;                                           // token index of this lane in the block it holds (b*HW + hw)
     double dsum = 0.0;
 
-    // this wave's five pieces of code tile (t mod 32) into ring slot t mod 4.  `vimg` = image base + this lane's offset inside
-    // a tile (made opaque once per phase: hipcc otherwise hoists the 160 per-step addresses of a phase out of the phase loop
-    // and spills them)
-    auto ring_issue = [&](const char *vimg, int t) __attribute__((always_inline)) {
+    // piece q (0..3: 1 KiB of the image, 4: this wave's copy of the seeds) of code tile (t mod 32) into ring slot t mod 4.
+    // `vimg` = image base + this lane's offset inside a tile (made opaque once per phase: hipcc otherwise hoists the per-step
+    // addresses of a phase out of the phase loop and spills them)
+    auto ring_piece = [&](const char *vimg, int t, int q) __attribute__((always_inline)) {
         const char *src = vimg + (size_t)(t & (T - 1)) * PTILE;
         char *dst = lds + L_RING + (t & (PNBUF - 1)) * PIMG + w4 * 4096;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(src + q * 1024, dst + q * 1024);
-        glds4(src + (PIMG - w4 * 4096 - lane * 12), enraw + ((t & (PNBUF - 1)) * 4 + w4) * 64);
+        if (q < 4) glds16(src + q * 1024, dst + q * 1024);
+        else glds4(src + (PIMG - w4 * 4096 - lane * 12), enraw + ((t & (PNBUF - 1)) * 4 + w4) * 64);
     };
 
     // =================================================================================================================
-    // compute role: the code loop of the block held in zb; 32 steps, one barrier each, no vector-memory instruction
-    // except the two waits that retire the ring pieces this wave issued at the end of its memory phase
+    // compute role: the code loop of the block held in zb; 32 steps, one barrier each; feeds the ring (tile t + 3 in step t)
     // =================================================================================================================
     auto compute_phase = [&]() __attribute__((always_inline)) {
         PIPE_STAMP(4 * phase_no);
@@ -178,9 +188,27 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 bt[t2] = (b1[t2] != om) ? tt : bt[t2];
             }
         };
+        const char *vimg = a.img + w4 * 4096 + lane * 16;
+        asm volatile("" : "+v"(vimg));
+#if DVQ_ABLATE & 1024
+        unsigned ck_vm = 0, ck_bar = 0, ck_lw = 0;
+        const int my_phase = phase_no - 1;
+#endif
         for (int t = 0; t < T; ++t) {
+            // ring: the computing group feeds it (pieces of tile t + 3 between the MFMAs below; past the phase's end they are
+            // the first tiles of the next phase, for the other group).  All but the youngest tile's pieces landed = tiles <= t + 1.
+#if DVQ_ABLATE & 1024
+            const unsigned c0_ = (unsigned)__builtin_readcyclecounter();
+#endif
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#if DVQ_ABLATE & 1024
+            const unsigned c1_ = (unsigned)__builtin_readcyclecounter();
+#endif
             __builtin_amdgcn_s_barrier();                    // tile t landed (everybody's pieces); tile t - 1 consumed
             asm volatile("" ::: "memory");
+#if DVQ_ABLATE & 1024
+            { const unsigned d_ = (unsigned)__builtin_readcyclecounter() - c0_; if (t < 16) ck_bar += d_; else if (t < 24) ck_vm += d_; else ck_lw += d_; }
+#endif
             const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
                                         lds + L_RING + (t & (PNBUF - 1)) * PIMG + lane * 16);
             f16x8 a0, a1, a2, a3;
@@ -199,25 +227,30 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 acc16[0][0] = e0; acc16[0][1] = e0; acc16[1][0] = e1; acc16[1][1] = e1;
             }
             __builtin_amdgcn_sched_barrier(0);
-#define PIPE_MM(src, F, WAIT)                                                                                  \
+#define PIPE_MM(src, F, WAIT, NEXT)                                                                            \
             asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             acc16[(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][(F) % S32], acc16[(F) / S32][0], 0, 0, 0); \
             acc16[(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][(F) % S32], acc16[(F) / S32][1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if ((F) + 4 < S16) { PIPE_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }
+            if ((F) + 4 < S16) { PIPE_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                  \
+            NEXT
+#if DVQ_PIPE_PRIO == 1
             __builtin_amdgcn_s_setprio(1);
-            PIPE_MM(a0, 0, 0) PIPE_MM(a1, 1, 1) PIPE_MM(a2, 2, 2) PIPE_MM(a3, 3, 3)
-            PIPE_MM(a0, 4, 3) PIPE_MM(a1, 5, 3) PIPE_MM(a2, 6, 3) PIPE_MM(a3, 7, 3)
-            PIPE_MM(a0, 8, 3) PIPE_MM(a1, 9, 3) PIPE_MM(a2, 10, 3) PIPE_MM(a3, 11, 3)
-            PIPE_MM(a0, 12, 3) PIPE_MM(a1, 13, 2) PIPE_MM(a2, 14, 1) PIPE_MM(a3, 15, 0)
+#endif
+            PIPE_MM(a0, 0, 0, ) PIPE_MM(a1, 1, 1, ring_piece(vimg, t + 3, 0);) PIPE_MM(a2, 2, 2, ) PIPE_MM(a3, 3, 3, )
+            PIPE_MM(a0, 4, 3, ring_piece(vimg, t + 3, 1);) PIPE_MM(a1, 5, 3, ) PIPE_MM(a2, 6, 3, ) PIPE_MM(a3, 7, 3, ring_piece(vimg, t + 3, 2);)
+            PIPE_MM(a0, 8, 3, ) PIPE_MM(a1, 9, 3, ) PIPE_MM(a2, 10, 3, ring_piece(vimg, t + 3, 3);) PIPE_MM(a3, 11, 3, )
+            PIPE_MM(a0, 12, 3, ) PIPE_MM(a1, 13, 2, ring_piece(vimg, t + 3, 4);) PIPE_MM(a2, 14, 1, ) PIPE_MM(a3, 15, 0, )
 #undef PIPE_MM
 #undef PIPE_RD
+#if DVQ_PIPE_PRIO == 1
             __builtin_amdgcn_s_setprio(0);
-            // the ring pieces this wave issued in the last two steps of its memory phase (tiles 1 and 2 of THIS phase)
-            if (t == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            if (t == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
+#if DVQ_ABLATE & 1024
+        PIPE_STAMPV(4 * my_phase + 3, (unsigned long long)ck_bar | ((unsigned long long)ck_vm << 21) | ((unsigned long long)ck_lw << 42));
+#endif
         top2(T - 1);
         // merge the four lane groups of a token column (lower lane wins ties), then hand the results to the lanes that own
         // the token in the (c, h) layout
@@ -271,9 +304,8 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P00::FN(ARG)) : "memory"); }                    \
         } while (0)
         PIPE_STAMP(4 * phase_no);
-        // ---- pre-step (nothing of this wave is in flight here: ordinary loads / atomics are safe)
-        const char *vimg = a.img + w4 * 4096 + lane * 16;
-        asm volatile("" : "+v"(vimg));
+        // ---- pre-step: ordinary loads / atomics (hipcc drains the vector-memory queue at their first use while this wave's last
+        // ring pieces are in flight: a stall of at most one L2 latency per phase)
         const float *ep = a.E + 8 * h;                       // chosen codebook row of this lane's token (EPI)
         const float *zqb = a.zq;                             // uniform base of this block's image in z_q (EPI)
         unsigned vst = 0;                                    // running byte offset of this lane's next z_q store
@@ -339,7 +371,6 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
             cell = (size_t)nb * a.rv.hc * a.rv.wc + (y / SC) * a.rv.wc + x / SC;
             graw = dvq_gate_fetch(a.rv.gate, a.rv.gate_mode, a.rv.G, cell);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (EPI) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(eg[0][0]) : "v"(ep));
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(eg[0][1]) : "v"(ep));
@@ -361,16 +392,25 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
             vld = (unsigned)(((8 * h) * HW + hwl) * 4);
         }
 
+#if DVQ_ABLATE & 1024
+        unsigned tk_bar = 0, tk_gw = 0, tk_lw = 0, tk0 = 0;
+#define PIPE_TICK(ACC) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); ACC += now_ - tk0; tk0 = now_; } while (0)
+#define PIPE_TICK0() do { tk0 = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define PIPE_TICK(ACC) do { } while (0)
+#define PIPE_TICK0() do { } while (0)
+#endif
 #define PIPE_STEP(t)                                                                                            \
         {                                                                                                          \
+            PIPE_TICK0();                                                                                          \
             __builtin_amdgcn_s_barrier();                                                                          \
             asm volatile("" ::: "memory");                                                                         \
+            if ((t) < 16) PIPE_TICK(tk_bar); else if ((t) < 24) PIPE_TICK(tk_gw); else PIPE_TICK(tk_lw);           \
             if ((t) == 16) PIPE_STAMP(4 * phase_no + 1);                                                           \
             if ((t) == 24) PIPE_STAMP(4 * phase_no + 2);                                                           \
-            ring_issue(vimg, (t) + 3);                                                                             \
             if (EPI && (t) < 16) {                                                                                 \
                 constexpr int u = (t) < 16 ? (t) : 0;                                                              \
-                if (u <= 13) {                                                                                     \
+                if (u <= 13 && !(DVQ_ABLATE & 2048)) {                                                             \
                     asm volatile("global_load_dwordx4 %0, %1, off offset:%c2" : "=v"(eg[(u + 2) % 3][0]) : "v"(ep), "i"(64 * (u + 2)));          \
                     asm volatile("global_load_dwordx4 %0, %1, off offset:%c2" : "=v"(eg[(u + 2) % 3][1]) : "v"(ep), "i"(64 * (u + 2) + 16));     \
                 }                                                                                                  \
@@ -380,13 +420,13 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 for (int j = 0; j < 8; ++j) {                                                                      \
                     const float e = eg[u % 3][j >> 2][j & 3];                                                      \
                     const float diff = __fsub_rn(e, zf[u][j]);                                                     \
-                    if (STORE) {                                                                                   \
+                    if (STORE && !(DVQ_ABLATE & 4096)) {                                                           \
                         asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(vst), "v"(__fadd_rn(zf[u][j], diff)), "s"(zqb) : "memory");   \
-                        vst += chstride;                                                                           \
+                        if (!(DVQ_ABLATE & 256)) vst += chstride;                                                  \
                     }                                                                                              \
-                    lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m_loss));                              \
+                    if (!(DVQ_ABLATE & 8192)) lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m_loss));    \
                 }                                                                                                  \
-                if (STORE) vst += 8 * chstride;                                                                    \
+                if (STORE && !(DVQ_ABLATE & 256)) vst += 8 * chstride;                                             \
                 asm volatile("" : "+v"(lsum));      /* the loss terms of this k-step are summed HERE, not parked in scratch */ \
             }                                                                                                      \
             if (PRO && (t) >= 16 && (t) < 24) {                                                                    \
@@ -397,9 +437,9 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                     _Pragma("unroll")                                                                              \
                     for (int j = 0; j < 8; ++j) {                                                                  \
                         asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(zf[2 * j2 + q][j]) : "v"(vld), "s"(zsrc));   \
-                        vld += chstride;                                                                           \
+                        if (!(DVQ_ABLATE & 128)) vld += chstride;                                                  \
                     }                                                                                              \
-                    vld += 8 * chstride;                                                                           \
+                    if (!(DVQ_ABLATE & 128)) vld += 8 * chstride;                                                  \
                 }                                                                                                  \
             }                                                                                                      \
             if (PRO && (t) >= 24) {                                                                                \
@@ -410,11 +450,9 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 for (int q = 0; q < 2; ++q)                                                                        \
                     _Pragma("unroll")                                                                              \
                     for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(zf[2 * j2 + q][j]));                        \
-                convert(2 * j2);                                                                                   \
-                convert(2 * j2 + 1);                                                                               \
+                if (!(DVQ_ABLATE & 512)) { convert(2 * j2); convert(2 * j2 + 1); }                                 \
             }                                                                                                      \
-            if ((t) >= 2) PIPE_WAIT(ring_wait, ((t) >= 2 ? (t) : 2));                                              \
-            else if (prev_mem) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+            if ((t) < 2 && !prev_mem) PIPE_WAIT(lead_wait, ((t) < 2 ? (t) : 0));                                   \
         }
 
         // staging DMA of the coarser branches of the next block (as vq_assign_filter_kernel<D, 2>): every wave of the group
@@ -513,12 +551,21 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
             for (int l = 0; l < 8; ++l) asm volatile("" : "+v"(pa[s & 1][l]));
         };
 
+#if DVQ_PIPE_PRIO == 2
+        __builtin_amdgcn_s_setprio(2);
+#endif
         PIPE_STEP(0) PIPE_STEP(1) PIPE_STEP(2) PIPE_STEP(3) PIPE_STEP(4) PIPE_STEP(5) PIPE_STEP(6) PIPE_STEP(7)
         PIPE_STEP(8) PIPE_STEP(9) PIPE_STEP(10) PIPE_STEP(11) PIPE_STEP(12) PIPE_STEP(13) PIPE_STEP(14) PIPE_STEP(15)
         PIPE_STEP(16) PIPE_STEP(17) PIPE_STEP(18) PIPE_STEP(19) PIPE_STEP(20) PIPE_STEP(21) PIPE_STEP(22) PIPE_STEP(23)
         PIPE_STEP(24) PIPE_STEP(25) PIPE_STEP(26) PIPE_STEP(27) PIPE_STEP(28) PIPE_STEP(29) PIPE_STEP(30) PIPE_STEP(31)
 #undef PIPE_STEP
 #undef PIPE_WAIT
+#if DVQ_PIPE_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#if DVQ_ABLATE & 1024
+        PIPE_STAMPV(4 * phase_no + 3, (unsigned long long)tk_bar | ((unsigned long long)tk_gw << 21) | ((unsigned long long)tk_lw << 42));
+#endif
 
         ++phase_no;
         if (EPI) dsum += (double)lsum;
@@ -548,9 +595,18 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
     //   group 0:  M(load b0)  C  M  C  ...  C  M(finish)  M(idle)
     //   group 1:  M(idle)  M(load b1)  C  M  ...  M  C  M(finish)
     // (the launcher gives every workgroup an even number of blocks: both groups have R rounds)
-    if (g == 1) memory_phase(false, false, 0, false);
+    // the first three code tiles of the first compute phase (group 0's): issued by group 0 now, landed long before its
+    // prologue's loads have (in-order retirement)
+    if (g == 0) {
+        const char *vimg0 = a.img + w4 * 4096 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ring_piece(vimg0, t, q);
+    }
+    if (g == 1) memory_phase(false, false, 0, true);
     for (int r = 0; r < R; ++r) {
-        memory_phase(r > 0, true, b_lo + 2 * r + g, g == 1 && r == 0);
+        memory_phase(r > 0, true, b_lo + 2 * r + g, r == 0);
         compute_phase();
     }
     memory_phase(true, false, 0, false);

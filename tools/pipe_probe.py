@@ -47,6 +47,12 @@ for g in (0, 1):
     s24 = (s[:, g, 2::4][:, :n - 1] - starts[:, :n - 1]) / 100.0
     out["group%d_to_step16_us" % g] = [round(float(x), 2) if x > 0 else None for x in np.median(s16, axis=0)]
     out["group%d_to_step24_us" % g] = [round(float(x), 2) if x > 0 else None for x in np.median(s24, axis=0)]
+    if os.environ.get("PIPE_TICKS"):                     # DVQ_ABLATE & 1024 build: cycle accumulators in slot 4p + 3
+        v = s[:, g, 3::4][:, :n - 1]
+        f = lambda sh: [int(x) for x in np.median((v >> sh) & ((1 << 21) - 1), axis=0)]
+        out["group%d_cycles_barrier" % g] = f(0)          # memory phases: all 32 barriers; compute phases: barriers
+        out["group%d_cycles_wait_a" % g] = f(21)          # memory phases: gather waits; compute phases: ring waits
+        out["group%d_cycles_wait_b" % g] = f(42)          # memory phases: load waits
     out["group%d_total_us" % g] = round(float(np.median(starts[:, n - 1] - starts[:, 0])) / 100.0, 2)
 out["kernel_span_us"] = round(float(s[:, :, 0::4].max() - s[:, :, 0][s[:, :, 0] > 0].min()) / 100.0, 2)
 print(json.dumps(out))
