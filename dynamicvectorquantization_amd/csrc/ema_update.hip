@@ -9,6 +9,10 @@
 // bytes per float-atomic wave-instruction, the shape that runs at the chip's full atomic rate
 // (64 lanes hitting 64 different rows would be ~17x slower).  Bound: float-atomic throughput.
 // Float atomics add in arrival order: sums agree with the reference to rounding (1e-5), not bit for bit.
+// Privatising the sums in LDS ([K][33] fp32 per 32-channel slice, ds_add_f32, one global atomic per non-zero entry at the
+// end: 8 M instead of 67 M global atomics at B = 256) was built and measured in round 3: 370 us against this kernel's 288 --
+// a ds_add_f32 wave-instruction takes 192 cycles whatever its address pattern (tools/micro/lds_atomic_rate.hip: three
+// cycles per lane, 170 G adds/s over the chip, below the 233 G/s the L2 atomics reach here); profiles/r03_ema_lds_negative.json.
 #include "dvq_common.h"
 
 __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__restrict__ z,

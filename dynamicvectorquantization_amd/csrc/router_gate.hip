@@ -530,8 +530,8 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     // two blocks of 32 cells per workgroup when the split tile of 64 cells fits the LDS and there are enough cells to keep
     // every CU busy that way
     const size_t shmem2 = ((size_t)2 * 32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
-    static int ncu = 0;
-    if (ncu == 0) {
+    int ncu = 256;                                           // of the CURRENT device (no process-wide cache)
+    {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         ncu = n > 0 ? n : 256;
