@@ -15,6 +15,12 @@
 // cycles per lane, 170 G adds/s over the chip, below the 233 G/s the L2 atomics reach here); profiles/r03_ema_lds_negative.json.
 #include "dvq_common.h"
 
+// COMBINE: tokens of a tile that chose the same code are summed in LDS first and reach the global sums as ONE row of
+// atomics (leader = the first such token; members as a 64-bit mask).  Equal codes inside 64 consecutive positions are the
+// rule, not the exception: the 2 x 2 / 4 x 4 copies of a coarse cell carry one code, and a trained codebook's usage is
+// skewed -- atomics on one address serialise in L2 (10 % of the tokens on one code: 1314 us without, profiles/
+// r02_ema_lds_table_negative_result.txt).  Needs a [K] int table in LDS: K <= 8192 (larger codebooks: plain form).
+template <bool COMBINE>
 __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__restrict__ z,
                                                              const long long *__restrict__ codes, int D, int HW,
                                                              long N, int K, float *__restrict__ cluster_size,
@@ -22,14 +28,39 @@ __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__rest
 {
     __shared__ float tile[64][65];                 // [channel][token], +1 pad: conflict-free transpose
     __shared__ int code_s[64];
+    __shared__ unsigned mask_s[64][2];             // COMBINE: members of the leader's class (bit t = token t), 0 for non-leaders
+    extern __shared__ int first_s[];               // COMBINE: [K] first token of the tile with this code (64 = none)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long tok0 = (long)blockIdx.x * 64;
+    if (COMBINE) {
+        for (int i = threadIdx.x; i < K; i += 256) first_s[i] = 64;
+        if (threadIdx.x < 64) { mask_s[threadIdx.x][0] = 0u; mask_s[threadIdx.x][1] = 0u; }
+        __syncthreads();
+    }
     {
         const long n = tok0 + threadIdx.x;
         if (threadIdx.x < 64) {
             long long cj = (n < N) ? codes[n] : -1;
-            code_s[threadIdx.x] = (cj >= 0 && cj < K) ? (int)cj : -1;
-            if (cj >= 0 && cj < K) atomicAdd(&cluster_size[cj], 1.0f);
+            const bool ok = cj >= 0 && cj < K;
+            code_s[threadIdx.x] = ok ? (int)cj : -1;
+            if (COMBINE) {
+                if (ok) atomicMin(&first_s[(int)cj], (int)threadIdx.x);
+            } else if (ok) {
+                atomicAdd(&cluster_size[cj], 1.0f);
+            }
+        }
+    }
+    if (COMBINE) {
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int cj = code_s[threadIdx.x];
+            if (cj >= 0) atomicOr(&mask_s[first_s[cj]][threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int cj = code_s[threadIdx.x];
+            const unsigned m0 = mask_s[threadIdx.x][0], m1 = mask_s[threadIdx.x][1];
+            if (cj >= 0 && (m0 | m1) != 0u) atomicAdd(&cluster_size[cj], (float)(__popc(m0) + __popc(m1)));
         }
     }
     const long n = tok0 + lane;                    // token of this lane while loading
@@ -49,8 +80,16 @@ __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__rest
         for (int i = 0; i < 16; ++i) {             // wave w adds tokens 16w + i: lane = channel
             const int tk = 16 * wave + i;
             const int cj = code_s[tk];
-            if (cj >= 0 && c0 + lane < D)
+            if (COMBINE) {
+                unsigned m0 = __builtin_amdgcn_readfirstlane(mask_s[tk][0]), m1 = __builtin_amdgcn_readfirstlane(mask_s[tk][1]);
+                if ((m0 | m1) == 0u) continue;     // not a leader (or no valid code)
+                float sum = 0.0f;
+                while (m0) { const int t = __builtin_ctz(m0); m0 &= m0 - 1; sum += tile[lane][t]; }
+                while (m1) { const int t = __builtin_ctz(m1); m1 &= m1 - 1; sum += tile[lane][32 + t]; }
+                if (c0 + lane < D) atomicAdd(&vectors_sum[(size_t)cj * D + c0 + lane], sum);
+            } else if (cj >= 0 && c0 + lane < D) {
                 atomicAdd(&vectors_sum[(size_t)cj * D + c0 + lane], tile[lane][tk]);
+            }
         }
     }
 }
@@ -73,7 +112,11 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(ema_zero_kernel, dim3(blocks), dim3(256), 0, st, cluster_size, (size_t)K, vectors_sum, n);
     }
-    hipLaunchKernelGGL(ema_accumulate_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, z, codes, D, HW, N, K,
-                       cluster_size, vectors_sum);
+    if (K <= 8192)
+        hipLaunchKernelGGL(ema_accumulate_kernel<true>, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)K * sizeof(int), st, z,
+                           codes, D, HW, N, K, cluster_size, vectors_sum);
+    else
+        hipLaunchKernelGGL(ema_accumulate_kernel<false>, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, z, codes, D, HW, N, K,
+                           cluster_size, vectors_sum);
     return (int)hipGetLastError();
 }

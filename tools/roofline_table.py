@@ -115,4 +115,10 @@ def ema():
     _lib.check(_lib.lib.dvq_ema_accumulate_nchw_f32(hf.data_ptr(), cod.data_ptr(), B, D, 1024, K, cs.data_ptr(), vs.data_ptr(), _lib.stream_ptr(dev)), "ema")
 s = timeit(ema, n=20, warm=5)
 row("ema_accumulate_kernel", "B=256 K=1024 (uniform random codes)", s, N * (D * 4 + 8), note="float atomics into K*D sums: atomic throughput, not HBM")
+# the same with the codes a dual-grain batch produces: half of the 2 x 2 cells carry one code (combined in LDS before the atomics)
+_fine = torch.randint(0, K, (B, 32, 32), device=dev)
+_up = lambda x: x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+cod = torch.where(_up(torch.rand((B, 16, 16), device=dev) < 0.5), _up(torch.randint(0, K, (B, 16, 16), device=dev)), _fine).contiguous()
+s = timeit(ema, n=20, warm=5)
+row("ema_accumulate_kernel", "B=256 K=1024 (dual-grain codes: half of the 2x2 cells coarse)", s, N * (D * 4 + 8), note="equal codes inside a 64-token tile are summed in LDS first: 0.625 of the atomics")
 print(json.dumps({"peaks": {"hbm_GB_per_s": HBM, "fp16_mfma_TFLOP_per_s": F16, "fp32_mfma_TFLOP_per_s": F32}, "rows": rows}, indent=1))
