@@ -490,7 +490,29 @@ class VQEmbedding(nn.Embedding):
         return super().forward(idxs)
 
 
-class VectorQuantize2(nn.Module):
+class _CodebookOps:
+    """what VectorQuantize2 and VectorQuantize2List share besides forward (quantize2_mask.py:193-208, quantize2_list.py)"""
+
+    @torch.no_grad()
+    def get_soft_codes(self, x, temp=1.0, stochastic=False):
+        """x [..., D] channel-last -> (softmax(-d / temp) over the K codes [..., K], hard code [...]):
+        a multinomial draw per token when `stochastic`, else the nearest code (quantize2_mask.py:193-205)."""
+        d = self.codebook.compute_distances(x)
+        soft = torch.softmax(d / (-temp), dim=-1)
+        if stochastic:
+            code = torch.multinomial(soft.reshape(-1, soft.shape[-1]), 1).reshape(soft.shape[:-1])
+        else:
+            code = torch.argmin(d, dim=-1)
+        return soft, code
+
+    def get_codebook_entry(self, indices, *kwargs):
+        return self.codebook.embed(indices)
+
+    def invalidate_codebook_cache(self):
+        self.codebook.invalidate_codebook_cache()
+
+
+class VectorQuantize2(_CodebookOps, nn.Module):
     """Reference modules/vector_quantization/quantize2_mask.py:135-210 (and quantize2.py:135)."""
 
     def __init__(self, codebook_size, codebook_dim=None, accept_image_fmap=True, commitment_beta=0.25,
@@ -544,26 +566,9 @@ class VectorQuantize2(nn.Module):
                 x_code = x_code.reshape(x.shape[0], -1)
         return x_q, loss, (None, None, x_code)
 
-    @torch.no_grad()
-    def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        """x [..., D] channel-last -> (softmax(-d / temp) over the K codes [..., K], hard code [...]):
-        a multinomial draw per token when `stochastic`, else the nearest code (quantize2_mask.py:193-205)."""
-        d = self.codebook.compute_distances(x)
-        soft = torch.softmax(d / (-temp), dim=-1)
-        if stochastic:
-            code = torch.multinomial(soft.reshape(-1, soft.shape[-1]), 1).reshape(soft.shape[:-1])
-        else:
-            code = torch.argmin(d, dim=-1)
-        return soft, code
-
-    def get_codebook_entry(self, indices, *kwargs):
-        return self.codebook.embed(indices)
-
-    def invalidate_codebook_cache(self):
-        self.codebook.invalidate_codebook_cache()
 
 
-class VectorQuantize2List(nn.Module):
+class VectorQuantize2List(_CodebookOps, nn.Module):
     """Reference modules/vector_quantization/quantize2_list.py:135-170 (class `VectorQuantize2` there): the input is a
     LIST of channel-last tensors x_i [..., D] (one per image, any number of tokens each); returns
     (list of x_q_i, loss, (None, None, list of codes_i)) with loss = mean over the items of
@@ -621,21 +626,6 @@ class VectorQuantize2List(nn.Module):
             code_list.append(codes.reshape(x.shape[:-1]))
         return xq_list, loss / n_items, (None, None, code_list)
 
-    @torch.no_grad()
-    def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        d = self.codebook.compute_distances(x)
-        soft = torch.softmax(d / (-temp), dim=-1)
-        if stochastic:
-            code = torch.multinomial(soft.reshape(-1, soft.shape[-1]), 1).reshape(soft.shape[:-1])
-        else:
-            code = torch.argmin(d, dim=-1)
-        return soft, code
-
-    def get_codebook_entry(self, indices, *kwargs):
-        return self.codebook.embed(indices)
-
-    def invalidate_codebook_cache(self):
-        self.codebook.invalidate_codebook_cache()
 
 
 class VectorQuantizer2(nn.Module):
