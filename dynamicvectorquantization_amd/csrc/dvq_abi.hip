@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 300   // 0.3.0
+#define DVQ_VERSION 310   // 0.3.1: the fused conv ops
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -28,12 +28,12 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st);
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv);
 int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
-                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st);
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
@@ -167,7 +167,7 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, nullptr, st);
+                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, nullptr, st, nullptr);
         return hip_rc(rc, "vq_assign_filter");     // the loss finalize is fused into its last kernel
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
@@ -180,6 +180,47 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
         if (rc) return hip_rc(rc, "vq_loss_finalize");
     }
     return DVQ_OK;
+}
+
+// ---- the 1x1 quant_conv fused into the assign (filter mode; D = 256) --------------------------------------------------
+static int conv_desc(const char *fn, const void *qconv_prep, float *h_buf, int h_all, int D, DvqConv *cv)
+{
+    if (!qconv_prep || !h_buf) { dvq_set_error("%s: qconv_prep and h_buf are required", fn); return DVQ_EINVAL; }
+    if (D != 256) { dvq_set_error("%s: the fused conv exists for D = 256 (got %d): use dvq_qconv_f32 + dvq_vq_assign_nchw_f32", fn, D); return DVQ_EUNSUPPORTED; }
+    if (((uintptr_t)qconv_prep & 255) != 0 || ((uintptr_t)h_buf & 3) != 0) { dvq_set_error("%s: qconv_prep must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    cv->meta = (const QconvMeta *)qconv_prep;
+    cv->wimg = (const char *)qconv_prep + 256;
+    cv->bias = (const float *)((const char *)qconv_prep + 256 + (size_t)(D / 32) * qconv_tile_bytes(D));
+    cv->h_buf = h_buf;
+    cv->h_all = h_all ? 1 : 0;
+    return DVQ_OK;
+}
+
+int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float *codebook, const void *prep,
+                            const float *mask, int B, int D, int HW, int K, float beta,
+                            float *zq, int64_t *codes, float *loss, float *h_buf, int h_all,
+                            void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    const char *fn = "dvq_vq_assign_qconv_f32";
+    if (!x || !codebook || !prep || !codes) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("%s: B=%d HW=%d K=%d must be positive", fn, B, HW, K); return DVQ_EINVAL; }
+    const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
+    if (mode != DVQ_MODE_FILTER && !pass1_only) { dvq_set_error("%s: mode %d (the conv is fused into the filter path only)", fn, mode); return DVQ_EINVAL; }
+    DvqConv cv;
+    int rc = conv_desc(fn, qconv_prep, h_buf, h_all, D, &cv);
+    if (rc) return rc;
+    const long N = (long)B * HW;
+    if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!ws || ws_bytes < dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER)) {
+        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER));
+        return DVQ_EWORKSPACE;
+    }
+    if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    double *partials = loss ? (double *)ws : nullptr;
+    rc = dvq_launch_filter(x, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
+                           (char *)ws + partials_bytes_for(N), pass1_only, false, loss, beta, nullptr, (hipStream_t)stream, &cv);
+    return hip_rc(rc, fn);
 }
 
 // token ids of a routed batch: at most one per output position
@@ -213,7 +254,8 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
                          const float *h_coarse, const float *h_median, const float *h_fine,
                          const float *codebook, const void *prep, int B, int D, int hc, int wc, int K, float beta,
                          float *zq, int64_t *codes, float *loss, int64_t *indices, float *cmask, int64_t *gate_out,
-                         void *ws, size_t ws_bytes, int mode, void *stream)
+                         void *ws, size_t ws_bytes, int mode, void *stream,
+                         const void *qconv_prep = nullptr, float *h_buf = nullptr, int h_all = 0, bool conv = false)
 {
     if (!gate || !h_coarse || !h_fine || !codebook || !prep || !codes || !indices || !cmask || (nb == 3 && !h_median)) {
         dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL;
@@ -227,6 +269,12 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
     if (pass1_only) mode = DVQ_MODE_FILTER;
     if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("%s: unknown mode %d", fn, mode); return DVQ_EINVAL; }
+    DvqConv cv;
+    if (conv) {
+        if (mode != DVQ_MODE_FILTER) { dvq_set_error("%s: mode %d (the conv is fused into the filter path only)", fn, mode); return DVQ_EINVAL; }
+        const int rcv = conv_desc(fn, qconv_prep, h_buf, h_all, D, &cv);
+        if (rcv) return rcv;
+    }
     const long N = (long)B * SC * hc * SC * wc;
     if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40) || B > 32768) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
     if (!dvq_filter_supported(D, SC * hc * SC * wc, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
@@ -241,7 +289,7 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     const int gmode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
     int rc = dvq_launch_routed(nb, gmode, gate, threshold, h_coarse, h_median, h_fine, prep, codebook, B, D, hc, wc, K,
                                beta, zq, (long long *)codes, loss, (long long *)indices, cmask, (long long *)gate_out,
-                               partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st);
+                               partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st, conv ? &cv : nullptr);
     return hip_rc(rc, fn);                                   // the loss finalize is part of the op in both modes
 }
 
@@ -270,6 +318,33 @@ int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
     return routed_common("dvq_vq_assign_routed_triple_f32", 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine,
                          codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, nullptr, ws, ws_bytes,
                          mode, stream);
+}
+
+int dvq_vq_assign_routed_qconv_dual_f32(const void *gate, int gate_kind, float threshold,
+                                        const float *h_coarse, const float *h_fine, const void *qconv_prep,
+                                        const float *codebook, const void *prep,
+                                        int B, int D, int hc, int wc, int K, float beta,
+                                        float *zq, int64_t *codes, float *loss,
+                                        int64_t *indices, float *cmask, int64_t *gate_out, float *h_buf, int h_all,
+                                        void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    return routed_common("dvq_vq_assign_routed_qconv_dual_f32", 2, gate, gate_kind, threshold, h_coarse, nullptr, h_fine,
+                         codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, gate_out, ws, ws_bytes,
+                         mode, stream, qconv_prep, h_buf, h_all, true);
+}
+
+int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
+                                          const float *h_coarse, const float *h_median, const float *h_fine,
+                                          const void *qconv_prep, const float *codebook, const void *prep,
+                                          int B, int D, int hc, int wc, int K, float beta,
+                                          float *zq, int64_t *codes, float *loss,
+                                          int64_t *indices, float *cmask, float *h_buf, int h_all,
+                                          void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    if (!h_median) { dvq_set_error("dvq_vq_assign_routed_qconv_triple_f32: null h_median"); return DVQ_EINVAL; }
+    return routed_common("dvq_vq_assign_routed_qconv_triple_f32", 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine,
+                         codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, nullptr, ws, ws_bytes,
+                         mode, stream, qconv_prep, h_buf, h_all, true);
 }
 
 int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx, int64_t n,

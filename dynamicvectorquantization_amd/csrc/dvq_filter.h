@@ -104,6 +104,33 @@ struct DvqRouted {
 // The G gate values of one cell, fetched (fetch) and reduced to the grain index (reduce) separately so that a kernel
 // can put other memory operations between the two.  Reduce = argmax with torch semantics (first maximal value wins,
 // NaN counts as the maximum); mode 2: entropy > thr (NaN compares false -> 0).
+// ---- 1x1 quant_conv (qconv.hip) shared with the CONV form of pass 1 ----------------------------------------------------
+struct QconvMeta {
+    int ok;            // weight finite
+    int b_exp;
+    float scale_w;     // 2^bw, 2^bw max|W| in [2^13, 2^14)
+    float inv_scale_w;
+    float pad[12];
+};
+__host__ __device__ inline size_t qconv_tile_bytes(int D) { return (size_t)2 * (D / 16) * 1024 + 256; }
+// MFMA row rho (0..31) of a weight tile -> output channel inside the tile: row = (r & 3) + 8 (r >> 2) + 4 h holds
+// channel 16 (r >> 3) + 8 h + (r & 7)  (r = accumulator register 0..15, h = lane half)
+__host__ __device__ inline int qconv_row_channel(int rho)
+{
+    const int r = (rho & 3) | ((rho >> 3) << 2), h = (rho >> 2) & 1;
+    return 16 * (r >> 3) + 8 * h + (r & 7);
+}
+// the conv fused into pass 1: weight images + meta of dvq_qconv_prepare_f32, and where the conv's output goes when it is
+// needed outside the kernel: h_buf [B, D, HW] receives the rows of the tokens pass 1 hands to the exact-list kernel (all
+// tokens with h_all != 0: tests)
+struct DvqConv {
+    const char *wimg;
+    const QconvMeta *meta;
+    const float *bias;     // channel order
+    float *h_buf;
+    int h_all;
+};
+
 struct DvqGateRaw { float f[3]; long long i[3]; };
 
 __device__ __forceinline__ DvqGateRaw dvq_gate_fetch(const void *gate, int mode, int G, size_t cell)

@@ -18,17 +18,9 @@
 // every store instruction writes 128-B runs of one output channel row.
 #include "dvq_filter.h"
 
-struct QconvMeta {
-    int ok;            // weight finite
-    int b_exp;
-    float scale_w;     // 2^bw, 2^bw max|W| in [2^13, 2^14)
-    float inv_scale_w;
-    float pad[12];
-};
-
-// prep buffer: [meta 256 B][tile t < D/32: hi image S16 KiB | lo image S16 KiB | bias 32 f32 + pad (256 B)]
-__host__ __device__ inline size_t qconv_tile_bytes(int D) { return (size_t)2 * (D / 16) * 1024 + 256; }
-size_t dvq_qconv_prep_bytes_impl(int D) { return 256 + (size_t)(D / 32) * qconv_tile_bytes(D); }
+// prep buffer: [meta 256 B][tile t < D/32: hi image S16 KiB | lo image S16 KiB | bias of the tile's 32 rows + pad (256 B)]
+//              [bias in channel order, D floats]   (QconvMeta, qconv_tile_bytes, qconv_row_channel: dvq_filter.h)
+size_t dvq_qconv_prep_bytes_impl(int D) { return 256 + (size_t)(D / 32) * qconv_tile_bytes(D) + (size_t)D * sizeof(float); }
 
 __global__ __launch_bounds__(1024) void qconv_meta_kernel(const float *__restrict__ Wt, int D, QconvMeta *__restrict__ meta)
 {
@@ -66,7 +58,10 @@ __global__ __launch_bounds__(1024) void qconv_meta_kernel(const float *__restric
     }
 }
 
-// image of tile t, k-step s, lane l, j < 8: W[32t + (l & 31)][16s + 8(l >> 5) + j]  (the A fragment of the MFMA)
+// image of tile t, k-step s, lane l, j < 8: W[32t + qconv_row_channel(l & 31)][16s + 8(l >> 5) + j]  (the A fragment of the
+// MFMA).  The MFMA rows of a tile are a PERMUTATION of its 32 output channels, chosen so that accumulator register r of lane
+// half h holds channel 32t + 16(r >> 3) + 8h + (r & 7): the (k-step, 8 channels per lane half) layout in which the assign's
+// pass 1 keeps its latents -- with the conv fused into pass 1 (CONV form) the accumulators ARE those registers.
 __global__ __launch_bounds__(256) void qconv_prep_kernel(const float *__restrict__ Wt, const float *__restrict__ bias,
                                                          int D, const QconvMeta *__restrict__ meta, char *__restrict__ img)
 {
@@ -81,16 +76,18 @@ __global__ __launch_bounds__(256) void qconv_prep_kernel(const float *__restrict
         char *tile = img + (size_t)t * tile_b;
         if (r < (int)per) {
             const int s = r >> 9, lane = (r >> 3) & 63, j = r & 7;
-            const int o = t * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+            const int o = t * 32 + qconv_row_channel(lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
             const float v = Wt[(size_t)o * D + k] * sw;
             const _Float16 hi = (_Float16)v;
             ((_Float16 *)tile)[r] = hi;
             ((_Float16 *)(tile + per * 2))[r] = (_Float16)(v - (float)hi);
         } else {
             const int q = r - (int)per;
-            ((float *)(tile + per * 4))[q] = (bias != nullptr) ? bias[t * 32 + q] : 0.0f;
+            ((float *)(tile + per * 4))[q] = (bias != nullptr) ? bias[t * 32 + qconv_row_channel(q)] : 0.0f;
         }
     }
+    float *bias_c = (float *)(img + (size_t)(D / 32) * tile_b);            // channel order, for the CONV form of pass 1
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D; i += gridDim.x * blockDim.x) bias_c[i] = (bias != nullptr) ? bias[i] : 0.0f;
 }
 
 template <int D, bool SEL>
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void qconv_kernel(
         xh[s] = __builtin_bit_cast(f16x8, ph);
         xl[s] = __builtin_bit_cast(f16x8, pl);
     }
-    float *hp = hout + ((size_t)b * D + 4 * h) * HW + pos;   // row o = 32t + (r&3) + 8(r>>2) + 4h
+    float *hp = hout + ((size_t)b * D + 8 * h) * HW + pos;   // register r = 4 g4 + q of lane half h: channel 32t + 16(r >> 3) + 8h + (r & 7)
 
     for (int t = 0; t < T; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void qconv_kernel(
                 const f32x4 b4 = *(const f32x4 *)(bias + 8 * g4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    hp[(size_t)(32 * t + q + 8 * g4) * HW] = __builtin_fmaf(acc[4 * g4 + q], unscale, b4[q]);
+                    hp[(size_t)(32 * t + 16 * (g4 >> 1) + 4 * (g4 & 1) + q) * HW] = __builtin_fmaf(acc[4 * g4 + q], unscale, b4[q]);
             }
         }
     }

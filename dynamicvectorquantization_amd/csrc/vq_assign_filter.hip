@@ -219,6 +219,16 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 //          into ring slots the code loop does not need yet and read back with ds_read_b32; the fine branch
 //          is read by every lane with the dense kernel's load pattern.  With the per-lane form (SEL = 1) the
 //          two / four waves that share a coarse line each fetched it (PMC: 2.1x the coarse bytes).
+//
+// CONV: the model's 1x1 quant_conv (qconv.hip) runs as the PROLOGUE: instead of loading its latents a wave computes them,
+//       h = W x + bias for its 32 tokens, on v_mfma_f32_32x32x16_f16 at fp32 grade (x = hi + lo per token, W = hi + lo,
+//       hi*hi + hi*lo + lo*hi; qconv.hip's arithmetic), streaming x in k-steps of 16 input channels (8 loads per lane, three
+//       k-steps in flight) and the weight images through the code ring's four slots (16 KiB per k-step: 8 row tiles x hi / lo).
+//       The rows of a weight tile are permuted (qconv_row_channel) so that the 128 accumulator registers of a lane ARE
+//       zf[s][j] in the layout the rest of the kernel expects; h never goes to memory (except the rows of tokens handed to
+//       the exact-list kernel, which reads them from cv.h_buf).  The per-token power-of-two scale of x follows the running
+//       maximum: when a k-step brings a value that would leave the fp16 range the accumulators are rescaled (exact, a
+//       workgroup-rare event), so no second pass over x is needed.
 // ---------------------------------------------------------------------------------------------
 #ifdef DVQ_TUNING
 // diagnostics of the tuning build only: per-workgroup clock stamps around the code loop (s_memtime / s_memrealtime,
@@ -238,14 +248,15 @@ __device__ __forceinline__ int dvq_cu_slot()
     return (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu));
 }
 
-template <int D, int SEL>
+template <int D, int SEL, bool CONV>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, int *__restrict__ cu_lock)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, int *__restrict__ cu_lock, const DvqConv cv)
 {
+    static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     constexpr int NW = 4;
     constexpr int S16 = D / 16;
     constexpr int S32 = S16 / 2;
@@ -303,6 +314,118 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     int sel_g = 0;                                           // SEL == 2: grain of this lane's cell
     unsigned stg_a = 0, stg_b = 0;                           // SEL == 2: LDS byte address of this lane's value of channel 8h in the
                                                              // image of the 2x-coarser / 4x-coarser branch
+    // ---- CONV: h = W x + bias into zf (see the header).  zp = this lane's x at input channel 8h, st = channel stride.
+    auto conv_prologue = [&](const float *zp, size_t st) __attribute__((always_inline)) {
+        constexpr int QIMG = S16 * 1024;                     // one weight image (hi or lo) of a row tile
+        constexpr int QTILE = 2 * QIMG + 256;
+        float *bias_l = enraw;                               // [D] bias, channel order (the seeds area is idle until the code loop)
+        // group k = the weight images of k-step k (4 pieces of 1 KiB per wave -> ring slot k & 3: [row tile][hi | lo]) and this
+        // lane's 8 x values of it.  All of it asm / DMA with counted waits: 12 vector-memory operations per group and wave.
+        float xr[3][8];
+        const float *xp = zp;
+        auto issue_group = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 4 * wave + q;                  // piece: row tile i >> 1, hi / lo i & 1
+                glds16(cv.wimg + (size_t)(i >> 1) * QTILE + (i & 1) * QIMG + k * 1024 + lane * 16,
+                       lds + (k & 3) * IMG_BYTES + i * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
+                xp += st;
+            }
+            xp += 8 * st;                                    // the other lane half's 8 channels
+        };
+        glds4(cv.bias + wave * 64 + lane, bias_l + wave * 64);
+        issue_group(0);
+        issue_group(1);
+        issue_group(2);
+        f32x16 acc[8];
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t8][r] = 0.0f;
+        int ea = 100;                                        // x is scaled by 2^ea (per token; both lane halves agree)
+        float sa = ldexpf(1.0f, 100);
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            // group s has landed for this wave: at most the two younger groups are outstanding
+            if (s <= S16 - 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (s == S16 - 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(xr[s % 3][j])); xv[j] = xr[s % 3][j]; }
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = vmax_abs(m, xv[j]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            // the scale follows the running maximum: a value that would reach 2^15 after scaling moves it (exact rescale of
+            // the accumulators by a power of two; wave-uniform branch, rare after the first k-steps)
+            const bool grow = (m > 0.0f) && (m < __builtin_inff()) && (m * sa >= 32768.0f);
+            if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+                int e;
+                (void)frexpf(grow ? m : 1.0f, &e);
+                int en = 14 - e;
+                en = en > 100 ? 100 : (en < -100 ? -100 : en);
+                en = grow ? en : ea;
+                if (s > 0) {
+                    const float f = ldexpf(1.0f, en - ea);
+#pragma unroll
+                    for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t8][r] *= f;
+                }
+                ea = en;
+                sa = ldexpf(1.0f, ea);
+            }
+            u32x4 ph, pl;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float v0 = xv[2 * j2] * sa, v1 = xv[2 * j2 + 1] * sa;
+                const f32x2 vv = {v0, v1};
+                const f16x2 hh = __builtin_convertvector(vv, f16x2);
+                const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};
+                const f16x2 ll = __builtin_convertvector(rr, f16x2);
+                ph[j2] = __builtin_bit_cast(unsigned, hh);
+                pl[j2] = __builtin_bit_cast(unsigned, ll);
+            }
+            const f16x8 xh = __builtin_bit_cast(f16x8, ph), xl = __builtin_bit_cast(f16x8, pl);
+            __builtin_amdgcn_s_barrier();                    // k-step s of the weights landed (everybody's pieces); s - 1 consumed
+            asm volatile("" ::: "memory");
+            if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers just converted
+            const char *buf = lds + (s & 3) * IMG_BYTES;
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const f16x8 ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
+                const f16x8 al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[t8], 0, 0, 0);
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[t8], 0, 0, 0);
+            }
+        }
+        const float unscale = ldexpf(cv.meta->inv_scale_w, -ea);
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            const f32x4 b0 = *(const f32x4 *)(bias_l + 16 * s + 8 * h), b1v = *(const f32x4 *)(bias_l + 16 * s + 8 * h + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                zf[s][j] = __builtin_fmaf(acc[s >> 1][8 * (s & 1) + j], unscale, (j < 4) ? b0[j & 3] : b1v[j & 3]);
+            __builtin_amdgcn_sched_barrier(0);               // in place, one k-step's bias at a time (hoisted bias reads spill)
+        }
+        if (cv.h_all && n >= 0) {                            // tests: the conv's output for every token
+            float *hp = cv.h_buf + token_base();
+#pragma unroll
+            for (int s = 0; s < S16; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
+        }
+        __builtin_amdgcn_s_barrier();                        // every wave is done with the weight slots and the bias:
+        asm volatile("" ::: "memory");                       // the ring and the seeds area go to the code tiles
+        for (int t = 0; t < 3; ++t) issue(t);
+        __builtin_amdgcn_sched_barrier(0);                   // (the conversion below must not be hoisted over this: all of zf is ready)
+    };
     if (SEL != 0) {
         // the router select, fused in: grain of this position's cell straight from the gate, source = the branch
         // that won the cell; indices / codebook_mask / the int64 gate are written here as by-products.
@@ -333,16 +456,20 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         if (SEL == 1) {
             const int g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
             by_products(g);
-            for (int t = 0; t < pre; ++t) issue(t);
             int stride_l;
             const float *zp = dvq_dense_source(rv, b, y, x, g, stride_l) + (size_t)8 * h * stride_l;
             const size_t st = (size_t)stride_l;
+            if constexpr (CONV) {
+                conv_prologue(zp, st);
+            } else {
+            for (int t = 0; t < pre; ++t) issue(t);
             __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int s = 0; s < S16; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_SEL(zp + (size_t)(16 * s + j) * st);
             __builtin_amdgcn_s_setprio(0);
+            }
         } else {
             for (int t = 0; t < pre; ++t) issue(t);
             // workgroup = output rows y0 .. y0 + 3 of image b (wave = row, lane = column); both are wave-uniform
@@ -383,6 +510,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             sel_g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
             by_products(sel_g);
         }
+    } else if constexpr (CONV) {
+        conv_prologue(z + token_base(), (size_t)HW);
     } else {
         for (int t = 0; t < pre; ++t) issue(t);
         const float *zp = z + token_base();
@@ -450,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 }
             }
             zprev = zcur;
+            if constexpr (CONV) __builtin_amdgcn_sched_barrier(0);   // zf is complete before the loop: keep the k-steps in order
         }
         float t8[8];
 #pragma unroll
@@ -672,6 +802,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         int pos = atomicAdd(&counters[1], 1);
         exact_list[pos] = n;
     }
+    auto spill_h = [&]() {                                  // CONV: the exact-list kernel reads this token's h from cv.h_buf
+        float *hp = cv.h_buf + token_base();
+#pragma unroll
+        for (int s = 0; s < S16; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
+    };
+    if (CONV && valid && hopeless && !cv.h_all) spill_h();
     float lsum = 0.0f;
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
@@ -719,6 +857,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 int pos = atomicAdd(&counters[1], 1);       // by the exact-list kernel, the loss term is dropped here
                 exact_list[pos] = n;
             }
+            if (CONV && !cv.h_all) spill_h();
             lsum = 0.0f;
             slot = -1;
         }
@@ -1652,21 +1791,22 @@ static bool staged_select_ok(const DvqRouted &rv)
     return true;
 }
 
-template <int D, int SEL>
+template <int D, int SEL, bool CONV = false>
 static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta *meta, const float *E,
                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
-                             double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st)
+                             double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st,
+                             const DvqConv &cv = DvqConv{})
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
-    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL>, (int)shmem1, &done);
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, CONV>, (int)shmem1, &done);
     if (rc) return rc;
     const unsigned grid = (unsigned)((N + 127) / 128);
     // anti-phase pays when every CU holds two workgroups for more than one generation
     int *lock = (g_tune.antiphase && grid >= 1024) ? w.counters + DVQ_LOCK0 : nullptr;
-    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL>), dim3(grid), dim3(256), shmem1, st,
+    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, rv, lock);
+                       w.cap / DVQ_QSHARDS, rv, lock, cv);
     return (int)hipGetLastError();
 }
 
@@ -1674,10 +1814,20 @@ template <int D>
 static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                         const float *mask, int HW, int K, long N, float *zq, long long *codes,
                         double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
-                        hipStream_t st)
+                        hipStream_t st, const DvqConv *cv = nullptr)
 {
     const int nb1 = (int)((N + 127) / 128);
     const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
+    if (cv != nullptr) {                                     // the 1x1 conv as the prologue (D = 256; the ABI layer checked)
+        if constexpr (D == 256) {
+            const DvqRouted none = {};
+            if (rv != nullptr)
+                return launch_pass1_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *cv);
+            return launch_pass1_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *cv);
+        } else {
+            return -1000;
+        }
+    }
 #ifdef DVQ_TUNING
     // tuning build: the persistent role-alternating form (vq_assign_pipe.hip; measured slower so far, see its header)
     if (g_tune.pipe && !force_wide && dvq_pipe_supported(D, HW, K, N, rv) && (rv == nullptr || staged_select_ok(*rv)))
@@ -1736,7 +1886,7 @@ static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, con
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st)
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
@@ -1753,9 +1903,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     if (rc) return rc;
     const int np1 = (int)((N + 127) / 128);
     switch (D) {
-    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
-    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
-    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st); break;
+    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
+    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
+    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;
@@ -1768,6 +1918,10 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + 4,
                               np1 + w.cap / RES_SLOTS + list_blocks(N),
                               1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS};
+    // conv fused in: the tokens on the list have their conv output in cv->h_buf (dense layout), written by pass 1
+    if (cv != nullptr)
+        return dvq_launch_exact_list(cv->h_buf, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
+                                     w.exact_list, w.counters + 1, tail, nullptr, st);
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
                                  w.exact_list, w.counters + 1, tail, rv, st);
 }
@@ -1786,7 +1940,7 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
-                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st)
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv)
 {
     const int SC = (G == 2) ? 2 : 4;
     const int Wout = SC * wc, HWout = SC * hc * Wout;
@@ -1815,5 +1969,5 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
         return dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
     }
     return dvq_launch_filter(nullptr, prep, E, cmask, D, HWout, K, N, zq, codes, partials, ws_extra, pass1_only, false,
-                             loss, beta, &rv, st);
+                             loss, beta, &rv, st, cv);
 }

@@ -51,13 +51,31 @@ def _can_fuse_conv(quantize, quant_conv, *feats):
     return all(t.is_cuda and t.dtype == torch.float32 for t in feats)
 
 
+def _can_route_conv(quantize, quant_conv, *feats):
+    """the whole chain select -> 1x1 quant_conv -> quantizer as ONE routed op with the conv as pass 1's prologue
+    (dvq_vq_assign_routed_qconv_*): the routed op's preconditions, a fusable conv, 256 channels, the filter path"""
+    return (_can_fuse_conv(quantize, quant_conv, *feats) and feats[0].shape[1] == 256
+            and _can_route(quantize, None, *feats) and quantize.assign_mode == _lib.MODE_FILTER)
+
+
 def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0):
     """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode
     (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).  Inference paths (no autograd):
       * no quant_conv: gate + routing tail + quantizer as ONE routed op (the select fused into the assign);
-      * a 1x1 quant_conv: select + conv as one kernel (no h_dual), then the dense assign;
+      * a 1x1 quant_conv on 256 channels: the same ONE op with the conv as its prologue (h_dual and the conv's output are
+        never written); other channel counts: select + conv as one kernel, then the dense assign;
     otherwise route select -> quant_conv -> dense assign as differentiable pieces."""
     fixed = isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda
+    if _can_route_conv(quantize, quant_conv, h_coarse, h_fine):
+        cb = quantize.codebook
+        kw = dict(beta=quantize.beta, mode=quantize.assign_mode, conv=quant_conv)
+        if fixed:
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
+                                      threshold=router.fine_grain_threshold, **kw)
+        else:
+            gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, gate=gate, **kw)
+        return r["zq"], r["loss"][1], (None, None, r["codes"]), r["indices"], r["gate"].permute(0, 3, 1, 2)
     if _can_fuse_conv(quantize, quant_conv, h_coarse, h_fine):
         if fixed:
             sel = qconv.quant_conv_select(quant_conv, h_coarse, h_fine, entropy=entropy,
@@ -92,6 +110,11 @@ def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=Non
 def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None, temp=0.0):
     """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77)."""
     gate = router(h_fine=h_fine, h_median=h_median, h_coarse=h_coarse, entropy=None)
+    if _can_route_conv(quantize, quant_conv, h_coarse, h_median, h_fine):
+        cb = quantize.codebook
+        r = vq_assign_routed_triple(h_coarse, h_median, h_fine, cb.codes, cb._prep, gate, beta=quantize.beta,
+                                    mode=quantize.assign_mode, conv=quant_conv)
+        return r["zq"], r["loss"][1], (None, None, r["codes"]), r["indices"], gate.permute(0, 3, 1, 2)
     if _can_fuse_conv(quantize, quant_conv, h_coarse, h_median, h_fine):
         sel = qconv.quant_conv_select(quant_conv, h_coarse, h_fine, h_median=h_median, gate=gate)
         quant, emb_loss, info = quantize(x=sel["h"], temp=temp, codebook_mask=sel["codebook_mask"])
@@ -110,7 +133,13 @@ def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None,
 
 
 def encode_fixed(quantize, h, quant_conv=None):
-    """-> (quant, emb_loss, info) as VQModel.encode (fixed granularity, models/stage1/vqgan.py:68-72)."""
+    """-> (quant, emb_loss, info) as VQModel.encode (fixed granularity, models/stage1/vqgan.py:68-72).  An eval-mode
+    VectorQuantize2 behind a 1x1 conv on 256 channels runs as one op (the conv is the assign's prologue)."""
+    if quant_conv is not None and h.dim() == 4 and _can_route_conv(quantize, quant_conv, h):
+        from .quantize import vq_assign
+        cb = quantize.codebook
+        zq, codes, loss = vq_assign(h, cb.codes, cb._prep, None, beta=quantize.beta, mode=quantize.assign_mode, conv=quant_conv)
+        return zq, loss[1], (None, None, codes)
     if quant_conv is not None:
         h = qconv.quant_conv(quant_conv, h) if _can_fuse_conv(quantize, quant_conv, h) else quant_conv(h)
     return quantize(h)

@@ -121,12 +121,36 @@ class _CodebookPrep:
         return (int(c[0]), int(c[1]))
 
 
+def _conv_args(conv, prep, shape, device, h_buf):
+    """(prepared conv buffer, h_buf, h_all) for the ops with the 1x1 quant_conv fused in.  h_buf [B, D, *spatial]: pass 1 writes
+    there the conv output of the few tokens it hands to the exact-list kernel (ALL tokens when the caller gives the tensor:
+    tests); without one a scratch tensor cached on the codebook's prep is used."""
+    from . import qconv as _qconv
+    if not _qconv.usable(conv) or conv.in_channels != 256:
+        raise _lib.DvqError("fused quant_conv: needs a 1x1 nn.Conv2d(256, 256) on the GPU (other sizes: quant_conv + vq_assign)")
+    h_all = h_buf is not None
+    if h_buf is None:
+        key = ("hbuf",) + tuple(shape) + (str(device),)
+        h_buf = prep._scratch.get(key) if hasattr(prep, "_scratch") else None
+        if h_buf is None:
+            if not hasattr(prep, "_scratch"):
+                prep._scratch = {}
+            prep._scratch.clear()
+            h_buf = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+            prep._scratch[key] = h_buf
+    elif tuple(h_buf.shape) != tuple(shape) or h_buf.dtype != torch.float32 or not h_buf.is_contiguous() or h_buf.device != device:
+        raise ValueError("h_buf must be a contiguous f32 tensor %s on %s" % (tuple(shape), device))
+    return _qconv._prep_of(conv).get(conv), h_buf, h_all
+
+
 def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=True,
-              mode=_lib.MODE_FILTER, out=None):
+              mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
     """z [B, D, *spatial] f32 cuda, codebook [K, D] -> (zq or None, codes [B, *spatial] i64, loss[2] or None).
 
     loss[0] = mean((e - z)^2 * mask), loss[1] = beta*mean + mean.  `out` may carry preallocated
-    (zq, codes, loss) tensors (used by the benchmark / graph capture)."""
+    (zq, codes, loss) tensors (used by the benchmark / graph capture).
+    conv: a 1x1 nn.Conv2d(256, 256) applied to z first INSIDE the assign kernel (`dvq_vq_assign_qconv_f32`: the model's
+    quant_conv; its output never reaches memory).  h_buf: see _conv_args."""
     z = _lib.require_cuda_f32(z, "z")
     codebook = _lib.require_cuda_f32(codebook, "codebook")
     B, D = z.shape[0], z.shape[1]
@@ -152,6 +176,15 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
             loss.fill_(float("nan"))
         return zq, codes, loss
     ws = prep.workspace(B, D, HW, K, mode, z.device)
+    if conv is not None:
+        with torch.cuda.device(z.device):
+            qbuf, hb, h_all = _conv_args(conv, prep, z.shape, z.device, h_buf)
+            pbuf = prep.get(codebook)
+            _lib.check(_lib_handle.dvq_vq_assign_qconv_f32(
+                z.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
+                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(), mode,
+                _lib.stream_ptr(z.device)), "dvq_vq_assign_qconv_f32")
+        return zq, codes, loss
     with torch.cuda.device(z.device):
         pbuf = prep.get(codebook)
         _lib.check(_lib_handle.dvq_vq_assign_nchw_f32(
@@ -184,14 +217,16 @@ def _routed_outputs(h_fine, B, hc, wc, S, want_zq, want_loss, with_gate):
 
 
 def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=None, threshold=None, beta=0.25,
-                          want_zq=True, want_loss=True, mode=_lib.MODE_FILTER, out=None):
+                          want_zq=True, want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
     """Routing tail of DualGrainEncoder (EncoderDual.py:134-149) + VectorQuantize2.forward
     (quantize2_mask.py:157-191) as ONE op on the unique tokens (`dvq_vq_assign_routed_dual_f32`):
     h_coarse [B, D, hc, wc], h_fine [B, D, 2hc, 2wc]; either `gate` [B, hc, wc, 2] (f32 logits / int64) or
     `entropy` [B, hc, wc] + `threshold` (the fixed-entropy router fused in).
     -> dict(zq, codes [B, 2hc, 2wc] i64, loss[2], indices [B, hc, wc] i64, codebook_mask [B, 1, 2hc, 2wc],
             gate (entropy form: the router's int64 gate [B, hc, wc, 2], else the input gate)).
-    `out` = (zq, codes, loss, indices, codebook_mask, gate_out) preallocated (benchmark / graph capture)."""
+    `out` = (zq, codes, loss, indices, codebook_mask, gate_out) preallocated (benchmark / graph capture).
+    conv: the model's 1x1 quant_conv between select and quantizer, fused in (`dvq_vq_assign_routed_qconv_dual_f32`): the
+    order every reference checkpoint runs (dqvae_dual_entropy.py:124-134), one kernel chain, h never written."""
     h_coarse = _lib.require_cuda_f32(h_coarse, "h_coarse")
     h_fine = _lib.require_cuda_f32(h_fine, "h_fine")
     codebook = _lib.require_cuda_f32(codebook, "codebook")
@@ -227,6 +262,16 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
     if nbytes == 0:
         raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
     ws = prep.workspace(B, D, ("routed2", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    if conv is not None:
+        with torch.cuda.device(h_fine.device):
+            qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
+            pbuf = prep.get(codebook)
+            _lib.check(_lib_handle.dvq_vq_assign_routed_qconv_dual_f32(
+                g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(),
+                pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss),
+                indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(),
+                mode, _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_dual_f32")
+        return res
     with torch.cuda.device(h_fine.device):
         pbuf = prep.get(codebook)
         _lib.check(_lib_handle.dvq_vq_assign_routed_dual_f32(
@@ -238,7 +283,7 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
 
 
 def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, beta=0.25, want_zq=True,
-                            want_loss=True, mode=_lib.MODE_FILTER, out=None):
+                            want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
     """Routing tail of TripleGrainEncoder (EncoderTriple.py:148-176) + VectorQuantize2.forward as ONE op on the
     unique tokens (`dvq_vq_assign_routed_triple_f32`): h_coarse [B, D, hc, wc], h_median [B, D, 2hc, 2wc],
     h_fine [B, D, 4hc, 4wc], gate [B, hc, wc, 3].  -> dict as vq_assign_routed_dual.
@@ -269,6 +314,16 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
     if nbytes == 0:
         raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
     ws = prep.workspace(B, D, ("routed3", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    if conv is not None:
+        with torch.cuda.device(h_fine.device):
+            qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
+            pbuf = prep.get(codebook)
+            _lib.check(_lib_handle.dvq_vq_assign_routed_qconv_triple_f32(
+                g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
+                codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(),
+                _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(),
+                mode, _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_triple_f32")
+        return res
     with torch.cuda.device(h_fine.device):
         pbuf = prep.get(codebook)
         _lib.check(_lib_handle.dvq_vq_assign_routed_triple_f32(

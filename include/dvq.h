@@ -189,6 +189,40 @@ int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, floa
                          int B, int D, int hc, int wc, float *h, int64_t *indices, float *cmask, int64_t *gate_out,
                          void *stream);
 
+/*
+ * The model order as ONE op: [select ->] 1x1 quant_conv -> assign, with the conv as the PROLOGUE of the assign's pass 1
+ * (reference: `h = self.quant_conv(h_dual)` between the routing tail and `self.quantize`, dqvae_dual_entropy.py:124-134,
+ * dqvae_dual_feat.py:59-68, dqvae_triple_feat.py:68-77, vqgan.py:68-72).  Each wave computes its tokens' conv output
+ * straight into the registers pass 1 keeps its latents in (same split-fp16 arithmetic as dvq_qconv_f32; the per-token
+ * scale follows the running maximum of the input channels): neither h_dual / h_triple nor the conv's output is written.
+ * Contract: the conv output h the op scores is within 1e-5 * sum |w||x| of the fp64 conv; codes, z_q and loss are
+ * bit-exact GIVEN that h.  D = 256 and DVQ_MODE_FILTER (or DVQ_MODE_FILTER_PASS1) only -- other sizes: dvq_qconv_* followed
+ * by the assign (DVQ_EUNSUPPORTED otherwise).
+ *   qconv_prep   the buffer dvq_qconv_prepare_f32 filled
+ *   h_buf        [B, D, HW] floats, REQUIRED: receives the conv output of the tokens pass 1 hands to the exact-list kernel
+ *                (non-finite or out-of-range latents, queue overflow), which reads them from there; with h_all != 0 the
+ *                conv output of EVERY token (how the tests check the contract above).  Other rows are not touched.
+ *   everything else as dvq_vq_assign_nchw_f32 / dvq_vq_assign_routed_{dual,triple}_f32 (x / h_coarse.. = the conv's INPUT)
+ */
+int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float *codebook, const void *prep,
+                            const float *mask, int B, int D, int HW, int K, float beta,
+                            float *zq, int64_t *codes, float *loss, float *h_buf, int h_all,
+                            void *ws, size_t ws_bytes, int mode, void *stream);
+int dvq_vq_assign_routed_qconv_dual_f32(const void *gate, int gate_kind, float threshold,
+                                        const float *h_coarse, const float *h_fine, const void *qconv_prep,
+                                        const float *codebook, const void *prep,
+                                        int B, int D, int hc, int wc, int K, float beta,
+                                        float *zq, int64_t *codes, float *loss,
+                                        int64_t *indices, float *cmask, int64_t *gate_out, float *h_buf, int h_all,
+                                        void *ws, size_t ws_bytes, int mode, void *stream);
+int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
+                                          const float *h_coarse, const float *h_median, const float *h_fine,
+                                          const void *qconv_prep, const float *codebook, const void *prep,
+                                          int B, int D, int hc, int wc, int K, float beta,
+                                          float *zq, int64_t *codes, float *loss,
+                                          int64_t *indices, float *cmask, float *h_buf, int h_all,
+                                          void *ws, size_t ws_bytes, int mode, void *stream);
+
 /* Audit aid (tools/bound_audit.py, tests/test_bound_audit.py): the pass-1 score arithmetic of DVQ_MODE_FILTER on
  * n tokens given as rows [n, D] -- every fp16-MFMA score G_j ~ -2^(b-1) (d_j - xn) as pass 1 sees it (index bits
  * packed into the low mantissa bits), the per-token decision threshold 2W, the exact norm xn and the codebook scale

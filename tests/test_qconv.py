@@ -85,13 +85,118 @@ def test_qconv_select_dual_and_triple(dev, oracle_mod):
     assert (np.abs(r["h"].cpu().numpy() - ref) / mag).max() < 2e-6
 
 
-def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
-    """the real encode order select -> quant_conv -> quantize (dqvae_dual_feat.py:59-68) through encode_dual: codes
-    / z_q bit-exact GIVEN the kernel's conv output; code match rate vs the fp64 conv-then-quantize order"""
+def _nan_equal(a, b):
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 7, 9), (2, 32, 32), (9, 16, 16)])
+def test_fused_conv_assign_dense(dev, oracle_mod, B, H, W):
+    """dvq_vq_assign_qconv_f32: the conv as pass 1's prologue.  With h_buf the op also writes the conv output it scored:
+    that h is within the conv's tolerance of the fp64 conv, and codes / z_q / loss are bit-exact GIVEN it (oracle); without
+    h_buf (production: h never written) the same bits come out; ragged token counts, masks, scale jumps between k-steps,
+    NaN / Inf / huge inputs (exact-list path, reads the spilled h rows)."""
     from dynamicvectorquantization_amd import synth
-    from dynamicvectorquantization_amd.encode import encode_dual, encode_fixed, encode_triple
-    from dynamicvectorquantization_amd.qconv import quant_conv_select
-    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    K, D = 1024, 256
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = synth.codebook_trained(K, D)
+    conv = _conv(dev, D, 600 + B)
+    x = synth.z_tokens(E, B, H, W, 610 + B)
+    x[0, :, 0, 0] *= np.float32(1e-3)
+    x[1, 5, 3, 3] = 40.0                                   # one large channel late in a token: the running scale moves
+    x[1, :16, 1, 1] = 1e-6
+    x[0, 200:, 2, 2] *= np.float32(1e4)
+    mask = np.where(synth.bernoulli(620 + B, (B, 1, H, W), 0.5), 1.0, 0.25).astype(np.float32)
+    hb = torch.empty((B, D, H, W), device=dev)
+    zq, codes, loss = vq_assign(t(x), t(E), _CodebookPrep(), t(mask), conv=conv, h_buf=hb)
+    h = hb.cpu().numpy()
+    ref, mag = _ref64(conv, x)
+    assert (np.abs(h - ref) / mag).max() < 2e-6
+    o = oracle_mod.vq_assign_nchw(h, E, mask)
+    assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+    ol = float(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    assert abs(float(loss[1]) - ol) <= 1e-5 * abs(ol)
+    zq2, codes2, loss2 = vq_assign(t(x), t(E), _CodebookPrep(), t(mask), conv=conv)          # production form
+    assert torch.equal(codes, codes2) and torch.equal(zq, zq2) and torch.equal(loss, loss2)
+    zq3, codes3, _ = vq_assign(t(x), t(E), _CodebookPrep(), t(mask), conv=conv, want_zq=False, want_loss=False)
+    assert zq3 is None and torch.equal(codes, codes3)
+    # special values
+    xs = x.copy()
+    xs[0, 7, 2, 2] = np.nan; xs[1, :, 5, 5] = np.inf; xs[2 % B, :, 6, 6] *= np.float32(1e30); xs[0, :, 1, 0] = 0.0
+    hb2 = torch.empty_like(hb)
+    zq4, codes4, _ = vq_assign(t(xs), t(E), _CodebookPrep(), t(mask), conv=conv, h_buf=hb2)
+    o4 = oracle_mod.vq_assign_nchw(hb2.cpu().numpy(), E, mask)
+    assert np.array_equal(codes4.cpu().numpy().reshape(B, -1), o4["codes"]) and _nan_equal(zq4.cpu().numpy(), o4["zq"])
+    zq5, codes5, _ = vq_assign(t(xs), t(E), _CodebookPrep(), t(mask), conv=conv)             # h rows spilled for the exact list
+    assert torch.equal(codes4, codes5) and _nan_equal(zq4.cpu().numpy(), zq5.cpu().numpy())
+
+
+def test_fused_conv_assign_routed_dual_and_triple(dev, oracle_mod):
+    """dvq_vq_assign_routed_qconv_{dual,triple}_f32: select -> conv -> assign as one op: the select's by-products bit-exact
+    vs the oracle, h = conv(oracle select) within the tolerance, codes / z_q / loss exact given h"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
+    K, D, B = 1024, 256, 6
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = synth.codebook_trained(K, D)
+    conv = _conv(dev, D, 700)
+    hf, hc = synth.z_tokens(E, B, 32, 32, 701), synth.z_tokens(E, B, 16, 16, 702)
+    ent = synth.entropy_map(703, B, 16, 16)
+    ent[0, 0, 0] = np.float32(THR); ent[1, 2, 3] = np.nan
+    for gate_kw, og in ((dict(entropy=t(ent), threshold=THR), oracle_mod.entropy_gate(ent, THR)),
+                        (dict(gate=t(synth.normal(704, (B, 16, 16, 2)))), synth.normal(704, (B, 16, 16, 2)))):
+        hb = torch.empty((B, D, 32, 32), device=dev)
+        r = vq_assign_routed_dual(t(hc), t(hf), t(E), _CodebookPrep(), conv=conv, h_buf=hb, **gate_kw)
+        osel = oracle_mod.route_select_dual(og, hc, hf)
+        assert np.array_equal(r["indices"].cpu().numpy(), osel["indices"])
+        assert np.array_equal(r["codebook_mask"].cpu().numpy(), osel["codebook_mask"])
+        if "entropy" in gate_kw:
+            assert np.array_equal(r["gate"].cpu().numpy(), og)
+        h = hb.cpu().numpy()
+        ref, mag = _ref64(conv, osel["h_dual"])
+        assert (np.abs(h - ref) / mag).max() < 2e-6
+        o = oracle_mod.vq_assign_nchw(h, E, osel["codebook_mask"])
+        assert np.array_equal(r["codes"].cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(r["zq"].cpu().numpy(), o["zq"])
+        ol = float(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+        assert abs(float(r["loss"][1]) - ol) <= 1e-5 * abs(ol)
+        r2 = vq_assign_routed_dual(t(hc), t(hf), t(E), _CodebookPrep(), conv=conv, **gate_kw)
+        assert torch.equal(r["codes"], r2["codes"]) and torch.equal(r["zq"], r2["zq"]) and torch.equal(r["loss"], r2["loss"])
+    # triple, ragged 12 x 20 grid (odd coarse width), no bias
+    conv3 = _conv(dev, D, 710, bias=False)
+    hf3, hm3, hc3 = synth.z_tokens(E, 3, 12, 20, 711), synth.z_tokens(E, 3, 6, 10, 712), synth.z_tokens(E, 3, 3, 5, 713)
+    lg = synth.grain_logits_triple(714, 3, 3, 5)
+    hb = torch.empty((3, D, 12, 20), device=dev)
+    r = vq_assign_routed_triple(t(hc3), t(hm3), t(hf3), t(E), _CodebookPrep(), t(lg), conv=conv3, h_buf=hb)
+    osel = oracle_mod.route_select_triple(lg, hc3, hm3, hf3)
+    assert np.array_equal(r["indices"].cpu().numpy(), osel["indices"]) and np.array_equal(r["codebook_mask"].cpu().numpy(), osel["codebook_mask"])
+    h = hb.cpu().numpy()
+    ref, mag = _ref64(conv3, osel["h_triple"])
+    assert (np.abs(h - ref) / mag).max() < 2e-6
+    o = oracle_mod.vq_assign_nchw(h, E, osel["codebook_mask"])
+    assert np.array_equal(r["codes"].cpu().numpy().reshape(3, -1), o["codes"]) and np.array_equal(r["zq"].cpu().numpy(), o["zq"])
+
+
+def test_fused_conv_refuses_what_it_cannot_do(dev):
+    from dynamicvectorquantization_amd import _lib, synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    E = torch.from_numpy(synth.codebook_trained(64, 128)).to(dev)
+    x = torch.zeros((1, 128, 4, 4), device=dev)
+    with pytest.raises(_lib.DvqError):                     # 128 channels: the two-kernel path is the one to use
+        vq_assign(x, E, _CodebookPrep(), None, conv=_conv(dev, 128, 800))
+    E2 = torch.from_numpy(synth.codebook_trained(64, 256)).to(dev)
+    with pytest.raises(_lib.DvqError):                     # exact mode has no conv prologue
+        vq_assign(torch.zeros((1, 256, 4, 4), device=dev), E2, _CodebookPrep(), None, conv=_conv(dev, 256, 801), mode=_lib.MODE_EXACT)
+
+
+def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
+    """the real encode order select -> quant_conv -> quantize (dqvae_dual_feat.py:59-68) through encode_dual, which runs it
+    as ONE routed op with the conv as the assign's prologue: equal to that op called directly (whose codes / z_q are exact
+    given the h it reports, previous tests); code match rate vs the fp64 conv-then-quantize order; a conv the kernels cannot
+    take (not a plain nn.Conv2d) falls back to torch's conv and agrees up to near-ties; 128 channels take the two-kernel path"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual, encode_fixed
+    from dynamicvectorquantization_amd.qconv import quant_conv, quant_conv_select
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, _CodebookPrep, vq_assign, vq_assign_routed_dual
     from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
     B, K, D = 8, 1024, 256
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -102,11 +207,14 @@ def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
     router = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
     vq = VectorQuantize2(K, D).to(dev).eval()
     vq.codebook.weight.data[:-1].copy_(t(E))
+    hb = torch.empty((B, D, 32, 32), device=dev)
     with torch.no_grad():
         quant, loss, info, grain, gate = encode_dual(router, vq, t(hf), t(hc), entropy=t(ent), quant_conv=conv)
-        sel = quant_conv_select(conv, t(hc), t(hf), entropy=t(ent), threshold=router.fine_grain_threshold)
-    h = sel["h"].cpu().numpy()
-    o = oracle_mod.vq_assign_nchw(h, E, sel["codebook_mask"].cpu().numpy())
+        r = vq_assign_routed_dual(t(hc), t(hf), t(E), _CodebookPrep(), entropy=t(ent), threshold=router.fine_grain_threshold,
+                                  conv=conv, h_buf=hb)
+    assert torch.equal(info[2], r["codes"]) and torch.equal(quant, r["zq"]) and float(loss) == float(r["loss"][1])
+    h = hb.cpu().numpy()
+    o = oracle_mod.vq_assign_nchw(h, E, r["codebook_mask"].cpu().numpy())
     codes = info[2].cpu().numpy().reshape(B, -1)
     assert np.array_equal(codes, o["codes"]) and np.array_equal(quant.cpu().numpy(), o["zq"])
     assert abs(float(loss) - float(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))) <= 1e-5 * float(loss)
@@ -119,13 +227,33 @@ def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
     rate = float((codes == o64["codes"]).mean())
     print("code match rate vs fp64 conv-then-quantize: %.5f" % rate)
     assert rate > 0.995
-    # same answer as torch's conv path up to near-ties (the select path with a non-1x1-able conv falls back)
+    # the two-kernel path (select + conv kernel, dense assign) agrees up to near-ties of its own h
+    with torch.no_grad():
+        sel = quant_conv_select(conv, t(hc), t(hf), entropy=t(ent), threshold=router.fine_grain_threshold)
+        _, c2, _ = vq_assign(sel["h"], t(E), _CodebookPrep(), sel["codebook_mask"])
+    assert float((c2 == info[2]).float().mean()) > 0.995
+    # same answer as torch's conv path up to near-ties (a conv the kernels cannot take falls back)
     with torch.no_grad():
         q2, _, info2, _, _ = encode_dual(router, vq, t(hf), t(hc), entropy=t(ent),
                                          quant_conv=torch.nn.Sequential(conv))        # not an nn.Conv2d -> torch path
     assert float((info2[2] == info[2]).float().mean()) > 0.995
-    # fixed-granularity model (VQModel.encode): dense conv then VectorQuantizer2-style call
+    # fixed-granularity model (VQModel.encode): one op as well; equal to the dense fused op, exact given its h
+    hb2 = torch.empty_like(hb)
     with torch.no_grad():
         qf, lf, inf_ = encode_fixed(vq, t(hf), quant_conv=conv)
-    of = oracle_mod.vq_assign_nchw(__import__("dynamicvectorquantization_amd.qconv", fromlist=["x"]).quant_conv(conv, t(hf)).cpu().numpy(), E, None)
-    assert np.array_equal(inf_[2].cpu().numpy().reshape(B, -1), of["codes"])
+        zqd, cd, ld = vq_assign(t(hf), t(E), _CodebookPrep(), None, conv=conv, h_buf=hb2)
+    assert torch.equal(inf_[2], cd) and torch.equal(qf, zqd)
+    of = oracle_mod.vq_assign_nchw(hb2.cpu().numpy(), E, None)
+    assert np.array_equal(cd.cpu().numpy().reshape(B, -1), of["codes"])
+    # 128 channels: select + conv kernel, then the dense assign (exact given that kernel's h)
+    E1 = synth.codebook_trained(256, 128)
+    conv1 = _conv(dev, 128, 520)
+    vq1 = VectorQuantize2(256, 128).to(dev).eval()
+    vq1.codebook.weight.data[:-1].copy_(t(E1))
+    hf1, hc1 = synth.z_tokens(E1, 2, 16, 16, 521), synth.z_tokens(E1, 2, 8, 8, 522)
+    ent1 = synth.entropy_map(523, 2, 8, 8)
+    with torch.no_grad():
+        q1, _, info1, _, _ = encode_dual(router, vq1, t(hf1), t(hc1), entropy=t(ent1), quant_conv=conv1)
+        sel1 = quant_conv_select(conv1, t(hc1), t(hf1), entropy=t(ent1), threshold=router.fine_grain_threshold)
+    o1 = oracle_mod.vq_assign_nchw(sel1["h"].cpu().numpy(), E1, sel1["codebook_mask"].cpu().numpy())
+    assert np.array_equal(info1[2].cpu().numpy().reshape(2, -1), o1["codes"]) and np.array_equal(q1.cpu().numpy(), o1["zq"])
