@@ -51,14 +51,13 @@ def parse():
                     help="weak: images per GPU (default 256); strong: GLOBAL batch (default 1024)")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
-    ap.add_argument("--path", choices=["routed", "select", "model", "tokens"], default="routed",
+    ap.add_argument("--path", choices=["routed", "select", "model", "model2", "tokens"], default="routed",
                     help="routed: ONE assign op straight from the encoder branches (the router select is fused into "
                          "pass 1, h_dual is never written); select: route-select kernel writing h_dual, then the "
-                         "dense assign (round-1 path); model: select + the models' 1x1 quant_conv as one kernel, then the "
-                         "dense assign (what a reference checkpoint runs); tokens: routed assign, codes only, + permuter")
-    ap.add_argument("--model-chunks", type=int, default=1,
-                    help="--path model: run conv + assign over this many slices of the batch, so that a slice's h "
-                         "(268 MB / chunks) is still in the Infinity Cache when the assign reads it")
+                         "dense assign (round-1 path); model: select -> the models' 1x1 quant_conv -> assign, the order a "
+                         "reference checkpoint runs, as ONE op (the conv is pass 1's prologue; neither h_dual nor the conv's "
+                         "output is written); model2: the same order as two kernels (select + conv kernel writing h, then the "
+                         "dense assign); tokens: routed assign, codes only, + permuter")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
@@ -261,11 +260,20 @@ class WeakDual:
         self.prep = _CodebookPrep()
         self.rank = rank
         self.conv = None
-        if a.path == "model":
+        self.conv_q = None
+        if a.path in ("model", "model2"):
+            # the models' quant_conv: a random orthogonal 256 x 256 matrix and a bias.  The encoder-branch inputs are generated as
+            # x = Q^T (t - b) from tokens t of the usual z_tokens distribution (inputs_np), so that the QUANTIZER sees the same
+            # distribution as on the other paths -- conv(x) = t up to rounding, as in a trained model whose conv output sits near
+            # its codebook -- instead of tokens scrambled away from every code.
+            import numpy as np
+            q, _ = np.linalg.qr(synth.normal(6012, (D, D), 0.0, 1.0).astype(np.float64))
+            self.conv_q = q.astype(np.float32)
+            self.conv_b = synth.normal(6013, (D,), 0.0, 0.1)
             self.conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
             with torch.no_grad():
-                self.conv.weight.copy_(torch.from_numpy(synth.normal(6012, (D, D, 1, 1), 0.0, 1.0 / 16.0)).to(dev))
-                self.conv.bias.copy_(torch.from_numpy(synth.normal(6013, (D,), 0.0, 0.1)).to(dev))
+                self.conv.weight.copy_(torch.from_numpy(self.conv_q.reshape(D, D, 1, 1)).to(dev))
+                self.conv.bias.copy_(torch.from_numpy(self.conv_b).to(dev))
         self.permuter = None
         if a.path == "tokens":
             from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
@@ -288,8 +296,13 @@ class WeakDual:
                 return base[:B]
             parts = [np.roll(base, 5 * j, axis=-1) for j in range((B + b0 - 1) // b0)]
             return np.ascontiguousarray(np.concatenate(parts, 0)[:B])
-        hf = tile(synth.z_tokens(self.E_np, b0, H, W, 2903 + 100 * k, image_offset=off))
-        hc = tile(synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913 + 100 * k, image_offset=off))
+        hf = synth.z_tokens(self.E_np, b0, H, W, 2903 + 100 * k, image_offset=off)
+        hc = synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913 + 100 * k, image_offset=off)
+        if self.conv_q is not None:                          # pre-images under the conv (see __init__)
+            pre = lambda t: np.einsum("oc,bohw->bchw", self.conv_q.astype(np.float64),
+                                      t.astype(np.float64) - self.conv_b.astype(np.float64)[None, :, None, None]).astype(np.float32)
+            hf, hc = pre(hf), pre(hc)
+        hf, hc = tile(hf), tile(hc)
         ent = tile(synth.entropy_map(5903 + 100 * k, b0, H // 2, W // 2, image_offset=off))
         return hf, hc, ent
 
@@ -307,12 +320,7 @@ class WeakDual:
         o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         o.loss = torch.empty(2, dtype=torch.float32, device=dev)
         o.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
-        if self.a.path == "model":
-            nch = max(1, self.a.model_chunks)
-            assert B % nch == 0, "--model-chunks must divide the batch"
-            o.h = torch.empty((B // nch,) + tuple(o.h_fine.shape[1:]), dtype=torch.float32, device=dev)   # reused by every chunk
-            o.h_full = torch.empty_like(o.h_fine) if nch == 1 else None
-            o.loss_chunks = torch.empty((nch, 2), dtype=torch.float32, device=dev)
+        o.h_full = torch.empty_like(o.h_fine) if self.a.path == "model2" else None       # the conv's output (two-kernel form)
         if self.a.path == "tokens":
             Lc, Lf = self.permuter.max_lengths()
             o.seq = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
@@ -322,8 +330,10 @@ class WeakDual:
     def describe(self):
         tail = {"routed": "entropy gate + dual routing + VectorQuantize2 assign as one op (quant_conv not in the path)",
                 "select": "entropy gate + route-select kernel + VectorQuantize2 assign (quant_conv not in the path)",
-                "model": "entropy gate + dual routing + 1x1 quant_conv (one kernel) + VectorQuantize2 assign: the order a "
-                         "reference checkpoint runs, %d batch slice(s)" % max(1, self.a.model_chunks),
+                "model": "entropy gate + dual routing + 1x1 quant_conv + VectorQuantize2 assign as ONE op (the conv is the "
+                         "prologue of the assign's pass 1): the order a reference checkpoint runs",
+                "model2": "entropy gate + dual routing + 1x1 quant_conv (one kernel writing h) + VectorQuantize2 assign: the "
+                          "order a reference checkpoint runs, as two ops",
                 "tokens": "entropy gate + dual routing + VectorQuantize2 assign (codes only) + DualGrainSeperatePermuter: "
                           "the tokenisation stage 2 consumes"}[self.a.path]
         return "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, %s" % (self.B, self.K, tail)
@@ -339,15 +349,13 @@ class WeakDual:
             route_select_dual_entropy(o.ent, THR_R05, o.h_coarse, o.h_fine, out=(o.h_dual, o.grain, o.cmask, o.gate))
             vq_assign(o.h_dual, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss))
         elif path == "model":
-            nch = max(1, self.a.model_chunks)
-            bs = self.B // nch
-            for c in range(nch):
-                sl = slice(c * bs, (c + 1) * bs)
-                h = o.h_full if nch == 1 else o.h
-                qconv.quant_conv_select(self.conv, o.h_coarse[sl], o.h_fine[sl], entropy=o.ent[sl], threshold=THR_R05,
-                                        out=(h, o.grain[sl], o.cmask[sl], o.gate[sl]))
-                vq_assign(h, self.E, self.prep, o.cmask[sl], beta=0.25, mode=self.mode,
-                          out=(o.zq[sl], o.codes[sl], o.loss_chunks[c]))
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05,
+                                  beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate),
+                                  conv=self.conv)
+        elif path == "model2":
+            qconv.quant_conv_select(self.conv, o.h_coarse, o.h_fine, entropy=o.ent, threshold=THR_R05,
+                                    out=(o.h_full, o.grain, o.cmask, o.gate))
+            vq_assign(o.h_full, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss))
         elif path == "tokens":
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05, beta=0.25,
                                   mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate))
@@ -357,7 +365,7 @@ class WeakDual:
                                   beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate))
         if ev:
             ev[1].record()
-        return o.codes, o.grain, (o.loss if path != "model" else o.loss_chunks[0])
+        return o.codes, o.grain, o.loss
 
     def dominant(self, o, ev):
         """the dominant kernel alone (pass 1 of the assign), same launch geometry"""
@@ -369,12 +377,17 @@ class WeakDual:
             vq_assign(o.h_dual if o.h_dual is not None else o.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT, out=(o.zq, o.codes, o.loss))
             ev[1].record()
-        elif path in ("select", "model"):
-            src = o.h_dual if path == "select" else (o.h_full if o.h_full is not None else o.h)
-            n = src.shape[0]
+        elif path in ("select", "model2"):
+            src = o.h_dual if path == "select" else o.h_full
             ev[0].record()
-            vq_assign(src, self.E, self.prep_dom, o.cmask[:n], beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                      out=(o.zq[:n], o.codes[:n], None))
+            vq_assign(src, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                      out=(o.zq, o.codes, None))
+            ev[1].record()
+        elif path == "model":
+            ev[0].record()
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
+                                  threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
+                                  out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv)
             ev[1].record()
         else:
             ev[0].record()
@@ -385,16 +398,16 @@ class WeakDual:
 
     def dominant_tokens(self):
         """tokens one launch of `dominant` processes"""
-        if self.a.path == "model" and self.a.model_chunks > 1:
-            return self.B // self.a.model_chunks * self.H * self.W
         return self.B * self.H * self.W
 
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        if self.a.path in ("select", "model"):
-            return "vq_assign_filter_kernel<256, 0> (dense pass 1)"
-        return "vq_assign_filter_kernel<256, 2> (pass 1, router select fused in, coarse branch staged through LDS)"
+        if self.a.path in ("select", "model2"):
+            return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)"
+        if self.a.path == "model":
+            return "vq_assign_filter_kernel<256, 1, true> (pass 1 with the router select and the 1x1 quant_conv fused in)"
+        return "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, coarse branch staged through LDS)"
 
     def parity(self, slot):
         """the step's outputs, still in HBM, against the oracle on ALL images of this rank (the slot's own inputs)"""
@@ -411,34 +424,38 @@ class WeakDual:
                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
                "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum())}
-        if self.a.path == "model":
+        if self.a.path in ("model", "model2"):
             # h is a tolerance-level quantity (1e-5 * sum |w||x| vs the conv in float64, checked on 8 images); codes, z_q and
-            # the loss are exact GIVEN the kernel's h -- recomputed here slice by slice when the batch runs in slices
+            # the loss are exact GIVEN the h the kernels scored.  Two-kernel form: h is the conv kernel's output tensor.  One-op
+            # form: h exists only inside pass 1 -- the op is run once more with an h_buf, which makes it write the conv output
+            # of every token beside the same codes / z_q / loss (checked to be the same bits as the timed step's).
             import torch
 
-            from dynamicvectorquantization_amd import qconv
-            nch = max(1, self.a.model_chunks)
-            bs = self.B // nch
-            hs = []
-            for c in range(nch):
-                sl = slice(c * bs, (c + 1) * bs)
-                hs.append(qconv.quant_conv_select(self.conv, slot.h_coarse[sl], slot.h_fine[sl], entropy=slot.ent[sl],
-                                                  threshold=THR_R05)["h"].cpu().numpy())
-            h = np.concatenate(hs, 0)
+            from dynamicvectorquantization_amd.quantize import vq_assign_routed_dual
+            if self.a.path == "model":
+                hb = torch.empty_like(slot.h_fine)
+                chk = [torch.empty_like(slot.zq), torch.empty_like(slot.codes), torch.empty_like(slot.loss),
+                       torch.empty_like(slot.grain), torch.empty_like(slot.cmask), torch.empty_like(slot.gate)]
+                vq_assign_routed_dual(slot.h_coarse, slot.h_fine, self.E, self.prep, entropy=slot.ent, threshold=THR_R05,
+                                      beta=0.25, mode=self.mode, out=tuple(chk), conv=self.conv, h_buf=hb)
+                torch.cuda.synchronize()
+                res["rerun_with_h_buf_mismatches"] = int(not (torch.equal(chk[0], slot.zq) and torch.equal(chk[1], slot.codes)
+                                                              and torch.equal(chk[2], slot.loss)))
+                h = hb.cpu().numpy()
+                del hb, chk
+            else:
+                h = slot.h_full.cpu().numpy()
             w64 = self.conv.weight.detach().double().cpu().numpy()[:, :, 0, 0]
             x64 = osel["h_dual"][:8].astype(np.float64)
             ref = np.einsum("ok,bkhw->bohw", w64, x64) + self.conv.bias.detach().double().cpu().numpy()[None, :, None, None]
             bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64))
             res["h_max_err_over_bound"] = float((np.abs(h[:8] - ref) / (1e-5 * bound + 1e-30)).max())
+            res["h_bound_mismatches"] = int(not res["h_max_err_over_bound"] <= 1.0)
             o = oracle.vq_assign_nchw(h, self.E_np, osel["codebook_mask"])
             ref_fp64 = oracle.vq_assign_nchw(ref.astype(np.float32), self.E_np, osel["codebook_mask"][:8])
             res["codes_match_rate_vs_fp64_conv"] = float((slot.codes.cpu().numpy()[:8].reshape(8, -1) == ref_fp64["codes"]).mean())
-            lsum, lerr = 0.0, 0.0
-            for c in range(nch):
-                oc = oracle.vq_assign_nchw(h[c * bs:(c + 1) * bs], self.E_np, osel["codebook_mask"][c * bs:(c + 1) * bs])
-                ol = float(oracle.vq_loss(oc["sqerr"], oc["numel"], 0.25))
-                lerr = max(lerr, abs(float(slot.loss_chunks[c, 1]) - ol) / abs(ol))
-            res["loss_rel_err"] = lerr
+            ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
+            res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol)
         else:
             o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
         self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
@@ -460,7 +477,7 @@ class WeakDual:
                 bad += int((got[:, :L] != want).sum()) + int((got[:, L:] != pads[nme]).sum())   # beyond the batch maximum: PAD
             res["token_stream_mismatches"] = bad
             res["loss_rel_err"] = 0.0
-        elif self.a.path != "model":
+        elif self.a.path not in ("model", "model2"):
             ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
             res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol)
         return res
@@ -750,7 +767,7 @@ def run_rank(a):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(a.mode if a.path in ("select", "model") else "routed", {}).get("hbm_bytes_per_launch")
+            traffic = tj.get(a.mode if a.path in ("select", "model2") else ("routed" if a.path != "model" else "model"), {}).get("hbm_bytes_per_launch")
             tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected by tools/pmc_traffic.py; not re-measured in this run)"
         except Exception:
             traffic = None

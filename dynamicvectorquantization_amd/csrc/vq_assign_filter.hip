@@ -348,21 +348,30 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             for (int r = 0; r < 16; ++r) acc[t8][r] = 0.0f;
         int ea = 100;                                        // x is scaled by 2^ea (per token; both lane halves agree)
         float sa = ldexpf(1.0f, 100);
-#pragma unroll
-        for (int s = 0; s < S16; ++s) {
-            // group s has landed for this wave: at most the two younger groups are outstanding
-            if (s <= S16 - 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (s == S16 - 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DVQ_TUNING
+        unsigned tc_wait = 0, tc_bar = 0;
+        const unsigned tc_begin = (unsigned)__builtin_readcyclecounter();
+#define DVQ_TC(ACC, STMT) do { const unsigned t0_ = (unsigned)__builtin_readcyclecounter(); STMT; ACC += (unsigned)__builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define DVQ_TC(ACC, STMT) do { STMT; } while (0)
+#endif
+        // group g has landed for this wave when at most the (up to two) younger groups are outstanding; its 8 values are scaled
+        // and split into the hi / lo B fragments.  The scale follows the running maximum: a value that would reach 2^15 after
+        // scaling moves it (exact rescale of the accumulators by a power of two; wave-uniform branch, rare after the first
+        // k-steps).
+        f16x8 xh, xl;
+        auto take_group = [&](int g) __attribute__((always_inline)) {
+            DVQ_TC(tc_wait, {
+            if (g <= S16 - 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (g == S16 - 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); });
             float xv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(xr[s % 3][j])); xv[j] = xr[s % 3][j]; }
+            for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(xr[g % 3][j])); xv[j] = xr[g % 3][j]; }
             float m = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) m = vmax_abs(m, xv[j]);
             m = fmaxf(m, __shfl_xor(m, 32));
-            // the scale follows the running maximum: a value that would reach 2^15 after scaling moves it (exact rescale of
-            // the accumulators by a power of two; wave-uniform branch, rare after the first k-steps)
             const bool grow = (m > 0.0f) && (m < __builtin_inff()) && (m * sa >= 32768.0f);
             if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
                 int e;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 int en = 14 - e;
                 en = en > 100 ? 100 : (en < -100 ? -100 : en);
                 en = grow ? en : ea;
-                if (s > 0) {
+                if (g > 0) {
                     const float f = ldexpf(1.0f, en - ea);
 #pragma unroll
                     for (int t8 = 0; t8 < 8; ++t8)
@@ -391,20 +400,35 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 ph[j2] = __builtin_bit_cast(unsigned, hh);
                 pl[j2] = __builtin_bit_cast(unsigned, ll);
             }
-            const f16x8 xh = __builtin_bit_cast(f16x8, ph), xl = __builtin_bit_cast(f16x8, pl);
-            __builtin_amdgcn_s_barrier();                    // k-step s of the weights landed (everybody's pieces); s - 1 consumed
+            xh = __builtin_bit_cast(f16x8, ph);
+            xl = __builtin_bit_cast(f16x8, pl);
+        };
+        take_group(0);
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            DVQ_TC(tc_bar, { __builtin_amdgcn_s_barrier(); });   // k-step s of the weights landed (everybody's pieces); s - 1 consumed
             asm volatile("" ::: "memory");
-            if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers just converted
+            if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers already converted
             const char *buf = lds + (s & 3) * IMG_BYTES;
+            const f16x8 bh = xh, bl = xl;
 #pragma unroll
             for (int t8 = 0; t8 < 8; ++t8) {
                 const f16x8 ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
                 const f16x8 al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[t8], 0, 0, 0);
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[t8], 0, 0, 0);
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t8], 0, 0, 0);
+                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t8], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);               // the MFMAs are issued; the next k-step's conversion runs under them
+            if (s + 1 < S16) take_group(s + 1);
         }
+#ifdef DVQ_TUNING
+        if (g_dvq_tokdbg != nullptr && tid == 0) {           // cycles of this wave in the conv loop: total, in its counted waits, in its barriers
+            f32x4 dbg = {(float)((unsigned)__builtin_readcyclecounter() - tc_begin), (float)tc_wait, (float)tc_bar, 0.0f};
+            *(f32x4 *)(g_dvq_tokdbg + 4 * (size_t)blockIdx.x) = dbg;
+        }
+#endif
+#undef DVQ_TC
         const float unscale = ldexpf(cv.meta->inv_scale_w, -ea);
 #pragma unroll
         for (int s = 0; s < S16; ++s) {

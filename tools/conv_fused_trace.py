@@ -37,9 +37,14 @@ if os.environ.get("STAMPS") and hasattr(_lib.lib, "dvq_tuning_buffers"):
                      ("plain_dense", lambda: vq_assign(h, E, prep, None, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)))):
         for _ in range(30): fn()
         stamps.zero_()
-        _lib.lib.dvq_tuning_buffers(stamps.data_ptr(), 0)
+        dbg = torch.zeros((B * 1024, 4), device=dev)
+        _lib.lib.dvq_tuning_buffers(stamps.data_ptr(), dbg.data_ptr())
         fn(); torch.cuda.synchronize()
         _lib.lib.dvq_tuning_buffers(0, 0)
+        if name.startswith("fused"):
+            d = dbg[:G].cpu().numpy()
+            print(json.dumps({"kernel": name, "conv_loop_cycles_median": float(np.median(d[:, 0])), "in_counted_waits": float(np.median(d[:, 1])),
+                              "in_barriers": float(np.median(d[:, 2]))}))
         st = stamps.cpu().numpy().astype(np.int64)
         slot, r_in, r_pro, r_l0, c_l0, r_l1, c_l1, r_out = (st[:, i] for i in range(8))
         ok = (r_l1 > r_l0) & (r_out >= r_l1)

@@ -18,7 +18,8 @@ if has bench; then
   timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
   timeout 300 python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_streams1.json
   timeout 300 python bench.py --path model --no-cpu-baseline > $O/bench_model.json 2>> $O/bench.err; cut -c1-200 $O/bench_model.json
-  timeout 300 python bench.py --path model --model-chunks 4 --no-cpu-baseline > $O/bench_model_chunks4.json 2>> $O/bench.err; cut -c1-200 $O/bench_model_chunks4.json
+  timeout 300 python bench.py --path model2 --no-cpu-baseline > $O/bench_model2.json 2>> $O/bench.err; cut -c1-200 $O/bench_model2.json
+  timeout 300 python bench.py --path model --streams 1 --no-cpu-baseline --no-parity > $O/bench_model_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_model_streams1.json
   timeout 300 python bench.py --path tokens --no-cpu-baseline > $O/bench_tokens.json 2>> $O/bench.err; cut -c1-200 $O/bench_tokens.json
   timeout 300 python bench.py --path select --no-cpu-baseline > $O/bench_select_path.json 2>> $O/bench.err; cut -c1-200 $O/bench_select_path.json
   timeout 300 python bench.py --scaling strong --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_strong_n1.json 2>> $O/bench.err; cut -c1-200 $O/bench_strong_n1.json
