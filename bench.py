@@ -51,13 +51,14 @@ def parse():
                     help="weak: images per GPU (default 256); strong: GLOBAL batch (default 1024)")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
-    ap.add_argument("--path", choices=["routed", "select", "model", "model2", "tokens"], default="routed",
+    ap.add_argument("--path", choices=["routed", "select", "model", "model2", "tokens", "tokens_model"], default="routed",
                     help="routed: ONE assign op straight from the encoder branches (the router select is fused into "
                          "pass 1, h_dual is never written); select: route-select kernel writing h_dual, then the "
                          "dense assign (round-1 path); model: select -> the models' 1x1 quant_conv -> assign, the order a "
                          "reference checkpoint runs, as ONE op (the conv is pass 1's prologue; neither h_dual nor the conv's "
                          "output is written); model2: the same order as two kernels (select + conv kernel writing h, then the "
-                         "dense assign); tokens: routed assign, codes only, + permuter")
+                         "dense assign); tokens: routed assign, codes only, + permuter; tokens_model: the same behind the models' "
+                         "quant_conv (the fused op, codes only), what stage 2's encode_to_z runs on a stage-1 checkpoint")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
@@ -261,7 +262,7 @@ class WeakDual:
         self.rank = rank
         self.conv = None
         self.conv_q = None
-        if a.path in ("model", "model2"):
+        if a.path in ("model", "model2", "tokens_model"):
             # the models' quant_conv: a random orthogonal 256 x 256 matrix and a bias.  The encoder-branch inputs are generated as
             # x = Q^T (t - b) from tokens t of the usual z_tokens distribution (inputs_np), so that the QUANTIZER sees the same
             # distribution as on the other paths -- conv(x) = t up to rounding, as in a trained model whose conv output sits near
@@ -275,7 +276,7 @@ class WeakDual:
                 self.conv.weight.copy_(torch.from_numpy(self.conv_q.reshape(D, D, 1, 1)).to(dev))
                 self.conv.bias.copy_(torch.from_numpy(self.conv_b).to(dev))
         self.permuter = None
-        if a.path == "tokens":
+        if a.path in ("tokens", "tokens_model"):
             from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
             self.permuter = DualGrainSeperatePermuter(coarse_hw=H // 2, fine_hw=H, content_pad_code=K, content_eos_code=K + 1)
         # one set of inputs AND outputs per stream slot, preallocated: the step allocates nothing and no step reads the
@@ -316,12 +317,12 @@ class WeakDual:
         o.h_dual = torch.empty_like(o.h_fine) if self.a.path == "select" else None
         o.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
         o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        o.zq = torch.empty_like(o.h_fine) if self.a.path != "tokens" else None
+        o.zq = torch.empty_like(o.h_fine) if self.a.path not in ("tokens", "tokens_model") else None
         o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         o.loss = torch.empty(2, dtype=torch.float32, device=dev)
         o.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
         o.h_full = torch.empty_like(o.h_fine) if self.a.path == "model2" else None       # the conv's output (two-kernel form)
-        if self.a.path == "tokens":
+        if self.a.path in ("tokens", "tokens_model"):
             Lc, Lf = self.permuter.max_lengths()
             o.seq = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
                     [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]
@@ -335,7 +336,9 @@ class WeakDual:
                 "model2": "entropy gate + dual routing + 1x1 quant_conv (one kernel writing h) + VectorQuantize2 assign: the "
                           "order a reference checkpoint runs, as two ops",
                 "tokens": "entropy gate + dual routing + VectorQuantize2 assign (codes only) + DualGrainSeperatePermuter: "
-                          "the tokenisation stage 2 consumes"}[self.a.path]
+                          "the tokenisation stage 2 consumes",
+                "tokens_model": "entropy gate + dual routing + 1x1 quant_conv + VectorQuantize2 assign (ONE op, codes only) + "
+                                "DualGrainSeperatePermuter: the tokenisation stage 2 runs on a stage-1 checkpoint"}[self.a.path]
         return "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, %s" % (self.B, self.K, tail)
 
     def step(self, o, ev=None):
@@ -356,9 +359,9 @@ class WeakDual:
             qconv.quant_conv_select(self.conv, o.h_coarse, o.h_fine, entropy=o.ent, threshold=THR_R05,
                                     out=(o.h_full, o.grain, o.cmask, o.gate))
             vq_assign(o.h_full, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss))
-        elif path == "tokens":
+        elif path in ("tokens", "tokens_model"):
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05, beta=0.25,
-                                  mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate))
+                                  mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv)
             self.permuter(o.codes, o.grain, max_len=self.permuter.max_lengths(), out=o.seq)
         else:
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05,
@@ -383,7 +386,7 @@ class WeakDual:
             vq_assign(src, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                       out=(o.zq, o.codes, None))
             ev[1].record()
-        elif path == "model":
+        elif path in ("model", "tokens_model"):
             ev[0].record()
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
@@ -405,7 +408,7 @@ class WeakDual:
             return "vq_assign_exact_kernel<256>"
         if self.a.path in ("select", "model2"):
             return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)"
-        if self.a.path == "model":
+        if self.a.path in ("model", "tokens_model"):
             return "vq_assign_filter_kernel<256, 1, true> (pass 1 with the router select and the 1x1 quant_conv fused in)"
         return "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, coarse branch staged through LDS)"
 
@@ -424,7 +427,7 @@ class WeakDual:
                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
                "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum())}
-        if self.a.path in ("model", "model2"):
+        if self.a.path in ("model", "model2", "tokens_model"):
             # h is a tolerance-level quantity (1e-5 * sum |w||x| vs the conv in float64, checked on 8 images); codes, z_q and
             # the loss are exact GIVEN the h the kernels scored.  Two-kernel form: h is the conv kernel's output tensor.  One-op
             # form: h exists only inside pass 1 -- the op is run once more with an h_buf, which makes it write the conv output
@@ -432,15 +435,17 @@ class WeakDual:
             import torch
 
             from dynamicvectorquantization_amd.quantize import vq_assign_routed_dual
-            if self.a.path == "model":
+            if self.a.path in ("model", "tokens_model"):
                 hb = torch.empty_like(slot.h_fine)
-                chk = [torch.empty_like(slot.zq), torch.empty_like(slot.codes), torch.empty_like(slot.loss),
+                chk = [torch.empty_like(slot.h_fine), torch.empty_like(slot.codes), torch.empty_like(slot.loss),
                        torch.empty_like(slot.grain), torch.empty_like(slot.cmask), torch.empty_like(slot.gate)]
                 vq_assign_routed_dual(slot.h_coarse, slot.h_fine, self.E, self.prep, entropy=slot.ent, threshold=THR_R05,
                                       beta=0.25, mode=self.mode, out=tuple(chk), conv=self.conv, h_buf=hb)
                 torch.cuda.synchronize()
-                res["rerun_with_h_buf_mismatches"] = int(not (torch.equal(chk[0], slot.zq) and torch.equal(chk[1], slot.codes)
-                                                              and torch.equal(chk[2], slot.loss)))
+                same = torch.equal(chk[1], slot.codes)
+                if slot.zq is not None:
+                    same = same and torch.equal(chk[0], slot.zq) and torch.equal(chk[2], slot.loss)
+                res["rerun_with_h_buf_mismatches"] = int(not same)
                 h = hb.cpu().numpy()
                 del hb, chk
             else:
@@ -455,7 +460,7 @@ class WeakDual:
             ref_fp64 = oracle.vq_assign_nchw(ref.astype(np.float32), self.E_np, osel["codebook_mask"][:8])
             res["codes_match_rate_vs_fp64_conv"] = float((slot.codes.cpu().numpy()[:8].reshape(8, -1) == ref_fp64["codes"]).mean())
             ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
-            res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol)
+            res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol) if self.a.path != "tokens_model" else 0.0
         else:
             o = oracle.vq_assign_nchw(osel["h_dual"], self.E_np, osel["codebook_mask"])
         self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
@@ -463,7 +468,7 @@ class WeakDual:
         res["code_mismatches"] = int((codes != o["codes"]).sum())
         if slot.zq is not None:
             res["zq_mismatches"] = int((slot.zq.cpu().numpy() != o["zq"]).sum())
-        if self.a.path == "tokens":
+        if self.a.path in ("tokens", "tokens_model"):
             from oracle import permuter as operm
             ref = operm.forward(o["codes"].reshape(self.B, self.H, self.W), osel["indices"], coarse_hw=self.H // 2,
                                 fine_hw=self.H, content_pad=self.K, content_eos=self.K + 1)
@@ -757,7 +762,7 @@ def run_rank(a):
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
     N = wl.dominant_tokens()                                  # tokens per launch of the dominant kernel
-    per_token = D * 4 + 8 + 4 + (D * 4 if a.path != "tokens" else 0)   # z read + int64 code + mask (+ z_q write)
+    per_token = D * 4 + 8 + 4 + (D * 4 if a.path not in ("tokens", "tokens_model") else 0)   # z read + int64 code + mask (+ z_q write)
     alg_bytes = N * per_token + K * D * 4                     # codebook once per launch
     alg_flops = 2.0 * K * D * N
     gbs = alg_bytes / (dom_ms * 1e-3) / 1e9

@@ -145,18 +145,22 @@ def encode_fixed(quantize, h, quant_conv=None):
     return quantize(h)
 
 
-def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None, max_len=None, out=None):
+def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None, max_len=None, out=None, quant_conv=None):
     """Codes-only tokenisation for stage 2 (reference models/stage2_dynamic/dqtransformer_uncond_entropy.py:166-171,182:
     `_, z_out = self.encode_to_z(x)` keeps only `permuter(indices, grain_indices)` and discards quant): the routed assign
     with want_zq = False / want_loss = False (pass 1 writes no z_q: 1032 B per token instead of 2060) followed by the
     permuter on the same stream.  With `max_len` (see DualGrainSeperatePermuter.forward; `permuter.max_lengths()`) nothing
     is read back to the host: three kernels (counter zero, pass 1, resolver + list) and one permuter kernel, all queued.
     -> (permuter dict, grain_indices [B, hc, wc] int64, codes [B, 2hc, 2wc] int64).
-    Needs the fused routed op's preconditions (eval-mode VectorQuantize2, no quant_conv, no autograd)."""
+    quant_conv: the first stage's 1x1 conv between select and quantizer (what `encode_to_z` runs through the stage-1 `encode`):
+    fused into the same op (256 channels).
+    Needs the fused routed op's preconditions (eval-mode VectorQuantize2, no autograd)."""
     if not _can_route(quantize, None, h_coarse, h_fine):
         raise _lib.DvqError("encode_to_tokens: needs an eval-mode VectorQuantize2 on fp32 GPU feature maps without autograd")
+    if quant_conv is not None and not _can_route_conv(quantize, quant_conv, h_coarse, h_fine):
+        raise _lib.DvqError("encode_to_tokens: the quant_conv must be a 1x1 nn.Conv2d(256, 256) on the GPU (filter mode)")
     cb = quantize.codebook
-    kw = dict(beta=quantize.beta, mode=quantize.assign_mode, want_zq=False, want_loss=False)
+    kw = dict(beta=quantize.beta, mode=quantize.assign_mode, want_zq=False, want_loss=False, conv=quant_conv)
     if isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda:
         r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
                                   threshold=router.fine_grain_threshold, **kw)

@@ -153,3 +153,42 @@ def test_encode_to_tokens_vs_oracle(dev, oracle_mod, golden_dir):
             L = ref[k].shape[1]
             assert np.array_equal(seqs2[k].cpu().numpy(), ref[k]), k
             assert np.array_equal(seqs[k].cpu().numpy()[:, :L], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_encode_to_tokens_with_quant_conv(dev, oracle_mod, golden_dir):
+    """stage 2's tokenisation of a first stage WITH its 1x1 quant_conv (dqtransformer_uncond_entropy.py:166-171 through
+    dqvae_dual_entropy.py:124-134): one fused op (select -> conv -> assign, codes only) + permuter; the codes equal the fused
+    op's with z_q requested (whose exactness given its h is tested in test_qconv.py), the token stream equals the oracle
+    permuter on them"""
+    import os
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual, encode_to_tokens
+    from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    from oracle import permuter as P
+    B, K, D = 16, 1024, 256
+    E = synth.codebook_trained(K, D)
+    hf, hc = synth.z_tokens(E, B, 32, 32, 7401), synth.z_tokens(E, B, 16, 16, 7402)
+    ent = synth.entropy_map(7403, B, 16, 16)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(synth.normal(7404, (D, D, 1, 1), 0.0, 1.0 / 16.0)))
+        conv.bias.copy_(t(synth.normal(7405, (D,), 0.0, 0.1)))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    router = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    perm = DualGrainSeperatePermuter()
+    with torch.no_grad():
+        seqs, grain, codes = encode_to_tokens(router, vq, perm, t(hf), t(hc), entropy=t(ent), quant_conv=conv)
+        _, _, info, grain2, _ = encode_dual(router, vq, t(hf), t(hc), entropy=t(ent), quant_conv=conv)
+    assert torch.equal(codes, info[2]) and torch.equal(grain, grain2)
+    og = oracle_mod.entropy_gate(ent, router.fine_grain_threshold)
+    assert np.array_equal(grain.cpu().numpy(), oracle_mod.route_select_dual(og, hc, hf)["indices"])
+    ref = P.forward(codes.cpu().numpy(), grain.cpu().numpy())
+    for k in KEYS:
+        assert np.array_equal(seqs[k].cpu().numpy(), ref[k]), k
+    with pytest.raises(Exception):                          # a conv the kernels cannot fuse is refused, not silently dropped
+        encode_to_tokens(router, vq, perm, t(hf), t(hc), entropy=t(ent), quant_conv=torch.nn.Sequential(conv))

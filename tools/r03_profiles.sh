@@ -21,6 +21,7 @@ if has bench; then
   timeout 300 python bench.py --path model2 --no-cpu-baseline > $O/bench_model2.json 2>> $O/bench.err; cut -c1-200 $O/bench_model2.json
   timeout 300 python bench.py --path model --streams 1 --no-cpu-baseline --no-parity > $O/bench_model_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_model_streams1.json
   timeout 300 python bench.py --path tokens --no-cpu-baseline > $O/bench_tokens.json 2>> $O/bench.err; cut -c1-200 $O/bench_tokens.json
+  timeout 300 python bench.py --path tokens_model --no-cpu-baseline > $O/bench_tokens_model.json 2>> $O/bench.err; cut -c1-200 $O/bench_tokens_model.json
   timeout 300 python bench.py --path select --no-cpu-baseline > $O/bench_select_path.json 2>> $O/bench.err; cut -c1-200 $O/bench_select_path.json
   timeout 300 python bench.py --scaling strong --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_strong_n1.json 2>> $O/bench.err; cut -c1-200 $O/bench_strong_n1.json
   timeout 300 python bench.py --scaling strong --batch 128 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_strong_b128_rank_size.json 2>> $O/bench.err; cut -c1-200 $O/bench_strong_b128_rank_size.json
