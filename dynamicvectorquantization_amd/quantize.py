@@ -45,6 +45,7 @@ class _CodebookPrep:
         self.track_users = False # set by training-mode forwards: the image may be rebuilt while other streams read it
         self._users = {}         # stream handle -> event after that stream's last use
         self._ws = {}            # (B, D, HW, K, mode, device, stream) -> uint8 tensor
+        self._hbuf = {}          # (shape, device, stream) -> f32 tensor: h rows of exact-list tokens (ops with the conv fused in)
         self._last_ws = None
 
     def invalidate(self):
@@ -105,6 +106,17 @@ class _CodebookPrep:
         self._last_ws = (key, ws)
         return ws
 
+    def h_scratch(self, shape, device):
+        """[B, D, *spatial] f32 buffer of the ops with the quant_conv fused in, PER STREAM like the workspaces (pass 1 writes the
+        conv output of its exact-list tokens there and the list kernel of the same op reads them back)"""
+        key = (tuple(shape), device, _lib.stream_ptr(device))
+        hb = self._hbuf.get(key)
+        if hb is None:
+            if len(self._hbuf) >= 8:
+                self._hbuf.clear()
+            hb = self._hbuf[key] = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+        return hb
+
     def fallback_count(self):
         """(tokens queued for the resolver, tokens sent to the full exact pass) of the last
         filter-mode call through this object (syncs)"""
@@ -124,20 +136,13 @@ class _CodebookPrep:
 def _conv_args(conv, prep, shape, device, h_buf):
     """(prepared conv buffer, h_buf, h_all) for the ops with the 1x1 quant_conv fused in.  h_buf [B, D, *spatial]: pass 1 writes
     there the conv output of the few tokens it hands to the exact-list kernel (ALL tokens when the caller gives the tensor:
-    tests); without one a scratch tensor cached on the codebook's prep is used."""
+    tests); without one a scratch tensor cached on the codebook's prep, one per stream, is used."""
     from . import qconv as _qconv
     if not _qconv.usable(conv) or conv.in_channels != 256:
         raise _lib.DvqError("fused quant_conv: needs a 1x1 nn.Conv2d(256, 256) on the GPU (other sizes: quant_conv + vq_assign)")
     h_all = h_buf is not None
     if h_buf is None:
-        key = ("hbuf",) + tuple(shape) + (str(device),)
-        h_buf = prep._scratch.get(key) if hasattr(prep, "_scratch") else None
-        if h_buf is None:
-            if not hasattr(prep, "_scratch"):
-                prep._scratch = {}
-            prep._scratch.clear()
-            h_buf = torch.empty(tuple(shape), dtype=torch.float32, device=device)
-            prep._scratch[key] = h_buf
+        h_buf = prep.h_scratch(shape, device)
     elif tuple(h_buf.shape) != tuple(shape) or h_buf.dtype != torch.float32 or not h_buf.is_contiguous() or h_buf.device != device:
         raise ValueError("h_buf must be a contiguous f32 tensor %s on %s" % (tuple(shape), device))
     return _qconv._prep_of(conv).get(conv), h_buf, h_all
