@@ -596,8 +596,8 @@ class StrongTriple:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256, 0> (dense pass 1)" if self.a.path == "select" else \
-            "vq_assign_filter_kernel<256, 2> (pass 1, router select fused in, median / coarse branches staged through LDS)"
+        return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)" if self.a.path == "select" else \
+            "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, median / coarse branches staged through LDS)"
 
     def parity(self, slot):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
@@ -778,12 +778,14 @@ def run_rank(a):
             traffic = None
     # rocprofv3 --kernel-trace --stats duration of the same kernel, if a summary made from THESE sources is committed
     rocprof_ms = None
-    try:
-        meta = json.load(open(os.path.join(ROOT, "profiles", "bench_kernel_stats.meta.json")))
-        if meta.get("source_sha16") == source_sha16() and meta.get("path") == a.path and meta.get("scaling") == a.scaling:
-            rocprof_ms = meta.get("dominant_kernel_avg_ms")
-    except Exception:
-        pass
+    for mname in ("bench_kernel_stats.%s.meta.json" % a.path, "bench_kernel_stats.meta.json"):     # per path, then the default path's
+        try:
+            meta = json.load(open(os.path.join(ROOT, "profiles", mname)))
+            if meta.get("source_sha16") == source_sha16() and meta.get("path") == a.path and meta.get("scaling") == a.scaling:
+                rocprof_ms = meta.get("dominant_kernel_avg_ms")
+                break
+        except Exception:
+            pass
     if a.mode == "filter":
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}

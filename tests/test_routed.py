@@ -337,7 +337,10 @@ def test_dual_feature_router_config_end_to_end(dev, oracle_mod):
     assert np.all(np.abs(h[:4] - ref) <= 1e-5 * bound + 1e-30)
 
 
-def test_routed_op_is_graph_capturable(dev):
+@pytest.mark.parametrize("with_conv", [False, True])
+def test_routed_op_is_graph_capturable(dev, with_conv):
+    """the routed op -- and the model-order op with the 1x1 quant_conv fused in -- captured into a hipGraph and replayed on
+    new inputs: no host synchronisation, no allocation outside the capture's pool, same bits as an eager call"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
     B, K, D = 4, 1024, 256
@@ -351,7 +354,12 @@ def test_routed_op_is_graph_capturable(dev):
     out = (torch.empty_like(hf), torch.empty((B, 32, 32), dtype=torch.int64, device=dev), torch.empty(2, device=dev),
            torch.empty((B, 16, 16), dtype=torch.int64, device=dev), torch.empty((B, 1, 32, 32), device=dev),
            torch.empty((B, 16, 16, 2), dtype=torch.int64, device=dev))
-    step = lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, out=out)
+    conv = None
+    if with_conv:
+        conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+        with torch.no_grad():
+            conv.weight.copy_(t(synth.normal(9310, (D, D, 1, 1), 0.0, 1.0 / 16.0)))
+    step = lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, out=out, conv=conv)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

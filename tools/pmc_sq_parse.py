@@ -4,7 +4,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        short = ("pass1_fused_select" if "vq_assign_filter_kernel<256, 1" in k else
+        short = ("pass1_fused_select" if "vq_assign_filter_kernel<256, 1, false>" in k else
                  "filter" if "vq_assign_filter" in k else
                  ("resolve" if "vq_resolve" in k else ("exact" if "vq_assign_exact" in k else None)))
         if short is None:

@@ -26,8 +26,9 @@ kernels = {}
 def find(per, prefix):
     ks = [k for k in per if k.startswith(prefix)]
     return ks[0] if ks else None
-for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0"), ("fused_pass1", "vq_assign_filter_kernel<256, 2"),
-                      ("fused_pass1_per_lane_select", "vq_assign_filter_kernel<256, 1"), ("resolver", "vq_resolve_kernel<256>")):
+for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0, false>"), ("fused_pass1", "vq_assign_filter_kernel<256, 2, false>"),
+                      ("fused_pass1_per_lane_select", "vq_assign_filter_kernel<256, 1, false>"),
+                      ("model_pass1", "vq_assign_filter_kernel<256, 1, true>"), ("resolver", "vq_resolve_kernel<256>")):
     kf, kw = find(fetch, prefix), find(write, prefix)
     if kf is None or kw is None:
         continue
@@ -50,5 +51,14 @@ if "fused_pass1" in kernels:
                      "note": "resolver kernels of both ops are averaged together under 'resolver'"}
     if "fused_pass1_per_lane_select" in kernels:
         out["routed"]["per_lane_select_form_bytes"] = kernels["fused_pass1_per_lane_select"]["hbm_bytes_per_launch"]
+if "model_pass1" in kernels:
+    # select + 1x1 quant_conv + assign as one kernel: same algorithmic bytes as the routed op (the conv's output is never written);
+    # the 256 KiB of weight images are re-read by every workgroup from L2
+    floor = N * (D * 4 + D + D * 4 + 8 + 4) + N // 4 * 4 + 1024 * D * 4
+    out["model"] = {"hbm_bytes_per_launch": kernels["model_pass1"]["hbm_bytes_per_launch"], "algorithmic_bytes": alg,
+                    "ratio_dominant_kernel_to_algorithmic": kernels["model_pass1"]["hbm_bytes_per_launch"] / alg,
+                    "line_granular_floor_bytes": floor,
+                    "ratio_to_line_granular_floor": kernels["model_pass1"]["hbm_bytes_per_launch"] / floor,
+                    "note": "per-lane select form (the ring slots the staged form parks the coarse branch in carry the conv's weights)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: out.get(k) for k in ("filter", "routed")}), "factor", factor)
+print(json.dumps({k: out.get(k) for k in ("filter", "routed", "model")}), "factor", factor)

@@ -39,4 +39,12 @@ if hasattr(_lib.lib, "dvq_tuning_set"):
         vq_assign_routed_dual(hc, z, Et, pr, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER)
     torch.cuda.synchronize()
     _lib.lib.dvq_tuning_set(b"sel_staged", 1)
+# (5) the model order as one op: select + 1x1 quant_conv + assign (bench.py --path model)
+conv = torch.nn.Conv2d(256, 256, 1).to(dev).eval()
+with torch.no_grad():
+    conv.weight.copy_(t(synth.normal(6012, (256, 256, 1, 1), 0.0, 1.0 / 16.0)))
+pm = _CodebookPrep()
+for _ in range(4):
+    vq_assign_routed_dual(hc, z, Et, pm, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER, conv=conv)
+torch.cuda.synchronize()
 print("queued/exact dense", p.fallback_count(), "routed", pr.fallback_count())
