@@ -128,3 +128,19 @@ def test_shard_slices_cover_batch():
         assert sl[0][0] == 0 and sl[-1][1] == B
         assert all(sl[i][1] == sl[i + 1][0] for i in range(G - 1))
         assert max(e - s for s, e in sl) - min(e - s for s, e in sl) <= 1
+
+
+def test_conv_prologue_isa_has_no_load_hazards():
+    """the conv prologue of pass 1 (csrc/vq_assign_filter.hip, CONV form) issues its x loads as inline asm three k-steps ahead and
+    waits with counted s_waitcnt: on the generated gfx950 ISA nothing may touch a load's destination registers before its covering
+    wait, and the sixteen counted waits must be the ones the source placed (tools/isa_hazard_check.py; hipcc cross-compiles here)"""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_hazard_check.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 hazards, counted waits as placed") == 2, r.stdout
