@@ -54,6 +54,17 @@ __device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_bas
         (const __attribute__((address_space(1))) void *)gsrc_lane,
         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// the same with an instruction offset OFF (bytes, < 4096): it is added to BOTH addresses -- global gsrc_lane + OFF, LDS
+// lds_wave_base + OFF + lane*16 (measured: tools/micro/glds_offset.hip) -- so the pieces of one contiguous copy share one
+// address register pair and one M0 value
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void *gsrc_lane, void *lds_wave_base)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed instruction offset");
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc_lane,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, OFF, 0);
+}
 __device__ __forceinline__ void glds4(const void *gsrc_lane, void *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds(

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
     constexpr int CPW = (S16 + NW - 1) / NW;
+    static_assert(CPW * NW == S16 && CPW <= 4, "a wave's chunks of a code tile are contiguous and within the instruction offset");
     constexpr int PER_TILE = CPW + 1;
     constexpr int NBUF = 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -285,9 +286,16 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         const int tt = (t < T) ? t : T - 1;
         const char *src = img + (size_t)tt * TILE_STRIDE;
         if (q < CPW) {
-            int chunk = wave * CPW + q;
-            if (chunk >= S16) chunk = S16 - 1;
-            glds16(src + chunk * 1024 + lane * 16, lds + (t & (NBUF - 1)) * IMG_BYTES + chunk * 1024);
+            // this wave's CPW chunks are contiguous (S16 = NW * CPW for every supported D): one base, the chunk as the
+            // instruction offset, which applies to the global and the LDS address alike
+            const char *s0 = src + wave * (CPW * 1024) + lane * 16;
+            char *d0 = lds + (t & (NBUF - 1)) * IMG_BYTES + wave * (CPW * 1024);
+            switch (q) {
+            case 0: glds16_off<0>(s0, d0); break;
+            case 1: glds16_off<1024>(s0, d0); break;
+            case 2: glds16_off<2048>(s0, d0); break;
+            default: glds16_off<3072>(s0, d0); break;
+            }
         } else {
             glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
         }
@@ -959,8 +967,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
         const int tt = (t < T) ? t : T - 1;
         const char *src = img + (size_t)tt * TILE_STRIDE;
         if (q < CPW) {
-            int chunk = wave * CPW + q;
-            glds16(src + chunk * 1024 + lane * 16, lds + (t & (NBUF - 1)) * IMG_BYTES + chunk * 1024);
+            const char *s0 = src + wave * (CPW * 1024) + lane * 16;   // (one base + instruction offsets: vq_assign_filter_kernel)
+            char *d0 = lds + (t & (NBUF - 1)) * IMG_BYTES + wave * (CPW * 1024);
+            switch (q) {
+            case 0: glds16_off<0>(s0, d0); break;
+            case 1: glds16_off<1024>(s0, d0); break;
+            case 2: glds16_off<2048>(s0, d0); break;
+            default: glds16_off<3072>(s0, d0); break;
+            }
         } else {
             glds4(src + IMG_BYTES + lane * 4, enraw + ((t & (NBUF - 1)) * NW + wave) * 64);
         }
