@@ -48,7 +48,8 @@
 #endif
 #ifndef DVQ_ABLATE
 #define DVQ_ABLATE 0             // timing experiments of the tuning build only (results are WRONG): 1 no top-2 update, 2 no ring DMA in the
-#endif                           // loop, 4 no per-tile barrier, 8 no MFMAs, 16 no A-fragment reads, 32 no seed reads
+#endif                           // loop, 4 no per-tile barrier, 8 no MFMAs, 16 no A-fragment reads, 32 no seed reads; conv prologue: 64 no x loads,
+                                 // 128 no weight DMA, 256 no weight-fragment reads, 512 no barrier, 1024 no hi / lo conversion, 2048 no MFMAs
 #ifndef DVQ_LOCK_MAX_SPINS
 #define DVQ_LOCK_MAX_SPINS 4000  // anti-phase lock: give up waiting after about 3 ms
 #endif
@@ -333,14 +334,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         const float *xp = zp;
         auto issue_group = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < ((DVQ_ABLATE & 128) ? 0 : 4); ++q) {
                 const int i = 4 * wave + q;                  // piece: row tile i >> 1, hi / lo i & 1
                 glds16(cv.wimg + (size_t)(i >> 1) * QTILE + (i & 1) * QIMG + k * 1024 + lane * 16,
                        lds + (k & 3) * IMG_BYTES + i * 1024);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
+                if (DVQ_ABLATE & 64) asm volatile("v_mov_b32 %0, 0" : "=v"(xr[k % 3][j]) :: "memory");
+                else asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
                 xp += st;
             }
             xp += 8 * st;                                    // the other lane half's 8 channels
@@ -398,6 +400,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 sa = ldexpf(1.0f, ea);
             }
             u32x4 ph, pl;
+            if (DVQ_ABLATE & 1024) {
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) { ph[j2] = __float_as_uint(xv[2 * j2]); pl[j2] = __float_as_uint(xv[2 * j2 + 1]); }
+            } else {
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
                 const float v0 = xv[2 * j2] * sa, v1 = xv[2 * j2 + 1] * sa;
@@ -408,21 +414,27 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 ph[j2] = __builtin_bit_cast(unsigned, hh);
                 pl[j2] = __builtin_bit_cast(unsigned, ll);
             }
+            }
             xh = __builtin_bit_cast(f16x8, ph);
             xl = __builtin_bit_cast(f16x8, pl);
         };
         take_group(0);
 #pragma unroll
         for (int s = 0; s < S16; ++s) {
-            DVQ_TC(tc_bar, { __builtin_amdgcn_s_barrier(); });   // k-step s of the weights landed (everybody's pieces); s - 1 consumed
+            if (!(DVQ_ABLATE & 512)) DVQ_TC(tc_bar, { __builtin_amdgcn_s_barrier(); });   // k-step s of the weights landed (everybody's pieces); s - 1 consumed
             asm volatile("" ::: "memory");
             if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers already converted
             const char *buf = lds + (s & 3) * IMG_BYTES;
             const f16x8 bh = xh, bl = xl;
 #pragma unroll
             for (int t8 = 0; t8 < 8; ++t8) {
-                const f16x8 ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
-                const f16x8 al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
+                f16x8 ah, al;
+                if (DVQ_ABLATE & 256) { ah = bh; al = bl; }
+                else {
+                    ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
+                    al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
+                }
+                if (DVQ_ABLATE & 2048) { asm volatile("" : "+v"(acc[t8]) : "v"(ah), "v"(al), "v"(bh), "v"(bl)); continue; }
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t8], 0, 0, 0);
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t8], 0, 0, 0);
