@@ -59,6 +59,10 @@ def parse():
                          "output is written); model2: the same order as two kernels (select + conv kernel writing h, then the "
                          "dense assign); tokens: routed assign, codes only, + permuter; tokens_model: the same behind the models' "
                          "quant_conv (the fused op, codes only), what stage 2's encode_to_z runs on a stage-1 checkpoint")
+    ap.add_argument("--no-model-order", action="store_true",
+                    help="default command only (1 GPU, weak, --path routed): skip the short second measurement of the "
+                         "model order (--path model: the same step behind the models' 1x1 quant_conv, as one op) that is "
+                         "reported under 'model_order' beside the headline")
     ap.add_argument("--spinup", type=int, default=100,
                     help="untimed steps before the warmup that bring the GPU out of its idle power state "
                          "(the first ~30 ms after idle run ~10 %% slower); reported in config.spinup_steps")
@@ -299,9 +303,14 @@ class WeakDual:
             return np.ascontiguousarray(np.concatenate(parts, 0)[:B])
         hf = synth.z_tokens(self.E_np, b0, H, W, 2903 + 100 * k, image_offset=off)
         hc = synth.z_tokens(self.E_np, b0, H // 2, W // 2, 2913 + 100 * k, image_offset=off)
-        if self.conv_q is not None:                          # pre-images under the conv (see __init__)
-            pre = lambda t: np.einsum("oc,bohw->bchw", self.conv_q.astype(np.float64),
-                                      t.astype(np.float64) - self.conv_b.astype(np.float64)[None, :, None, None]).astype(np.float32)
+        if self.conv_q is not None:                          # pre-images under the conv (see __init__); float64, on the GPU (set-up)
+            import torch
+            q64 = torch.from_numpy(self.conv_q.astype(np.float64)).to(self.dev)
+            b64 = torch.from_numpy(self.conv_b.astype(np.float64)).to(self.dev)
+
+            def pre(t):
+                t64 = torch.from_numpy(t).to(self.dev).double() - b64[None, :, None, None]
+                return torch.einsum("oc,bohw->bchw", q64, t64).float().cpu().numpy()
             hf, hc = pre(hf), pre(hc)
         hf, hc = tile(hf), tile(hc)
         ent = tile(synth.entropy_map(5903 + 100 * k, b0, H // 2, W // 2, image_offset=off))
@@ -735,6 +744,45 @@ def run_rank(a):
                 parity["exchange_ok"] = bool(torch.equal(g_codes[s0:s0 + B], last.codes) and
                                              torch.equal(g_grain[s0:s0 + B], last.grain))
 
+    # the model order beside the headline: the same step behind the models' 1x1 quant_conv (select -> conv -> assign as ONE op,
+    # --path model), a short second measurement on the same streams, its own inputs and its own parity check
+    model_order = None
+    if (world == 1 and a.scaling == "weak" and a.path == "routed" and a.mode == "filter" and not a.no_model_order and not force_xch):
+        import copy
+        a2 = copy.copy(a)
+        a2.path = "model"
+        wl2 = WeakDual(a2, rank, world, dev)
+        wl2.prep_dom = wl.prep_dom
+        n2 = [0]
+
+        def step2():
+            k = n2[0]
+            n2[0] += 1
+            with torch.cuda.stream(streams[k % S]):
+                wl2.step(wl2.slots[k % S])
+        step2()
+        torch.cuda.synchronize()
+        for _ in range(50):
+            step2()
+        torch.cuda.synchronize()
+        k2 = min(a.steps, 200)
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            step2()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        model_order = {"path": "model", "workload": wl2.describe(), "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                       "value": wl2.Bglobal * k2 / dt2, "unit": "images/s",
+                       "note": "bench.py --path model is the full measurement of this path (own roofline, serial step, all slots checked)"}
+        if not a.no_parity:
+            p2 = wl2.parity(wl2.slots[(n2[0] - 1) % S])
+            bad2 = sum(v for k_, v in p2.items() if k_.endswith("_mismatches"))
+            model_order["parity_checked"] = bool(bad2 == 0 and p2["loss_rel_err"] <= 1e-5)
+            model_order["parity"] = {k_: p2[k_] for k_ in ("images_checked", "code_mismatches", "zq_mismatches", "h_max_err_over_bound",
+                                                          "codes_match_rate_vs_fp64_conv", "rerun_with_h_buf_mismatches", "loss_rel_err")}
+        del wl2
+        torch.cuda.empty_cache()
+
     # the same K steps strictly serial (one stream, one slot's buffers): what a caller without stream slots gets
     serial_ms = None
     if S > 1:
@@ -826,6 +874,8 @@ def run_rank(a):
             out["parity"] = parity
             if world == 1 and getattr(wl, "oracle_seconds", None):
                 out["parity"]["oracle_full_batch_images_per_s"] = wl.B / wl.oracle_seconds   # cold, fresh output arrays
+        if model_order is not None:
+            out["model_order"] = model_order
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
         sys.stdout.flush()

@@ -16,7 +16,7 @@ if has tests; then
 fi
 if has bench; then
   timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
-  timeout 300 python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_streams1.json
+  timeout 300 python bench.py --streams 1 --no-cpu-baseline --no-model-order > $O/bench_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_streams1.json
   timeout 300 python bench.py --path model --no-cpu-baseline > $O/bench_model.json 2>> $O/bench.err; cut -c1-200 $O/bench_model.json
   timeout 300 python bench.py --path model2 --no-cpu-baseline > $O/bench_model2.json 2>> $O/bench.err; cut -c1-200 $O/bench_model2.json
   timeout 300 python bench.py --path model --streams 1 --no-cpu-baseline --no-parity > $O/bench_model_streams1.json 2>> $O/bench.err; cut -c1-200 $O/bench_model_streams1.json
@@ -28,7 +28,7 @@ if has bench; then
 fi
 if has rocprof; then
   cd /tmp && export TMPDIR=/tmp
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s1 -o t -- python3 $R/bench.py --streams 1 --no-cpu-baseline --no-parity > $O/trace_bench_streams1.json 2> $O/trace.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s1 -o t -- python3 $R/bench.py --streams 1 --no-cpu-baseline --no-parity --no-model-order > $O/trace_bench_streams1.json 2> $O/trace.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_model -o t -- python3 $R/bench.py --path model --streams 1 --no-cpu-baseline --no-parity > $O/trace_bench_model.json 2>> $O/trace.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tokens -o t -- python3 $R/bench.py --path tokens --streams 1 --no-cpu-baseline --no-parity > $O/trace_bench_tokens.json 2>> $O/trace.err
   cd $R
@@ -47,7 +47,7 @@ fi
 if has xch; then
   # what the exchange (pack kernel + RCCL all-gather + unpack kernel) adds to a step, on the 1-rank RCCL group a 1-GPU box allows
   for S in 1 3; do
-    timeout 300 python bench.py --streams $S --no-cpu-baseline --no-parity > $O/xch_plain_s$S.json 2>> $O/bench.err
+    timeout 300 python bench.py --streams $S --no-cpu-baseline --no-parity --no-model-order > $O/xch_plain_s$S.json 2>> $O/bench.err
     DVQ_BENCH_FORCE_EXCHANGE=1 timeout 300 python bench.py --streams $S --no-cpu-baseline --no-parity > $O/xch_rccl1_s$S.json 2>> $O/bench.err
   done
   cd /tmp && export TMPDIR=/tmp
