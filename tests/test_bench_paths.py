@@ -1,0 +1,44 @@
+"""GPU (-m gpu): every path of bench.py at a small batch -- one JSON line with the contract's fields, `roofline`, the path's own
+parity check green; the default path also reports the model order (the fused quant_conv op) beside the headline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--spinup", "2", "--batch", "16",
+                        "--no-cpu-baseline"] + list(extra), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("path", ["model", "model2", "tokens_model", "tokens"])
+def test_bench_path_runs_and_checks_itself(path):
+    d = _run("--path", path)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["config"]["path"] == path and d["steps"] == 6 and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["parity_checked"] is True, d["parity"]
+    assert d["parity"]["code_mismatches"] == 0 and d["parity"]["slots_checked"] == 3
+    if path in ("model", "model2", "tokens_model"):
+        assert d["parity"]["h_max_err_over_bound"] < 1.0 and d["parity"]["codes_match_rate_vs_fp64_conv"] > 0.995
+    if path in ("model", "tokens_model"):
+        assert d["parity"]["rerun_with_h_buf_mismatches"] == 0
+        assert "1, true>" in d["roofline"]["kernel"]
+
+
+def test_default_bench_reports_the_model_order_too():
+    d = _run()
+    assert d["config"]["path"] == "routed" and d["parity_checked"] is True
+    m = d["model_order"]
+    assert m["path"] == "model" and m["ms_per_step"] > 0 and m["parity_checked"] is True and m["parity"]["code_mismatches"] == 0
+    assert "model_order" not in _run("--no-model-order", "--no-parity")
