@@ -310,7 +310,7 @@ class WeakDual:
 
             def pre(t):
                 t64 = torch.from_numpy(t).to(self.dev).double() - b64[None, :, None, None]
-                return torch.einsum("oc,bohw->bchw", q64, t64).float().cpu().numpy()
+                return np.ascontiguousarray(torch.einsum("oc,bohw->bchw", q64, t64).float().cpu().numpy())
             hf, hc = pre(hf), pre(hc)
         hf, hc = tile(hf), tile(hc)
         ent = tile(synth.entropy_map(5903 + 100 * k, b0, H // 2, W // 2, image_offset=off))
