@@ -257,3 +257,51 @@ def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
         sel1 = quant_conv_select(conv1, t(hc1), t(hf1), entropy=t(ent1), threshold=router.fine_grain_threshold)
     o1 = oracle_mod.vq_assign_nchw(sel1["h"].cpu().numpy(), E1, sel1["codebook_mask"].cpu().numpy())
     assert np.array_equal(info1[2].cpu().numpy().reshape(2, -1), o1["codes"]) and np.array_equal(q1.cpu().numpy(), o1["zq"])
+
+
+def test_fused_conv_running_scale_adversarial(dev, oracle_mod):
+    """the conv prologue's per-token scale follows the RUNNING maximum over the k-steps (an exact power-of-two rescale of the
+    accumulators when a later k-step outgrows it): tokens whose 16-channel groups differ by up to 2^+-30 in either order, groups
+    of zeros first / last / everywhere, fp32 subnormals, values near the fp32 maximum (the conv overflows: exact-list path) --
+    the conv output stays within 1e-5 * sum |w||x| of the fp64 conv and codes / z_q stay exact given it"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    K, D, B, H, W = 1024, 256, 4, 16, 16
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = synth.codebook_trained(K, D)
+    conv = _conv(dev, D, 900)
+    rng = np.random.default_rng(901)
+    x = synth.z_tokens(E, B, H, W, 902)
+    n = B * H * W
+    ex = rng.integers(-30, 31, size=(n, 16))                       # per token and 16-channel group: 2^ex
+    ex[: n // 4] = np.sort(ex[: n // 4], axis=1)                   # monotonically growing (a rescale at almost every k-step)
+    ex[n // 4: n // 2] = -np.sort(-ex[n // 4: n // 2], axis=1)     # monotonically shrinking (never a rescale after the first)
+    scale = np.repeat(np.ldexp(1.0, ex).astype(np.float32), 16, axis=1).reshape(B, H, W, D).transpose(0, 3, 1, 2)
+    x = (x * scale).astype(np.float32)
+    x[0, :16, 0, 0] = 0.0                                          # first group zero
+    x[0, 240:, 0, 1] = 0.0                                         # last group zero
+    x[0, :, 0, 2] = 0.0                                            # an all-zero token: h = bias
+    x[0, :, 0, 3] = np.float32(1e-40)                              # subnormal inputs
+    x[0, :, 0, 4] = 0.0; x[0, 255, 0, 4] = 3.0                     # everything in the last channel
+    x[0, :, 0, 5] = 0.0; x[0, 0, 0, 5] = -7.0                      # everything in the first channel
+    hb = torch.empty((B, D, H, W), device=dev)
+    zq, codes, loss = vq_assign(t(x), t(E), _CodebookPrep(), None, conv=conv, h_buf=hb)
+    h = hb.cpu().numpy()
+    ref, mag = _ref64(conv, x)
+    assert np.isfinite(h).all()
+    err = np.abs(h - ref) / mag
+    assert err.max() < 1e-5, err.max()
+    assert np.array_equal(h[0, :, 0, 2], conv.bias.detach().cpu().numpy())
+    o = oracle_mod.vq_assign_nchw(h, E, None)
+    assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+    # overflow: |x| near the fp32 maximum makes the conv non-finite; the token takes the exact-list path with the spilled h
+    xo = x.copy()
+    xo[1, :, 3, 3] = np.float32(3e38)
+    xo[2, 17, 5, 5] = np.float32(-3.3e38)
+    hb2 = torch.empty_like(hb)
+    zq2, codes2, _ = vq_assign(t(xo), t(E), _CodebookPrep(), None, conv=conv, h_buf=hb2)
+    h2 = hb2.cpu().numpy()
+    o2 = oracle_mod.vq_assign_nchw(h2, E, None)
+    assert np.array_equal(codes2.cpu().numpy().reshape(B, -1), o2["codes"]) and _nan_equal(zq2.cpu().numpy(), o2["zq"])
+    zq3, codes3, _ = vq_assign(t(xo), t(E), _CodebookPrep(), None, conv=conv)
+    assert torch.equal(codes2, codes3) and _nan_equal(zq2.cpu().numpy(), zq3.cpu().numpy())
