@@ -43,6 +43,8 @@ int dvq_launch_route_select(int G, int gate_mode, const void *gate, const float 
                             float *h_out, long long *indices, float *cmask, float thr, long long *gate_out,
                             hipStream_t st);
 int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate, hipStream_t st);
+int dvq_launch_vq_backward_z(const float *z, const float *E, const long long *codes, const float *mask, const float *g_zq,
+                             const float *g_loss, float coef_scale, int D, int HW, int K, long N, float *gz, hipStream_t st);
 int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
                             hipStream_t st);
 
@@ -345,6 +347,20 @@ int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
     return routed_common("dvq_vq_assign_routed_qconv_triple_f32", 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine,
                          codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, nullptr, ws, ws_bytes,
                          mode, stream, qconv_prep, h_buf, h_all, true);
+}
+
+int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+                             const float *g_zq, const float *g_loss, float coef_scale,
+                             int B, int D, int HW, int K, float *g_z, void *stream)
+{
+    const char *fn = "dvq_vq_backward_nchw_f32";
+    if (!z || !codebook || !codes || !g_z) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if (!g_zq && !g_loss) { dvq_set_error("%s: neither g_zq nor g_loss given", fn); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    if (D % 16 != 0) { dvq_set_error("%s: D=%d must be a multiple of 16", fn, D); return DVQ_EUNSUPPORTED; }
+    if ((((uintptr_t)codebook) & 15) != 0) { dvq_set_error("%s: codebook must be 16-byte aligned", fn); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_vq_backward_z(z, codebook, (const long long *)codes, mask, g_zq, g_loss, coef_scale, D, HW, K,
+                                           (long)B * HW, g_z, (hipStream_t)stream), fn);
 }
 
 int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx, int64_t n,

@@ -59,9 +59,12 @@
 //   image of tile t: [s < D/16][lane < 64][j < 8] halves = fp16(2^b E[32t + (lane&31)][16s + 8(lane>>5) + j])
 //   -> the A fragment of k-step s is ONE ds_read_b128 at s*1024 + lane*16 (lane-linear, conflict-free)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void codebook_meta_kernel(const float *__restrict__ E, int K, int D,
-                                                             const float *__restrict__ en_all,
-                                                             DvqF16Meta *__restrict__ meta)
+// two steps (the codebook is rebuilt at every training step: a single workgroup scanning K x D took 74 us): META_BLOCKS workgroups
+// reduce slices to partial maxima, parked in the unused tail of the 256-byte meta slot; one wave finishes.
+static constexpr int META_BLOCKS = 16;                   // 3 floats each: 192 B = the slot's tail
+__global__ __launch_bounds__(1024) void codebook_meta_partial_kernel(const float *__restrict__ E, int K, int D,
+                                                                     const float *__restrict__ en_all,
+                                                                     DvqF16Meta *__restrict__ meta)
 {
     __shared__ float s_max[1024];
     __shared__ float s_en[1024];
@@ -69,12 +72,12 @@ __global__ __launch_bounds__(1024) void codebook_meta_kernel(const float *__rest
     float amax = 0.0f, enmax = 0.0f;
     int bad = 0;
     const size_t total = (size_t)K * D;
-    for (size_t i = threadIdx.x; i < total; i += 1024) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (size_t)META_BLOCKS * 1024) {
         float v = fabsf(E[i]);
         bad |= !(v < __builtin_inff());
         amax = fmaxf(amax, v);
     }
-    for (int j = threadIdx.x; j < K; j += 1024) {
+    for (int j = blockIdx.x * 1024 + threadIdx.x; j < K; j += META_BLOCKS * 1024) {
         float v = en_all[j];
         bad |= !(v < __builtin_inff());
         enmax = fmaxf(enmax, v);
@@ -92,9 +95,24 @@ __global__ __launch_bounds__(1024) void codebook_meta_kernel(const float *__rest
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        amax = s_max[0];
-        enmax = s_en[0];
-        bad = s_bad[0];
+        float *part = (float *)((char *)meta + 64) + 3 * blockIdx.x;
+        part[0] = s_max[0];
+        part[1] = s_en[0];
+        part[2] = s_bad[0] ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(64) void codebook_meta_kernel(DvqF16Meta *__restrict__ meta)
+{
+    const float *part = (const float *)((const char *)meta + 64);
+    if (threadIdx.x == 0) {
+        float amax = 0.0f, enmax = 0.0f;
+        int bad = 0;
+        for (int i = 0; i < META_BLOCKS; ++i) {
+            amax = fmaxf(amax, part[3 * i]);
+            enmax = fmaxf(enmax, part[3 * i + 1]);
+            bad |= part[3 * i + 2] != 0.0f;
+        }
         int b = 0;
         if (amax > 0.0f) {
             int e;
@@ -180,25 +198,26 @@ __global__ __launch_bounds__(256) void codebook_prep_f16x_kernel(const float *__
     }
 }
 
-// etamax = max_j || 2^b e_j - fp16(2^b e_j) ||_2 (each residual is exact in fp32), rounded up
+// etamax = max_j || 2^b e_j - fp16(2^b e_j) ||_2 (each residual is exact in fp32), rounded up.  A wave per code (coalesced rows).
 __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restrict__ E, int K, int D,
                                                            DvqF16Meta *__restrict__ meta)
 {
     const float sb = meta->scale_b;
+    const int lane = threadIdx.x & 63;
     float best = 0.0f;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K; j += gridDim.x * blockDim.x) {
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < K; j += gridDim.x * 4) {
         const float *e = E + (size_t)j * D;
         float s = 0.0f;
-        for (int k = 0; k < D; ++k) {
+        for (int k = lane; k < D; k += 64) {
             float v = e[k] * sb;
             float r = v - (float)(_Float16)v;
             s += r * r;
         }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         best = fmaxf(best, s);
     }
-    for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
-    if ((threadIdx.x & 63) == 0 && best > 0.0f) {
-        float v = sqrtf(best) * 1.001f;
+    if (lane == 0 && best > 0.0f) {
+        float v = sqrtf(best) * 1.001f;     // (the summation order differs from a sequential sum by a few ulp: inside the 0.1 % margin)
         atomicMax((int *)&meta->etamax, __float_as_int(v));       // positive floats order as ints
     }
 }
@@ -1791,14 +1810,19 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     DvqF16Meta *meta = (DvqF16Meta *)base;
     char *img = base + 256;
     const float *en_all = (const float *)((char *)prep + dvq_prep_en_offset(K, D));
-    hipLaunchKernelGGL(codebook_meta_kernel, dim3(1), dim3(1024), 0, st, E, K, D, en_all, meta);
+    hipLaunchKernelGGL(codebook_meta_partial_kernel, dim3(META_BLOCKS), dim3(1024), 0, st, E, K, D, en_all, meta);
+    hipLaunchKernelGGL(codebook_meta_kernel, dim3(1), dim3(64), 0, st, meta);
     size_t total = (size_t)dvq_num_tiles(K) * ((size_t)(D / 16) * 512 + 128);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(codebook_prep_f16_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all, img);
     hipLaunchKernelGGL(codebook_prep_f16x_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all,
                        img + dvq_img16_offset(K, D));
-    hipLaunchKernelGGL(codebook_eta_kernel, dim3((K + 255) / 256), dim3(256), 0, st, E, K, D, meta);
+    {
+        int eb = (K + 3) / 4;
+        if (eb > 2048) eb = 2048;
+        hipLaunchKernelGGL(codebook_eta_kernel, dim3(eb), dim3(256), 0, st, E, K, D, meta);
+    }
     return (int)hipGetLastError();
 }
 

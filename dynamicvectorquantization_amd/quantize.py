@@ -360,9 +360,11 @@ class _VQStraightThrough(torch.autograd.Function):
     plus the commitment-loss gradients 2 c (z - e) m / numel on z (c = coefficient of the
     (z_q.detach() - z)^2 term) and 2 c' (e - z) m / numel scattered onto the codebook rows.
 
-    The codebook is NOT saved for backward: like the reference (F.embedding on the codebook keeps
-    only the indices) the rows e chosen at forward time are what the gradient uses, so the EMA update
-    may overwrite the weight in place between forward and backward."""
+    The live codebook is NOT what backward reads: like the reference (F.embedding keeps only the indices and the rows it read)
+    the rows chosen at forward time are what the gradient uses, so the EMA update may overwrite the weight in place between
+    forward and backward -- a snapshot of the [K, D] codebook (1 MiB) is saved, not the [B, HW, D] gathered rows.
+    d/dz runs as ONE kernel (`dvq_vq_backward_nchw_f32`: read z and g_zq, gather e from the snapshot, write g_z) in the same fp32
+    operation order as the torch expression below, which remains the path for CPU tensors / odd channel counts."""
 
     @staticmethod
     def forward(ctx, z, weight, mask, prep, K, coef_z, coef_e, mode):
@@ -373,31 +375,46 @@ class _VQStraightThrough(torch.autograd.Function):
             prep.used(z.device)
         need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_z or need_w:
-            e = embed_gather(codebook, codes.reshape(z.shape[0], -1))          # [B, HW, D], forward-time rows
-            ctx.save_for_backward(z, e, mask, codes)
+            ctx.save_for_backward(z, codebook.detach().clone(), mask, codes)      # forward-time codebook
         ctx.wshape, ctx.coef_z, ctx.coef_e = tuple(weight.shape), coef_z, coef_e
         ctx.mark_non_differentiable(codes)
         return zq, loss[1], codes
 
     @staticmethod
     def backward(ctx, g_zq, g_loss, _g_codes):
-        z, e, mask, codes = ctx.saved_tensors
+        z, snap, mask, codes = ctx.saved_tensors
         B, D = z.shape[0], z.shape[1]
-        diff = z - e.permute(0, 2, 1).reshape(z.shape)
-        if mask is not None:
-            diff = diff * mask.reshape(B, 1, *z.shape[2:])
+        need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         scale = 2.0 / z.numel()
-        gz = g_zq if ctx.needs_input_grad[0] else None
-        gw = None
-        if g_loss is not None:
-            if ctx.needs_input_grad[0]:
-                gz = (g_zq if g_zq is not None else 0) + g_loss * (ctx.coef_z * scale) * diff
-            if ctx.needs_input_grad[1]:
-                gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
+        gz, gw = None, None
+        fused = (need_z and z.is_cuda and z.dtype == torch.float32 and D % 16 == 0 and z.is_contiguous()
+                 and (g_zq is None or (g_zq.dtype == torch.float32 and g_zq.is_cuda)))
+        if need_z and g_loss is None:
+            gz = g_zq
+        elif fused:
+            HW = z[0, 0].numel()
+            gq = None if g_zq is None else g_zq.contiguous()
+            gl = g_loss.reshape(1).to(torch.float32).contiguous()
+            m = None if mask is None else _lib.require_cuda_f32(mask, "codebook_mask")
+            gz = torch.empty_like(z)
+            with torch.cuda.device(z.device):
+                _lib.check(_lib_handle.dvq_vq_backward_nchw_f32(
+                    z.data_ptr(), snap.data_ptr(), codes.data_ptr(), _lib.ptr(m), _lib.ptr(gq), gl.data_ptr(),
+                    float(ctx.coef_z * scale), B, D, HW, snap.shape[0], gz.data_ptr(), _lib.stream_ptr(z.device)),
+                    "dvq_vq_backward_nchw_f32")
+        diff = None
+        if (need_z and gz is None) or (need_w and g_loss is not None):
+            e = embed_gather(snap, codes.reshape(B, -1)) if z.is_cuda else snap[codes.reshape(B, -1)]   # [B, HW, D]
+            diff = z - e.permute(0, 2, 1).reshape(z.shape)
+            if mask is not None:
+                diff = diff * mask.reshape(B, 1, *z.shape[2:])
+        if need_z and gz is None:
+            gz = (g_zq if g_zq is not None else 0) + g_loss * (ctx.coef_z * scale) * diff
+        if need_w:
+            gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
+            if g_loss is not None:
                 ge = (-(g_loss * (ctx.coef_e * scale)) * diff).reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D)
                 gw.index_add_(0, codes.reshape(-1), ge)
-        elif ctx.needs_input_grad[1]:
-            gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
         return gz, gw, None, None, None, None, None, None
 
 
@@ -494,9 +511,10 @@ class VQEmbedding(nn.Embedding):
         the reference's two all_reduce calls (:87-88) are one all_reduce over the flat [K*D + K]
         statistics buffer; the restart vectors are broadcast from rank 0 as in :100."""
         n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
-        vectors = vectors.reshape(-1, embed_dim)
         idxs = idxs.reshape(-1)
-        n_vectors = vectors.shape[0]
+        if nchw is None or not (nchw.is_cuda and nchw.dtype == torch.float32):
+            vectors = vectors.reshape(-1, embed_dim)      # token rows (with NCHW latents on the GPU they are never materialised:
+            nchw = None                                   # `vectors` stays the permuted VIEW [B, HW, D], rows are picked by index)
         cluster_size, vectors_sum_per_cluster, flat = self._cluster_sums(vectors, idxs, nchw)
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -510,10 +528,16 @@ class VQEmbedding(nn.Embedding):
         """n_embed input vectors in random order (tiled with noise if the batch has fewer), the same on
         every rank (quantize2_mask.py:93-100)"""
         n_embed = self.weight.shape[0] - 1
-        if vectors.shape[0] < n_embed:
-            vectors = self._tile_with_noise(vectors, n_embed)
-        pick = torch.randperm(vectors.shape[0], device=vectors.device)[:n_embed]
-        chosen = vectors[pick]
+        n_vectors = vectors.numel() // vectors.shape[-1]
+        if n_vectors < n_embed:
+            vectors = self._tile_with_noise(vectors.reshape(-1, vectors.shape[-1]), n_embed)
+            n_vectors = vectors.shape[0]
+        pick = torch.randperm(n_vectors, device=vectors.device)[:n_embed]
+        if vectors.dim() == 3:                            # the permuted view [B, HW, D] of NCHW latents: K rows by (image, position)
+            hw = vectors.shape[1]
+            chosen = vectors[torch.div(pick, hw, rounding_mode="floor"), pick % hw].contiguous()
+        else:
+            chosen = vectors[pick]
         if dist.is_available() and dist.is_initialized():
             dist.broadcast(chosen, 0)
         return chosen

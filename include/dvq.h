@@ -223,6 +223,19 @@ int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
                                           int64_t *indices, float *cmask, float *h_buf, int h_all,
                                           void *ws, size_t ws_bytes, int mode, void *stream);
 
+/*
+ * Backward of the quantizer's forward with respect to its input -- what autograd derives from the reference graph
+ * (quantize2_mask.py:172-182, quantize_vqgan.py:290-298): identity through z + (z_q - z).detach() plus the commitment term,
+ *   g_z = g_zq + (g_loss * coef_scale) * ((z - e) * mask),   e = codebook[codes]  (the codebook AS IT WAS at forward time:
+ *   callers keep a snapshot, the EMA update rewrites the weight between forward and backward), coef_scale = 2 c / numel.
+ * One streaming pass (the reference: five or six element-wise passes and a transposed copy of e); same fp32 operation order
+ * as that expression.  g_zq nullable (only the loss was used), g_loss nullable (only z_q was used; a device scalar otherwise),
+ * mask nullable; D % 16 == 0.
+ */
+int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+                             const float *g_zq, const float *g_loss, float coef_scale,
+                             int B, int D, int HW, int K, float *g_z, void *stream);
+
 /* Audit aid (tools/bound_audit.py, tests/test_bound_audit.py): the pass-1 score arithmetic of DVQ_MODE_FILTER on
  * n tokens given as rows [n, D] -- every fp16-MFMA score G_j ~ -2^(b-1) (d_j - xn) as pass 1 sees it (index bits
  * packed into the low mantissa bits), the per-token decision threshold 2W, the exact norm xn and the codebook scale

@@ -274,3 +274,51 @@ def test_list_quantizer_train_golden(dev, monkeypatch):
                       ("weight_after", m.codebook.weight[:K])):
         assert _close(got.detach().cpu().numpy(), g[name], 1e-5), name
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,HW", [(256, 32 * 32), (64, 7 * 9), (128, 16)])
+def test_fused_backward_kernel_equals_the_torch_expression(dev, D, HW):
+    """dvq_vq_backward_nchw_f32 (one streaming pass) against the element-wise torch expression it replaces, bit for bit:
+    g_z = g_zq + (g_loss * fl(2 c / numel)) * ((z - e) * m), with and without mask / g_zq, and through autograd with a loss-only
+    and a z_q-only objective; the forward-time codebook is used even when the weight is overwritten before backward"""
+    from dynamicvectorquantization_amd import _lib, synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    B, K = 3, 256
+    E = synth.codebook_trained(K, D, seed=8101)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    z = t(synth.normal(8102, (B, D, HW), 0.0, 1.0))
+    codes = torch.from_numpy(np.random.default_rng(8103).integers(0, K, (B, HW))).to(dev)
+    mask = t(np.where(synth.bernoulli(8104, (B, HW), 0.5), 1.0, 0.25).astype(np.float32))
+    gq = t(synth.normal(8105, (B, D, HW), 0.0, 1.0))
+    gl = torch.tensor(3.0, device=dev)
+    Et = t(E)
+    e = Et[codes].permute(0, 2, 1)
+    cs = 0.25 * (2.0 / z.numel())
+    for m_, gq_ in ((mask, gq), (None, gq), (mask, None)):
+        gz = torch.empty_like(z)
+        _lib.check(_lib.lib.dvq_vq_backward_nchw_f32(z.data_ptr(), Et.data_ptr(), codes.data_ptr(), _lib.ptr(m_), _lib.ptr(gq_),
+                                                     gl.reshape(1).data_ptr(), float(cs), B, D, HW, K, gz.data_ptr(),
+                                                     _lib.stream_ptr(dev)), "bw")
+        diff = z - e
+        if m_ is not None:
+            diff = diff * m_.reshape(B, 1, HW)
+        want = (gq_ if gq_ is not None else 0) + gl * cs * diff
+        assert torch.equal(gz, want)
+    # through the module: the loss alone, z_q alone, and the weight overwritten between forward and backward
+    vq = VectorQuantize2(K, D, accept_image_fmap=True).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(Et)
+    x = z.reshape(B, D, HW, 1).clone().requires_grad_(True)
+    q, loss, (_, _, c) = vq(x)
+    w0 = vq.codebook.weight.data[:-1].clone()
+    vq.codebook.weight.data[:-1].mul_(-3.0)                   # what an in-place EMA update would do before backward
+    loss.backward()
+    e2 = w0[c.reshape(B, HW)].permute(0, 2, 1).reshape(x.shape)
+    want = (torch.tensor(1.0, device=dev) * (0.25 * (2.0 / x.numel()))) * (x.detach() - e2)
+    assert torch.equal(x.grad, want)
+    x.grad = None
+    vq.codebook.weight.data[:-1].copy_(w0)
+    vq.invalidate_codebook_cache()
+    q, loss, _ = vq(x)
+    q.backward(gq.reshape(x.shape))
+    assert torch.equal(x.grad, gq.reshape(x.shape))
