@@ -64,5 +64,8 @@ if has misc; then
   DVQ_LIBRARY=$TUNE timeout 400 python tools/bound_audit.py 256 --production > $O/bound_audit_production.json 2>> $O/bench.err; tail -1 $O/bound_audit_production.json
   timeout 300 python tools/stream_power_probe.py > $O/stream_power_probe.json 2>> $O/bench.err
   timeout 300 python tools/roofline_table.py > $O/roofline_table.json 2>> $O/bench.err
+  timeout 300 python tools/train_step_probe.py > $O/train_step.jsonl 2>> $O/bench.err; cat $O/train_step.jsonl
+  timeout 300 python tools/ema_probe.py > $O/ema_probe.txt 2>> $O/bench.err
+  timeout 300 python tools/conv_fused_probe.py > $O/conv_fused_probe.json 2>> $O/bench.err; cut -c1-300 $O/conv_fused_probe.json
 fi
 ls $O | head -80
