@@ -45,6 +45,8 @@ int dvq_launch_route_select(int G, int gate_mode, const void *gate, const float 
 int dvq_launch_entropy_gate(const float *ent, long n, float thr, long long *gate, hipStream_t st);
 int dvq_launch_vq_backward_z(const float *z, const float *E, const long long *codes, const float *mask, const float *g_zq,
                              const float *g_loss, float coef_scale, int D, int HW, int K, long N, float *gz, hipStream_t st);
+int dvq_launch_codebook_grad(const float *z, const float *E, const long long *codes, const float *mask, const float *g_loss,
+                             float coef_scale, int D, int HW, long N, int K, float *gw, hipStream_t st);
 int dvq_launch_embed_gather(const float *E, int K, int D, const long long *idx, long n, float *out,
                             hipStream_t st);
 
@@ -361,6 +363,18 @@ int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_
     if ((((uintptr_t)codebook) & 15) != 0) { dvq_set_error("%s: codebook must be 16-byte aligned", fn); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_vq_backward_z(z, codebook, (const long long *)codes, mask, g_zq, g_loss, coef_scale, D, HW, K,
                                            (long)B * HW, g_z, (hipStream_t)stream), fn);
+}
+
+int dvq_vq_backward_codebook_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+                                      const float *g_loss, float coef_scale, int B, int D, int HW, int K,
+                                      float *g_weight, void *stream)
+{
+    const char *fn = "dvq_vq_backward_codebook_nchw_f32";
+    if (!z || !codebook || !codes || !g_loss || !g_weight) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
+    if (K > 8192) { dvq_set_error("%s: K=%d > 8192 (index_add the differences instead)", fn, K); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_codebook_grad(z, codebook, (const long long *)codes, mask, g_loss, coef_scale, D, HW, (long)B * HW, K,
+                                           g_weight, (hipStream_t)stream), fn);
 }
 
 int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx, int64_t n,

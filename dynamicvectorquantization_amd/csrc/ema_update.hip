@@ -94,6 +94,77 @@ __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float *__rest
     }
 }
 
+// Gradient of the commitment loss with respect to the codebook (quantizers that train it by back-propagation: VectorQuantizer2,
+// quantize_vqgan.py:290-298; VectorQuantize2 without EMA): g_w[j, :] += c * sum over the tokens t with code j of (z_t - e_j) m_t,
+// c = -(g_loss * 2 c' / numel), e = the forward-time codebook.  The reference materialises the [N, D] differences, permutes them
+// and index_add_s them; here the EMA kernel's scheme applies: [64 channel x 64 token] tiles transposed through LDS, equal codes of
+// a tile summed first (leader + member mask), one row of float atomics per distinct code and tile.  K <= 8192 (the LDS table).
+__global__ __launch_bounds__(256) void codebook_grad_kernel(const float *__restrict__ z, const float *__restrict__ E,
+                                                            const long long *__restrict__ codes, const float *__restrict__ mask,
+                                                            const float *__restrict__ g_loss, float coef_scale,
+                                                            int D, int HW, long N, int K, float *__restrict__ gw)
+{
+    __shared__ float tile[64][65];
+    __shared__ int code_s[64];
+    __shared__ float m_s[64];
+    __shared__ unsigned mask_s[64][2];
+    extern __shared__ int first_s[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long tok0 = (long)blockIdx.x * 64;
+    for (int i = threadIdx.x; i < K; i += 256) first_s[i] = 64;
+    if (threadIdx.x < 64) { mask_s[threadIdx.x][0] = 0u; mask_s[threadIdx.x][1] = 0u; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const long n = tok0 + threadIdx.x;
+        long long cj = (n < N) ? codes[n] : -1;
+        const bool ok = cj >= 0 && cj < K;
+        code_s[threadIdx.x] = ok ? (int)cj : -1;
+        m_s[threadIdx.x] = (ok && mask != nullptr) ? mask[n] : 1.0f;
+        if (ok) atomicMin(&first_s[(int)cj], (int)threadIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cj = code_s[threadIdx.x];
+        if (cj >= 0) atomicOr(&mask_s[first_s[cj]][threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+    }
+    const float c = -__fmul_rn(g_loss[0], coef_scale);
+    const long n = tok0 + lane;
+    const long nn = (n < N) ? n : N - 1;
+    const long b = nn / HW;
+    const int hw = (int)(nn - b * HW);
+    const float *zp = z + (size_t)b * D * HW + hw;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = 16 * wave + i;
+            tile[ch][lane] = (c0 + ch < D) ? zp[(size_t)(c0 + ch) * HW] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int tk = 16 * wave + i;
+            unsigned m0 = __builtin_amdgcn_readfirstlane(mask_s[tk][0]), m1 = __builtin_amdgcn_readfirstlane(mask_s[tk][1]);
+            if ((m0 | m1) == 0u) continue;
+            const int cj = code_s[tk];
+            const float e = (c0 + lane < D) ? E[(size_t)cj * D + c0 + lane] : 0.0f;
+            float sum = 0.0f;
+            while (m0) { const int t = __builtin_ctz(m0); m0 &= m0 - 1; sum += (tile[lane][t] - e) * m_s[t]; }
+            while (m1) { const int t = __builtin_ctz(m1); m1 &= m1 - 1; sum += (tile[lane][32 + t] - e) * m_s[32 + t]; }
+            if (c0 + lane < D) atomicAdd(&gw[(size_t)cj * D + c0 + lane], c * sum);
+        }
+    }
+}
+
+int dvq_launch_codebook_grad(const float *z, const float *E, const long long *codes, const float *mask, const float *g_loss,
+                             float coef_scale, int D, int HW, long N, int K, float *gw, hipStream_t st)
+{
+    if (K > 8192) return -1000;
+    hipLaunchKernelGGL(codebook_grad_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)K * sizeof(int), st, z, E, codes,
+                       mask, g_loss, coef_scale, D, HW, N, K, gw);
+    return (int)hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void ema_zero_kernel(float *__restrict__ a, size_t na, float *__restrict__ b, size_t nb)
 {
     const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -402,6 +402,16 @@ class _VQStraightThrough(torch.autograd.Function):
                     z.data_ptr(), snap.data_ptr(), codes.data_ptr(), _lib.ptr(m), _lib.ptr(gq), gl.data_ptr(),
                     float(ctx.coef_z * scale), B, D, HW, snap.shape[0], gz.data_ptr(), _lib.stream_ptr(z.device)),
                     "dvq_vq_backward_nchw_f32")
+        if need_w and g_loss is not None and z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and snap.shape[0] <= 8192:
+            HW = z[0, 0].numel()
+            gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
+            gl = g_loss.reshape(1).to(torch.float32).contiguous()
+            m = None if mask is None else _lib.require_cuda_f32(mask, "codebook_mask")
+            with torch.cuda.device(z.device):
+                _lib.check(_lib_handle.dvq_vq_backward_codebook_nchw_f32(
+                    z.data_ptr(), snap.data_ptr(), codes.data_ptr(), _lib.ptr(m), gl.data_ptr(), float(ctx.coef_e * scale),
+                    B, D, HW, snap.shape[0], gw.data_ptr(), _lib.stream_ptr(z.device)), "dvq_vq_backward_codebook_nchw_f32")
+            need_w = False                                # done
         diff = None
         if (need_z and gz is None) or (need_w and g_loss is not None):
             e = embed_gather(snap, codes.reshape(B, -1)) if z.is_cuda else snap[codes.reshape(B, -1)]   # [B, HW, D]
@@ -410,9 +420,9 @@ class _VQStraightThrough(torch.autograd.Function):
                 diff = diff * mask.reshape(B, 1, *z.shape[2:])
         if need_z and gz is None:
             gz = (g_zq if g_zq is not None else 0) + g_loss * (ctx.coef_z * scale) * diff
-        if need_w:
+        if need_w or (gw is None and ctx.needs_input_grad[1]):
             gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
-            if g_loss is not None:
+            if g_loss is not None and need_w:
                 ge = (-(g_loss * (ctx.coef_e * scale)) * diff).reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D)
                 gw.index_add_(0, codes.reshape(-1), ge)
         return gz, gw, None, None, None, None, None, None

@@ -235,6 +235,13 @@ int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
 int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
                              const float *g_zq, const float *g_loss, float coef_scale,
                              int B, int D, int HW, int K, float *g_z, void *stream);
+/* ... and with respect to a codebook trained by back-propagation (VectorQuantizer2, quantize_vqgan.py:290-298; no EMA):
+ *   g_weight[j, :] += -(g_loss * coef_scale) * sum over tokens with code j of (z - codebook[j]) * mask
+ * ACCUMULATES into g_weight [>= K rows, D] (zero it first); float atomics, one row per distinct code of a 64-token tile:
+ * equal to the reference's index_add_ of the [N, D] differences up to summation order.  K <= 8192. */
+int dvq_vq_backward_codebook_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+                                      const float *g_loss, float coef_scale, int B, int D, int HW, int K,
+                                      float *g_weight, void *stream);
 
 /* Audit aid (tools/bound_audit.py, tests/test_bound_audit.py): the pass-1 score arithmetic of DVQ_MODE_FILTER on
  * n tokens given as rows [n, D] -- every fp16-MFMA score G_j ~ -2^(b-1) (d_j - xn) as pass 1 sees it (index bits

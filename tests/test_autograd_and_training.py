@@ -322,3 +322,40 @@ def test_fused_backward_kernel_equals_the_torch_expression(dev, D, HW):
     q, loss, _ = vq(x)
     q.backward(gq.reshape(x.shape))
     assert torch.equal(x.grad, gq.reshape(x.shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,HW,K", [(256, 32 * 32, 1024), (64, 7 * 9, 100), (96, 50, 8192)])
+def test_codebook_gradient_kernel_vs_index_add(dev, D, HW, K):
+    """dvq_vq_backward_codebook_nchw_f32 (tiles transposed through LDS, equal codes of a tile combined, one row of float atomics per
+    distinct code and tile) against the reference's construction -- index_add_ of the [N, D] masked differences -- in float64:
+    equal up to fp32 summation order; accumulates into g_weight; skewed code usage and runs of equal codes included"""
+    from dynamicvectorquantization_amd import _lib, synth
+    B = 4
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(8200 + D)
+    E = t(synth.normal(8201, (K, D), 0.0, 0.5))
+    z = t(synth.normal(8202, (B, D, HW), 0.0, 1.0))
+    codes_np = (rng.random((B, HW)) ** 3 * K).astype(np.int64).clip(0, K - 1)        # skewed: many tokens on the low codes
+    codes_np[0, : HW // 2] = np.repeat(codes_np[0, : HW // 2: 4], 4)[: HW // 2]      # runs of four equal codes
+    codes = t(codes_np)
+    mask = t(np.where(synth.bernoulli(8203, (B, HW), 0.5), 1.0, 0.25).astype(np.float32))
+    gl = torch.tensor(1.7, device=dev)
+    cs = 1.0 * (2.0 / z.numel())
+    for m_ in (mask, None):
+        gw = torch.zeros((K + 1, D), device=dev)
+        gw[K] = 0.5
+        run = lambda: _lib.check(_lib.lib.dvq_vq_backward_codebook_nchw_f32(
+            z.data_ptr(), E.data_ptr(), codes.data_ptr(), _lib.ptr(m_), gl.reshape(1).data_ptr(), float(cs), B, D, HW, K,
+            gw.data_ptr(), _lib.stream_ptr(dev)), "gw")
+        run()
+        diff = (z.double() - E.double()[codes].permute(0, 2, 1))
+        if m_ is not None:
+            diff = diff * m_.double().reshape(B, 1, HW)
+        ge = (-(gl.double() * cs) * diff).permute(0, 2, 1).reshape(-1, D)
+        want = torch.zeros((K + 1, D), dtype=torch.float64, device=dev).index_add_(0, codes.reshape(-1), ge)
+        err = (gw[:K].double() - want[:K]).abs().max() / want.abs().max()
+        assert float(err) < 1e-5, float(err)
+        assert torch.equal(gw[K], torch.full((D,), 0.5, device=dev))                 # the padding row is never touched
+        run()                                                                         # it ACCUMULATES
+        assert float((gw[:K].double() - 2 * want[:K]).abs().max() / want.abs().max()) < 2e-5
