@@ -305,3 +305,22 @@ def test_fused_conv_running_scale_adversarial(dev, oracle_mod):
     assert np.array_equal(codes2.cpu().numpy().reshape(B, -1), o2["codes"]) and _nan_equal(zq2.cpu().numpy(), o2["zq"])
     zq3, codes3, _ = vq_assign(t(xo), t(E), _CodebookPrep(), None, conv=conv)
     assert torch.equal(codes2, codes3) and _nan_equal(zq2.cpu().numpy(), zq3.cpu().numpy())
+
+
+@pytest.mark.parametrize("K", [100, 2048])
+def test_fused_conv_other_codebook_sizes(dev, oracle_mod, K):
+    """the conv prologue with codebooks that are not 1024 codes: fewer tiles than the ring's prefetch depth needs no special case,
+    and a large codebook takes the same (two-workgroups-per-CU) kernel -- exact given h in both cases"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    D, B, H, W = 256, 2, 16, 16
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = synth.codebook_trained(K, D)
+    conv = _conv(dev, D, 950 + K)
+    x = synth.z_tokens(E, B, H, W, 951 + K)
+    hb = torch.empty((B, D, H, W), device=dev)
+    zq, codes, loss = vq_assign(t(x), t(E), _CodebookPrep(), None, conv=conv, h_buf=hb)
+    o = oracle_mod.vq_assign_nchw(hb.cpu().numpy(), E, None)
+    assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+    ref, mag = _ref64(conv, x)
+    assert (np.abs(hb.cpu().numpy() - ref) / mag).max() < 2e-6
