@@ -324,3 +324,52 @@ def test_fused_conv_other_codebook_sizes(dev, oracle_mod, K):
     assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
     ref, mag = _ref64(conv, x)
     assert (np.abs(hb.cpu().numpy() - ref) / mag).max() < 2e-6
+
+
+def test_model_order_against_the_reference_models_own_encode(dev, oracle_mod, golden_dir):
+    """golden from the IMPORTED reference: `DualGrainVQModel.encode` itself (dqvae_dual_entropy.py:124-134; encoder, fixed-entropy
+    router and quantizer instantiated from the reference's YAML, seeded 1x1 quant_conv, trained-like codebook) run on CPU on one
+    synthetic image, the two encoder branch outputs captured by hooks (oracle/gen_golden_encode.py).  The fused op on those
+    inputs: grain map and gate equal; codes equal except at near-ties of the two convs' roundings (rate reported, > 99.5 %, and
+    every differing token's two candidates are within 1e-5 relative in distance given OUR h); loss within 1e-4; z_q within fp16
+    of the stored copy where the codes agree"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, _CodebookPrep, vq_assign_routed_dual
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    import zlib
+    g = np.load(os.path.join(golden_dir, "encode_dual_entropy_model_B1.npz"))
+    crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    K, D = 1024, 256
+    E = synth.codebook_trained(K, D)
+    cw, cb = synth.normal(9501, (D, D, 1, 1), 0.0, 1.0 / 16.0), synth.normal(9502, (D,), 0.0, 0.1)
+    assert crc(E) == g["cb_crc"] and crc(cw) == g["conv_w_crc"] and crc(cb) == g["conv_b_crc"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(cw)); conv.bias.copy_(t(cb))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    router = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    hf, hc, ent = t(g["h_fine"]), t(g["h_coarse"]), t(g["x_entropy"])
+    hb = torch.empty_like(hf)
+    with torch.no_grad():
+        quant, loss, info, grain, gate = encode_dual(router, vq, hf, hc, entropy=ent, quant_conv=conv)
+        r = vq_assign_routed_dual(hc, hf, t(E), _CodebookPrep(), entropy=ent, threshold=router.fine_grain_threshold, conv=conv, h_buf=hb)
+    assert torch.equal(info[2], r["codes"])
+    assert np.array_equal(grain.cpu().numpy(), g["grain"].astype(np.int64))
+    assert np.array_equal(gate.cpu().numpy(), g["gate"].astype(np.int64))
+    codes, ref = info[2].cpu().numpy().reshape(-1), g["codes"].astype(np.int64).reshape(-1)
+    rate = float((codes == ref).mean())
+    print("codes equal to the reference model's encode: %.5f (%d of %d differ)" % (rate, int((codes != ref).sum()), codes.size))
+    assert rate > 0.995
+    h = hb.cpu().numpy().reshape(D, -1).T.astype(np.float64)              # [tokens, D], the h our op scored
+    bad = np.nonzero(codes != ref)[0]
+    if bad.size:
+        d_ours = ((h[bad] - E[codes[bad]].astype(np.float64)) ** 2).sum(1)
+        d_ref = ((h[bad] - E[ref[bad]].astype(np.float64)) ** 2).sum(1)
+        assert np.all(np.abs(d_ref - d_ours) <= 1e-5 * np.maximum(d_ours, 1.0)), (d_ref - d_ours)
+    assert abs(float(loss) - float(g["emb_loss"])) <= 1e-4 * abs(float(g["emb_loss"]))
+    same = (codes == ref).reshape(1, 1, 32, 32).repeat(D, 1)
+    q, q16 = quant.cpu().numpy(), g["quant_f16"].astype(np.float32)
+    assert np.all(np.abs(q - q16)[same] <= 2e-3 * np.maximum(1.0, np.abs(q16))[same])
