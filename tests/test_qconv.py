@@ -373,3 +373,63 @@ def test_model_order_against_the_reference_models_own_encode(dev, oracle_mod, go
     same = (codes == ref).reshape(1, 1, 32, 32).repeat(D, 1)
     q, q16 = quant.cpu().numpy(), g["quant_f16"].astype(np.float32)
     assert np.all(np.abs(q - q16)[same] <= 2e-3 * np.maximum(1.0, np.abs(q16))[same])
+
+
+@pytest.mark.parametrize("kind", ["dual", "triple"])
+def test_feature_router_models_against_the_reference_models_own_encode(dev, golden_dir, kind):
+    """the same for the feature-router models: goldens from the reference's `DualGrainVQModel.encode` (dqvae_dual_feat.py:59-68) and
+    `TripleGrainVQModel.encode` (dqvae_triple_feat.py:68-77) run on CPU with encoder / router / quantizer from the reference's YAMLs and
+    a seeded router MLP: our drop-in router (fused gate kernel) + the fused select -> conv -> assign op give the gate logits within 1e-4,
+    the same grain map (all argmax margins of the golden exceed 2e-3), codes equal up to near-ties (> 99.5 %, each differing token's two
+    candidates within 1e-5 in distance given our h), loss within 1e-4"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual, encode_triple
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, _CodebookPrep, vq_assign_routed_dual, vq_assign_routed_triple
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    import zlib
+    g = np.load(os.path.join(golden_dir, "encode_%s_feature_model_B1.npz" % kind))
+    crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    G = 2 if kind == "dual" else 3
+    K, D = 1024, 256
+    F = G * D
+    E = synth.codebook_trained(K, D)
+    cw, cb = synth.normal(9501, (D, D, 1, 1), 0.0, 1.0 / 16.0), synth.normal(9502, (D,), 0.0, 0.1)
+    w1, b1 = synth.normal(9600 + G, (F, F), 0.0, 1.0 / np.sqrt(F)), synth.normal(9610 + G, (F,), 0.0, 0.1)
+    w2, b2 = synth.normal(9620 + G, (G, F), 0.0, 1.0 / np.sqrt(F)), synth.normal(9630 + G, (G,), 0.0, 0.1)
+    for a, k in ((E, "cb"), (cw, "conv_w"), (cb, "conv_b"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        assert crc(a) == g[k + "_crc"], k
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    router = (DualGrainFeatureRouter if G == 2 else TripleGrainFeatureRouter)(D, "group-32", "2layer-fc-SiLu").to(dev).eval()
+    with torch.no_grad():
+        router.gate[0].weight.copy_(t(w1)); router.gate[0].bias.copy_(t(b1))
+        router.gate[2].weight.copy_(t(w2)); router.gate[2].bias.copy_(t(b2))
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(cw)); conv.bias.copy_(t(cb))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    hf, hc = t(g["h_fine"]), t(g["h_coarse"])
+    hm = t(g["h_median"]) if G == 3 else None
+    hb = torch.empty_like(hf)
+    with torch.no_grad():
+        if G == 2:
+            quant, loss, info, grain, gate = encode_dual(router, vq, hf, hc, quant_conv=conv)
+            r = vq_assign_routed_dual(hc, hf, t(E), _CodebookPrep(), gate=router(h_fine=hf, h_coarse=hc), conv=conv, h_buf=hb)
+        else:
+            quant, loss, info, grain, gate = encode_triple(router, vq, hf, hm, hc, quant_conv=conv)
+            r = vq_assign_routed_triple(hc, hm, hf, t(E), _CodebookPrep(), router(h_fine=hf, h_median=hm, h_coarse=hc), conv=conv, h_buf=hb)
+    assert torch.equal(info[2], r["codes"])
+    assert float(g["gate_margin_min"]) > 2e-3
+    assert np.abs(gate.cpu().numpy() - g["gate"]).max() < 1e-4                     # [B, G, h, w] logits
+    assert np.array_equal(grain.cpu().numpy(), g["grain"].astype(np.int64))
+    codes, ref = info[2].cpu().numpy().reshape(-1), g["codes"].astype(np.int64).reshape(-1)
+    rate = float((codes == ref).mean())
+    print("%s feature model: codes equal to the reference model's encode: %.5f (%d differ)" % (kind, rate, int((codes != ref).sum())))
+    assert rate > 0.995
+    h = hb.cpu().numpy().reshape(D, -1).T.astype(np.float64)
+    bad = np.nonzero(codes != ref)[0]
+    if bad.size:
+        d_ours = ((h[bad] - E[codes[bad]].astype(np.float64)) ** 2).sum(1)
+        d_ref = ((h[bad] - E[ref[bad]].astype(np.float64)) ** 2).sum(1)
+        assert np.all(np.abs(d_ref - d_ours) <= 1e-5 * np.maximum(d_ours, 1.0))
+    assert abs(float(loss) - float(g["emb_loss"])) <= 1e-4 * abs(float(g["emb_loss"]))
