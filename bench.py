@@ -731,12 +731,19 @@ def run_rank(a):
         parity["slots_checked"] = nslots                      # stream slots (own inputs each) checked in full on this rank
         parity["slot_mismatches"] = nbad
         if world > 1:
-            keys = sorted(k for k in parity if k != "loss_rel_err")
-            tot = torch.tensor([parity[k] for k in keys], dtype=torch.int64, device=dev)
+            keys = sorted(k for k, v in parity.items() if isinstance(v, (int, bool)))          # counts: summed over the ranks
+            fkeys = sorted(k for k, v in parity.items() if isinstance(v, float) and k != "codes_match_rate_vs_fp64_conv")
+            tot = torch.tensor([int(parity[k]) for k in keys], dtype=torch.int64, device=dev)
             dist.all_reduce(tot)
-            lr = torch.tensor([parity["loss_rel_err"]], dtype=torch.float64, device=dev)
-            dist.all_reduce(lr, op=dist.ReduceOp.MAX)
-            parity = dict(zip(keys, (int(v) for v in tot.tolist())), loss_rel_err=float(lr.item()))
+            fl = torch.tensor([parity[k] for k in fkeys], dtype=torch.float64, device=dev)     # errors: the worst rank
+            dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+            rate = parity.get("codes_match_rate_vs_fp64_conv")
+            parity = dict(zip(keys, (int(v) for v in tot.tolist())))
+            parity.update(zip(fkeys, (float(v) for v in fl.tolist())))
+            if rate is not None:
+                rt = torch.tensor([rate], dtype=torch.float64, device=dev)
+                dist.all_reduce(rt, op=dist.ReduceOp.MIN)
+                parity["codes_match_rate_vs_fp64_conv"] = float(rt.item())
             if xchs:                       # the gathered global tensors agree with the local shard
                 xch = xchs[(nstep[0] - 1) % nx]
                 g_codes, g_grain, _ = xch.result()

@@ -141,7 +141,7 @@ def test_bench_launcher_spawns_ranks_and_exchanges_on_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DVQ_BENCH_BACKEND="gloo")
     env.pop("RANK", None)
-    for extra in (["--batch", "8"], ["--scaling", "strong", "--batch", "12"]):
+    for extra in (["--batch", "8"], ["--scaling", "strong", "--batch", "12"], ["--batch", "8", "--path", "model"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                             "--spinup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True,
                            timeout=900)
