@@ -61,6 +61,23 @@ def test_size_queries_and_validation_without_gpu():
     args[5], args[0] = 256, 5
     assert L.dvq_router_gate_f32(*args) == -1                                                  # branches
     assert L.dvq_permute_dual_count_i64(0, 1, 16, 16, 0, 0, 0) == -1
+    # round-3 entry points: the conv fused into the assign, the backward kernels
+    q = 256                                                                                     # a "pointer" that passes the alignment checks
+    assert L.dvq_vq_assign_qconv_f32(0, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, q, 0, q, 1 << 30, 1, 0) == -1      # null x
+    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 128, 1, 1, 0.25, 0, 1, 0, q, 0, q, 1 << 30, 1, 0) == -2      # D = 128
+    assert b"256" in L.dvq_last_error_string()
+    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, q, 0, q, 1 << 30, 0, 0) == -1      # exact mode
+    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, 0, 0, q, 1 << 30, 1, 0) == -1      # no h_buf
+    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1024, 1024, 0.25, 0, 1, 0, q, 0, q, 16, 1, 0) == -3    # workspace
+    assert L.dvq_vq_assign_routed_qconv_dual_f32(1, 0, 0.0, 1, 1, q, 1, 1, 1, 128, 4, 4, 64, 0.25, 0, 1, 0, 1, 1, 0, q, 0,
+                                                 q, 1 << 30, 1, 0) == -2                                              # D = 128
+    assert L.dvq_vq_assign_routed_qconv_triple_f32(1, 0, 1, 0, 1, q, 1, 1, 1, 256, 4, 4, 64, 0.25, 0, 1, 0, 1, 1, q, 0,
+                                                   q, 1 << 30, 1, 0) == -1                                            # null h_median
+    assert L.dvq_vq_backward_nchw_f32(0, 1, 1, 0, 1, 1, 1.0, 1, 256, 1, 8, 1, 0) == -1                              # null z
+    assert L.dvq_vq_backward_nchw_f32(1, 16, 1, 0, 0, 0, 1.0, 1, 256, 1, 8, 1, 0) == -1                             # nothing to propagate
+    assert L.dvq_vq_backward_nchw_f32(1, 16, 1, 0, 1, 1, 1.0, 1, 100, 1, 8, 1, 0) == -2                             # D % 16
+    assert L.dvq_vq_backward_codebook_nchw_f32(1, 1, 1, 0, 0, 1.0, 1, 256, 1, 8, 1, 0) == -1                        # null g_loss
+    assert L.dvq_vq_backward_codebook_nchw_f32(1, 1, 1, 0, 1, 1.0, 1, 256, 1, 10000, 1, 0) == -2                    # K > 8192
 
 
 def test_cpu_tensors_fail_loudly():
