@@ -522,10 +522,13 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         a.scale[i] = 1 << i;
     }
     a.nb = nb; a.B = B; a.C = C; a.hc = hc; a.wc = wc; a.groups = groups; a.eps = eps;
+    a.vec = 1;
+#ifdef DVQ_TUNING
     {
-        const char *e = getenv("DVQ_GATE_POOL_SCALAR");
-        a.vec = (e && e[0] == '1') ? 0 : 1;
+        const char *e = getenv("DVQ_GATE_POOL_SCALAR");       // tuning build only: the scalar pooling form for A/B
+        if (e && e[0] == '1') a.vec = 0;
     }
+#endif
     const int F = nb * C, Fp = (F + 15) & ~15;
     float2 *stats = (float2 *)ws;                            // (scale, shift) per (image, feature)
     float *pool = (float *)((char *)ws + align256r((size_t)B * F * sizeof(float2)));

@@ -161,3 +161,14 @@ def test_conv_prologue_isa_has_no_load_hazards():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_hazard_check.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 hazards, counted waits as placed") == 2, r.stdout
+
+
+def test_product_library_reads_no_environment():
+    """include/dvq.h promises that libdvq.so reads no environment variable (kernel choices are functions of the arguments and
+    compile-time constants): the product library does not even import getenv; the A/B switches live in libdvq_tuning.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "dynamicvectorquantization_amd", "csrc", "libdvq.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert out and "getenv" not in out

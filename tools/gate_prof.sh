@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export DVQ_LIBRARY=$R/dynamicvectorquantization_amd/csrc/libdvq_tuning.so   # the scalar / vector pooling switch exists in the tuning build only
 mkdir -p $R/gpurun_out/gateprof
 for sc in 0 1 0 1; do for cfg in "2 64" "2 256" "3 128" "3 512"; do
   set -- $cfg
