@@ -25,6 +25,7 @@ class _ConvPrep:
 
     def __init__(self):
         self.key, self.buf = None, None
+        self._built = None                   # (stream handle, event) of the last build: other streams wait for it once
 
     def get(self, conv):
         w = conv.weight
@@ -43,7 +44,16 @@ class _ConvPrep:
                 _lib.check(_lib_handle.dvq_qconv_prepare_f32(w2.data_ptr(), _lib.ptr(b2), D, self.buf.data_ptr(),
                                                              self.buf.numel(), _lib.stream_ptr(w.device)),
                            "dvq_qconv_prepare_f32")
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(w.device))
+                self._built = (_lib.stream_ptr(w.device), ev)
             self.key = key
+        elif self._built is not None and not torch.cuda.is_current_stream_capturing():
+            if self._built[0] != _lib.stream_ptr(w.device):
+                if self._built[1].query():
+                    self._built = None               # long done: nothing to order any more
+                else:
+                    torch.cuda.current_stream(w.device).wait_event(self._built[1])
         return self.buf
 
 

@@ -433,3 +433,24 @@ def test_feature_router_models_against_the_reference_models_own_encode(dev, gold
         d_ref = ((h[bad] - E[ref[bad]].astype(np.float64)) ** 2).sum(1)
         assert np.all(np.abs(d_ref - d_ours) <= 1e-5 * np.maximum(d_ours, 1.0))
     assert abs(float(loss) - float(g["emb_loss"])) <= 1e-4 * abs(float(g["emb_loss"]))
+
+
+def test_conv_weight_images_are_ordered_across_streams(dev):
+    """the conv's weight images are built on the stream of the first call; a second stream that uses them right away (no host
+    synchronisation in between, as encode.StreamSlots drives a model) waits for the build's event"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
+    K, D, B = 1024, 256, 8
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = t(synth.codebook_trained(K, D))
+    x = t(synth.z_tokens(synth.codebook_trained(K, D), B, 32, 32, 990))
+    conv = _conv(dev, D, 991)
+    prep = _CodebookPrep()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        zq1, c1, l1 = vq_assign(x, E, prep, None, conv=conv)
+    with torch.cuda.stream(s2):
+        zq2, c2, l2 = vq_assign(x, E, prep, None, conv=conv)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(zq1, zq2) and torch.equal(l1, l2)
