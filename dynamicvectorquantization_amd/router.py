@@ -240,6 +240,7 @@ class _GateWeightPrep:
     def __init__(self):
         self.key = None
         self.buf = None
+        self._built = None                   # (stream handle, event) of the last build: other streams wait for it once
 
     def invalidate(self):
         self.key = None
@@ -257,7 +258,16 @@ class _GateWeightPrep:
                 _lib.check(_lib_handle.dvq_router_gate_prepare_f32(
                     w1.data_ptr(), nb, C, hidden, self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
                     "dvq_router_gate_prepare_f32")
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(w1.device))
+                self._built = (_lib.stream_ptr(w1.device), ev)
             self.key = key
+        elif self._built is not None and not torch.cuda.is_current_stream_capturing():
+            if self._built[0] != _lib.stream_ptr(w1.device):     # built on another stream: order this one behind it, once
+                if self._built[1].query():
+                    self._built = None
+                else:
+                    torch.cuda.current_stream(w1.device).wait_event(self._built[1])
         return self.buf
 
 
