@@ -1334,8 +1334,11 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    int nslice, int *__restrict__ chunk_sync, int Wout)
+    int nslice, int *__restrict__ chunk_sync, int Wout, float *__restrict__ h_spill)
 {
+    // h_spill (conv fused into pass 1; null otherwise): [B, D, HW] buffer the exact-list kernel reads its tokens' latents from.
+    // Pass 1 spills the rows of ITS hand-offs; the tokens the resolver itself sends to that list (candidate overflow, no
+    // candidate) get their row written here, from the record (which holds the conv's output).
     // HW = positions per image of the OUTPUT grid; a routed token (RecMeta.rep > 1) covers rep x rep
     // positions, rows Wout apart, all rewritten with the same values.
     // Large codebooks: the code tiles are cut into `nslice` slices (blockIdx.y); each slice resolves its
@@ -1536,6 +1539,10 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         float delta = 0.0f;
         for (int k0 = lane * 4; k0 < D; k0 += 256) {
             f32x4 zv = *(const f32x4 *)(r2 + k0 * 4);
+            if (take_back_only && h_spill != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h_spill[((size_t)bimg * D + k0 + j) * HW + hw] = zv[j];
+            }
             f32x4 eo = *(const f32x4 *)(E + (size_t)m2.prov * D + k0);
             f32x4 en_ = take_back_only ? eo : *(const f32x4 *)(E + (size_t)win * D + k0);
 #pragma unroll
@@ -1746,7 +1753,7 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
 static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0, DVQ_PIPE_DEFAULT};
-extern "C" int dvq_tuning_set(const char *key, int value)
+extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "antiphase")) g_tune.antiphase = value;
     else if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
@@ -1757,7 +1764,7 @@ extern "C" int dvq_tuning_set(const char *key, int value)
 }
 // device buffers the tuning build's pass 1 writes its diagnostics to (null = off): stamps [grid][8] u64 (see
 // g_dvq_stamps); tokdbg [N][4] f32 = best, second, 2W, code
-extern "C" int dvq_tuning_buffers(void *stamps, void *tokdbg)
+extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *stamps, void *tokdbg)
 {
     hipError_t rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_stamps), &stamps, sizeof(void *));
     if (rc == hipSuccess) rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
@@ -1934,23 +1941,23 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
 template <int D>
 static int launch_resolver(const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                            const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                           const FilterWs &w, int Wout, hipStream_t st)
+                           const FilterWs &w, int Wout, float *h_spill, hipStream_t st)
 {
     const int nslice = resolver_slices(K);
     hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img, meta,
                        en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout);
+                       w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill);
     return (int)hipGetLastError();
 }
 
 static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                              const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                             const FilterWs &w, int Wout, hipStream_t st)
+                             const FilterWs &w, int Wout, float *h_spill, hipStream_t st)
 {
     switch (D) {
-    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
-    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
-    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, st);
+    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
+    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
+    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
     default:  return -1000;
     }
 }
@@ -1984,8 +1991,9 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     }
     if (rc || pass1_only) return rc;
     const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
+    // (h_all: pass 1 already wrote every token's row)
     rc = launch_resolver_d(D, img, meta, en_all, E, mask, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
-                           w, Wout, st);
+                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, st);
     if (rc) return rc;
     double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
     // the list kernel is the last of the op: it also sums all partials into loss[0..1]

@@ -111,7 +111,7 @@ struct PipeArgs {
 // tuning build: s_memrealtime (100 MHz) of lane 0 of each group's first wave at every phase start and at steps 16 / 24 of every
 // memory phase: [grid][2 groups][64] u64, slot = 4 * (phase + 1) + {0 start, 1 step 16, 2 step 24}; null = off
 __device__ unsigned long long *g_pipe_stamps = nullptr;
-extern "C" int dvq_tuning_pipe_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_stamps), &p, sizeof(void *)); }
+extern "C" __attribute__((visibility("default"))) int dvq_tuning_pipe_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_stamps), &p, sizeof(void *)); }
 #define PIPE_STAMP(SLOT) do { if (g_pipe_stamps != nullptr && w4 == 0 && lane == 0 && (SLOT) < 64) \
     g_pipe_stamps[((size_t)blockIdx.x * 2 + g) * 64 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PIPE_STAMPV(SLOT, V) do { if (g_pipe_stamps != nullptr && w4 == 0 && lane == 0 && (SLOT) < 64) \

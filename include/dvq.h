@@ -30,6 +30,9 @@
 extern "C" {
 #endif
 
+/* libdvq.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table */
+#define DVQ_API __attribute__((visibility("default")))
+
 #define DVQ_OK            0
 #define DVQ_EINVAL       (-1)  /* bad argument (null pointer, non-positive size, ...) */
 #define DVQ_EUNSUPPORTED (-2)  /* shape outside what the kernels implement            */
@@ -54,8 +57,8 @@ extern "C" {
 #define DVQ_GATE_ENTROPY 2  /* routed assign only: float32 entropy map [B, hc, wc] + threshold  */
                             /* (the fixed-entropy router fused in)                              */
 
-int dvq_version(void);
-const char *dvq_last_error_string(void);
+DVQ_API int dvq_version(void);
+DVQ_API const char *dvq_last_error_string(void);
 
 /*
  * Codebook preparation -- run once per codebook (weights change only in training).
@@ -64,8 +67,8 @@ const char *dvq_last_error_string(void);
  * and lays the codebook out as the LDS tile images the assign kernels stream.
  *   codebook [K, D] (for VQEmbedding pass weight[:-1]); prep: >= dvq_codebook_prep_bytes(K, D)
  */
-size_t dvq_codebook_prep_bytes(int K, int D);
-int dvq_codebook_prepare_f32(const float *codebook, int K, int D,
+DVQ_API size_t dvq_codebook_prep_bytes(int K, int D);
+DVQ_API int dvq_codebook_prepare_f32(const float *codebook, int K, int D,
                              void *prep, size_t prep_bytes, void *stream);
 
 /*
@@ -84,8 +87,8 @@ int dvq_codebook_prepare_f32(const float *codebook, int K, int D,
  * Distances follow the reference's fp32 arithmetic bit for bit: sequential-k FMA
  * chain, ATen-order norms, d = fl(fl(xn+en) - 2 dot).
  */
-size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode);
-int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *prep,
+DVQ_API size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode);
+DVQ_API int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *prep,
                            const float *mask, int B, int D, int HW, int K, float beta,
                            float *zq, int64_t *codes, float *loss,
                            void *ws, size_t ws_bytes, int mode, void *stream);
@@ -94,16 +97,16 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
  * call on that workspace: [0] tokens queued for the resolver (best and runner-up closer than the
  * error bound), [1] tokens handed to the full exact pass (non-finite / unscalable tokens,
  * overflow).  Read them after the stream has drained. */
-size_t dvq_vq_assign_fallback_count_offset(int B, int D, int HW, int K);
+DVQ_API size_t dvq_vq_assign_fallback_count_offset(int B, int D, int HW, int K);
 
 /* nn.Embedding gather (quantize2_mask.py:130-132, get_codebook_entry :207-210):
  * out[n, :] = codebook[idx[n], :];  an index outside [0, K) writes NaNs to that row. */
-int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx,
+DVQ_API int dvq_embed_gather_f32(const float *codebook, int K, int D, const int64_t *idx,
                          int64_t n, float *out, void *stream);
 
 /* DualGrainFixedEntropyRouter.forward (RouterDual.py:53-57):
  * gate[i, 0] = entropy[i] <= thr, gate[i, 1] = entropy[i] > thr, int64. */
-int dvq_entropy_gate_f32(const float *entropy, int64_t n, float thr, int64_t *gate,
+DVQ_API int dvq_entropy_gate_f32(const float *entropy, int64_t n, float thr, int64_t *gate,
                          void *stream);
 
 /*
@@ -113,7 +116,7 @@ int dvq_entropy_gate_f32(const float *entropy, int64_t n, float thr, int64_t *ga
  *   h_coarse [B, C, hc, wc], h_fine [B, C, 2hc, 2wc]
  *   h_out [B, C, 2hc, 2wc], indices [B, hc, wc] int64, cmask [B, 1, 2hc, 2wc] (0.25 / 1.0)
  */
-int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
+DVQ_API int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
                               const float *h_coarse, const float *h_fine,
                               int B, int C, int hc, int wc,
                               float *h_out, int64_t *indices, float *cmask, void *stream);
@@ -121,7 +124,7 @@ int dvq_route_select_dual_f32(const void *gate, int gate_dtype,
 /* The fixed-entropy router (RouterDual.py:46-57) fused into the dual select: entropy [B, hc, wc] f32,
  * gate = [(entropy <= threshold), (entropy > threshold)]; outputs as dvq_route_select_dual_f32 plus,
  * if gate_out != NULL, the router's int64 gate [B, hc, wc, 2] (DualGrainEncoder returns it). */
-int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, const float *h_coarse,
+DVQ_API int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, const float *h_coarse,
                                       const float *h_fine, int B, int C, int hc, int wc,
                                       float *h_out, int64_t *indices, float *cmask, int64_t *gate_out,
                                       void *stream);
@@ -131,7 +134,7 @@ int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, con
  *   gate [B, hc, wc, 3]; h_coarse [B,C,hc,wc], h_median [B,C,2hc,2wc], h_fine [B,C,4hc,4wc]
  *   cmask values 0.0625 / 0.25 / 1.0
  */
-int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
+DVQ_API int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
                                 const float *h_coarse, const float *h_median,
                                 const float *h_fine, int B, int C, int hc, int wc,
                                 float *h_out, int64_t *indices, float *cmask, void *stream);
@@ -156,15 +159,15 @@ int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
  * hc * wc <= 1024 coarse cells per image, B <= 32768; any hc, wc (32-wide output grids, i.e. every reference
  * config, take a form that stages the coarser branches through LDS).
  */
-size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int hc, int wc, int K, int mode);
-int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,
+DVQ_API size_t dvq_vq_assign_routed_workspace_bytes(int num_branches, int B, int D, int hc, int wc, int K, int mode);
+DVQ_API int dvq_vq_assign_routed_dual_f32(const void *gate, int gate_kind, float threshold,
                                   const float *h_coarse, const float *h_fine,
                                   const float *codebook, const void *prep,
                                   int B, int D, int hc, int wc, int K, float beta,
                                   float *zq, int64_t *codes, float *loss,
                                   int64_t *indices, float *cmask, int64_t *gate_out,
                                   void *ws, size_t ws_bytes, int mode, void *stream);
-int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
+DVQ_API int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
                                     const float *h_coarse, const float *h_median, const float *h_fine,
                                     const float *codebook, const void *prep,
                                     int B, int D, int hc, int wc, int K, float beta,
@@ -181,10 +184,10 @@ int dvq_vq_assign_routed_triple_f32(const void *gate, int gate_kind,
  *                          is never written): gate as for the routed assign, h_coarse / h_median / h_fine the encoder
  *                          branches; outputs h [B, D, S hc, S wc] plus the select's by-products indices, cmask, gate_out
  */
-size_t dvq_qconv_prep_bytes(int D);
-int dvq_qconv_prepare_f32(const float *weight, const float *bias, int D, void *prep, size_t prep_bytes, void *stream);
-int dvq_qconv_f32(const float *x, const void *prep, int B, int D, int HW, float *h, void *stream);
-int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, float threshold,
+DVQ_API size_t dvq_qconv_prep_bytes(int D);
+DVQ_API int dvq_qconv_prepare_f32(const float *weight, const float *bias, int D, void *prep, size_t prep_bytes, void *stream);
+DVQ_API int dvq_qconv_f32(const float *x, const void *prep, int B, int D, int HW, float *h, void *stream);
+DVQ_API int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, float threshold,
                          const float *h_coarse, const float *h_median, const float *h_fine, const void *prep,
                          int B, int D, int hc, int wc, float *h, int64_t *indices, float *cmask, int64_t *gate_out,
                          void *stream);
@@ -204,18 +207,18 @@ int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, floa
  *                conv output of EVERY token (how the tests check the contract above).  Other rows are not touched.
  *   everything else as dvq_vq_assign_nchw_f32 / dvq_vq_assign_routed_{dual,triple}_f32 (x / h_coarse.. = the conv's INPUT)
  */
-int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float *codebook, const void *prep,
+DVQ_API int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float *codebook, const void *prep,
                             const float *mask, int B, int D, int HW, int K, float beta,
                             float *zq, int64_t *codes, float *loss, float *h_buf, int h_all,
                             void *ws, size_t ws_bytes, int mode, void *stream);
-int dvq_vq_assign_routed_qconv_dual_f32(const void *gate, int gate_kind, float threshold,
+DVQ_API int dvq_vq_assign_routed_qconv_dual_f32(const void *gate, int gate_kind, float threshold,
                                         const float *h_coarse, const float *h_fine, const void *qconv_prep,
                                         const float *codebook, const void *prep,
                                         int B, int D, int hc, int wc, int K, float beta,
                                         float *zq, int64_t *codes, float *loss,
                                         int64_t *indices, float *cmask, int64_t *gate_out, float *h_buf, int h_all,
                                         void *ws, size_t ws_bytes, int mode, void *stream);
-int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
+DVQ_API int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
                                           const float *h_coarse, const float *h_median, const float *h_fine,
                                           const void *qconv_prep, const float *codebook, const void *prep,
                                           int B, int D, int hc, int wc, int K, float beta,
@@ -232,14 +235,14 @@ int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
  * as that expression.  g_zq nullable (only the loss was used), g_loss nullable (only z_q was used; a device scalar otherwise),
  * mask nullable; D % 16 == 0.
  */
-int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+DVQ_API int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
                              const float *g_zq, const float *g_loss, float coef_scale,
                              int B, int D, int HW, int K, float *g_z, void *stream);
 /* ... and with respect to a codebook trained by back-propagation (VectorQuantizer2, quantize_vqgan.py:290-298; no EMA):
  *   g_weight[j, :] += -(g_loss * coef_scale) * sum over tokens with code j of (z - codebook[j]) * mask
  * ACCUMULATES into g_weight [>= K rows, D] (zero it first); float atomics, one row per distinct code of a 64-token tile:
  * equal to the reference's index_add_ of the [N, D] differences up to summation order.  K <= 8192. */
-int dvq_vq_backward_codebook_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
+DVQ_API int dvq_vq_backward_codebook_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
                                       const float *g_loss, float coef_scale, int B, int D, int HW, int K,
                                       float *g_weight, void *stream);
 
@@ -248,11 +251,11 @@ int dvq_vq_backward_codebook_nchw_f32(const float *z, const float *codebook, con
  * packed into the low mantissa bits), the per-token decision threshold 2W, the exact norm xn and the codebook scale
  * 2^b -- so that the bound |G_j - truth_j| <= W can be checked against the reference arithmetic in float64 on the host.
  *   scores [n, 32*ceil(K/32)] (padding codes hold -3e38), threshold [n], xn [n], scale [1] (nullable) */
-int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,
+DVQ_API int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, int D, int K, float *scores,
                                 float *threshold, float *xn, float *scale, void *stream);
 
 /* as dvq_vq_assign_fallback_count_offset, for a routed workspace */
-size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K);
+DVQ_API size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D, int hc, int wc, int K);
 
 /*
  * Training-mode codebook statistics, the dense part of VQEmbedding._update_buffers
@@ -261,7 +264,7 @@ size_t dvq_vq_assign_routed_fallback_count_offset(int num_branches, int B, int D
  * z [B, D, HW] f32 (NCHW), codes [B, HW] int64; both outputs are overwritten.  Codes outside
  * [0, K) are ignored.  Float atomics: equal to the reference within rounding (1e-5).
  */
-int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int D, int HW, int K,
+DVQ_API int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int D, int HW, int K,
                                 float *cluster_size, float *vectors_sum, void *stream);
 
 /*
@@ -287,11 +290,11 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
  * features are read from HBM once.  w1_prep (nullable): the split fp16 tile images of w1 made by
  * dvq_router_gate_prepare_f32 into a caller-kept buffer of dvq_router_gate_prep_bytes -- valid while w1 is unchanged;
  * NULL: they are rebuilt inside the call. */
-size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden);
-size_t dvq_router_gate_prep_bytes(int num_branches, int C, int hidden);
-int dvq_router_gate_prepare_f32(const float *w1, int num_branches, int C, int hidden, void *w1_prep,
+DVQ_API size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden);
+DVQ_API size_t dvq_router_gate_prep_bytes(int num_branches, int C, int hidden);
+DVQ_API int dvq_router_gate_prepare_f32(const float *w1, int num_branches, int C, int hidden, void *w1_prep,
                                 size_t w1_prep_bytes, void *stream);
-int dvq_router_gate_f32(int num_branches, const float *h_coarse, const float *h_median, const float *h_fine,
+DVQ_API int dvq_router_gate_f32(int num_branches, const float *h_coarse, const float *h_median, const float *h_fine,
                         int B, int C, int hc, int wc, int num_groups, float eps,
                         const float *gn_w_coarse, const float *gn_b_coarse,
                         const float *gn_w_median, const float *gn_b_median,
@@ -305,7 +308,7 @@ int dvq_router_gate_f32(int num_branches, const float *h_coarse, const float *h_
  * patch_size 16: images [B, 3, H, W] f32 (H, W multiples of 16) -> out [B, H/16, W/16] f32.
  * Transcendental fp32 math: equal to the reference within 1e-5, not bit for bit.
  */
-int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream);
+DVQ_API int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, float *out, void *stream);
 
 /*
  * DualGrainSeperatePermuter (modules/dynamic_modules/permuter.py): dense codes + grain map <->
@@ -322,14 +325,14 @@ int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, flo
  *            ignored, no coarse upsample if the coarse stream has no EOS) -> target [B, 2hc, 2wc].
  * hc*wc <= 1024.
  */
-int dvq_permute_dual_count_i64(const int64_t *grain, int B, int hc, int wc,
+DVQ_API int dvq_permute_dual_count_i64(const int64_t *grain, int B, int hc, int wc,
                                int32_t *counts, int32_t *maxes, void *stream);
-int dvq_permute_dual_forward_i64(const int64_t *codes, const int64_t *grain, int B, int hc, int wc,
+DVQ_API int dvq_permute_dual_forward_i64(const int64_t *codes, const int64_t *grain, int B, int hc, int wc,
                                  int order, int Lc, int Lf, const int64_t *special,
                                  int64_t *coarse_content, int64_t *coarse_position, int64_t *coarse_segment,
                                  int64_t *fine_content, int64_t *fine_position, int64_t *fine_segment,
                                  void *stream);
-int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *fine_content,
+DVQ_API int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *fine_content,
                                   const int64_t *coarse_position, const int64_t *fine_position,
                                   int B, int Lc, int Lf, int hc, int wc,
                                   int64_t coarse_position_eos, int64_t fine_position_eos,
@@ -348,11 +351,11 @@ int dvq_permute_dual_backward_i64(const int64_t *coarse_content, const int64_t *
  *           mean (pairs added in rank order: same bits on every rank); shard r holds the images
  *           [r*base + min(r, extra), ...) of global_batch = world*base + extra, b_max = ceil(global_batch / world)
  */
-size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes);
-int dvq_exchange_pack(const int64_t *codes, const int64_t *grain, const float *loss, double numel, int b_local,
+DVQ_API size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes);
+DVQ_API int dvq_exchange_pack(const int64_t *codes, const int64_t *grain, const float *loss, double numel, int b_local,
                       int b_max, int64_t codes_per_image, int64_t grain_per_image, int num_codes, void *buf,
                       void *stream);
-int dvq_exchange_unpack(const void *gathered, int world, int global_batch, int64_t codes_per_image,
+DVQ_API int dvq_exchange_unpack(const void *gathered, int world, int global_batch, int64_t codes_per_image,
                         int64_t grain_per_image, int num_codes, int64_t *codes, int64_t *grain, float *mean,
                         void *stream);
 

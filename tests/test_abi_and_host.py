@@ -28,6 +28,21 @@ def test_header_symbols_exported():
     assert _lib.lib.dvq_version() >= 100
 
 
+def test_dynamic_symbol_table_is_exactly_the_abi():
+    """libdvq.so is linked with -fvisibility=hidden and a version script (csrc/libdvq.map): `nm -D` shows the
+    entry points include/dvq.h declares and NOTHING else -- no mangled launcher, no kernel stub"""
+    import subprocess
+    from dynamicvectorquantization_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    syms = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert not [s for s in syms if s.startswith("_Z") or "__device_stub__" in s or "__hip" in s], syms
+    extra = set(syms) - set(_declared())
+    if os.path.basename(_lib.LIB_PATH) != "libdvq.so":          # DVQ_LIBRARY=<tuning build>: plus its A/B switches
+        extra = {s for s in extra if not s.startswith("dvq_tuning_")}
+    assert not extra, extra
+    assert set(_declared()) <= set(syms)
+
+
 def test_size_queries_and_validation_without_gpu():
     from dynamicvectorquantization_amd import _lib
     L = _lib.lib

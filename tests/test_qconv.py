@@ -454,3 +454,55 @@ def test_conv_weight_images_are_ordered_across_streams(dev):
         zq2, c2, l2 = vq_assign(x, E, prep, None, conv=conv)
     torch.cuda.synchronize()
     assert torch.equal(c1, c2) and torch.equal(zq1, zq2) and torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("routed", [False, True])
+def test_fused_conv_resolver_overflow_hands_h_to_the_exact_list(dev, oracle_mod, routed):
+    """with the conv fused in, the tokens the RESOLVER sends to the exact list (more than RES_CAND = 512
+    candidate pairs per 32 queued tokens: a codebook with many duplicate codes) must reach the exact-list kernel with their
+    conv output:
+    the resolver writes the record's h into h_buf before it appends the token.  Without an h_buf tensor (scratch = torch.empty,
+    never written by pass 1 for those rows) the op has to give the same bits as with h_all, and as qconv followed by the assign."""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.qconv import quant_conv
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
+    D, K, B = 256, 1024, 4
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    E = np.ascontiguousarray(np.tile(synth.codebook_trained(32, D, seed=961), (32, 1)))   # 32 distinct vectors x 32 copies:
+    conv = _conv(dev, D, 962)                                  # every token's best is a 32-way exact tie -> queued, 1024
+                                                               # candidate pairs per resolver group -> the exact list
+    if routed:
+        hf, hc = synth.features(963, B, D, 32, 32), synth.features(964, B, D, 16, 16)
+        ent = synth.entropy_map(965, B, 16, 16)
+        prep = _CodebookPrep()
+        hb = torch.empty((B, D, 32, 32), device=dev)
+        r_all = vq_assign_routed_dual(t(hc), t(hf), t(E), prep, entropy=t(ent), threshold=THR, conv=conv, h_buf=hb)
+        # poison what the scratch rows may hold: a stale h from another batch must not leak into the result
+        prep2 = _CodebookPrep()
+        prep2.h_scratch((B, D, 32, 32), dev).fill_(float("nan"))
+        r = vq_assign_routed_dual(t(hc), t(hf), t(E), prep2, entropy=t(ent), threshold=THR, conv=conv)
+        torch.cuda.synchronize()
+        queued, listed = prep2.fallback_count()
+        assert listed > 0, (queued, listed)
+        assert torch.equal(r["codes"], r_all["codes"]) and torch.equal(r["zq"], r_all["zq"])
+        assert abs(float(r["loss"][1]) - float(r_all["loss"][1])) <= 1e-6 * abs(float(r_all["loss"][1]))
+        o = oracle_mod.vq_assign_nchw(hb.cpu().numpy(), E, r["codebook_mask"].cpu().numpy().reshape(B, -1))
+        assert np.array_equal(r["codes"].cpu().numpy().reshape(B, -1), o["codes"])
+        assert np.array_equal(r["zq"].cpu().numpy(), o["zq"])
+    else:
+        x = synth.features(966, B, D, 16, 16)
+        h = quant_conv(conv, t(x))
+        zq0, codes0, loss0 = vq_assign(h, t(E), _CodebookPrep(), None)
+        prep = _CodebookPrep()
+        prep.h_scratch((B, D, 16, 16), dev).fill_(float("nan"))
+        zq, codes, loss = vq_assign(t(x), t(E), prep, None, conv=conv)
+        torch.cuda.synchronize()
+        queued, listed = prep.fallback_count()
+        assert listed > 0, (queued, listed)
+        hb = torch.empty((B, D, 16, 16), device=dev)
+        zq1, codes1, loss1 = vq_assign(t(x), t(E), _CodebookPrep(), None, conv=conv, h_buf=hb)
+        assert torch.equal(codes, codes1) and torch.equal(zq, zq1)
+        o = oracle_mod.vq_assign_nchw(hb.cpu().numpy(), E, None)
+        assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+        if torch.equal(hb, h):                                 # the two conv kernels agree bit for bit on this data: so must the ops
+            assert torch.equal(codes, codes0) and torch.equal(zq, zq0)

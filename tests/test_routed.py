@@ -1,7 +1,7 @@
 """GPU (-m gpu): the routed assign (dvq_vq_assign_routed_{dual,triple}_f32 -- routing tail + VectorQuantize2
 as one op, the select fused into pass 1) against the CPU oracle's select + assign on the same seeded inputs, at
 every form pass 1 takes (32-wide output grids stage the coarser branches through LDS, other grids address them per
-lane; >= 1024 workgroups switch the per-CU anti-phase lock on), and at DISPATCH size: the exact bench step at
+lane), and at DISPATCH size: the exact bench step at
 B = 256 on all images, configs[1] end to end at B = 64, the triple encode at the per-rank size B = 128, K = 16384
 through the wide pass-1 kernel + sliced resolver at B = 128 and at configs[4]'s B = 512.
 Bar: codes, grain indices, codebook_mask, gate and z_q bit-exact; loss 1e-5."""
@@ -194,7 +194,7 @@ def test_routed_special_tokens_and_queue_overflow(dev, oracle_mod):
 
 def test_bench_step_full_size_all_images(dev, oracle_mod):
     """BASELINE configs[2] exactly as bench.py runs it (entropy gate + routing + masked assign, B = 256, K = 1024:
-    2048 workgroups, LDS-staged select, anti-phase lock on), every one of the 256 images against the oracle, both
+    2048 workgroups, LDS-staged select), every one of the 256 images against the oracle, both
     the routed op and the round-1 select + dense assign path; codes-only call as the tokenisation path makes it"""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
@@ -419,3 +419,67 @@ def test_encode_dual_uses_routed_op_and_matches_select_path(dev, oracle_mod, gol
     q, loss, _, _, _ = encode_dual(r_ent, vq, hf_g, hc, entropy=ent)          # autograd -> differentiable path
     (q.sum() + loss).backward()
     assert hf_g.grad is not None and float(hf_g.grad.abs().sum()) > 0
+
+
+def test_two_host_threads_two_streams(dev, oracle_mod):
+    """include/dvq.h promises re-entrancy (no mutable process-wide state; the last-error string is thread-local): two Python
+    threads drive `dvq_vq_assign_routed_dual_f32` concurrently, each on its own HIP stream with its own inputs, SHARING one
+    quantizer prep object (image built once, workspaces per stream).  Every call of both threads must equal the oracle."""
+    import threading
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign_routed_dual
+    B, K, D, ROUNDS = 8, 1024, 256, 12
+    E = synth.codebook_trained(K, D)
+    t = _t(dev)
+    tE = t(E)
+    prep = _CodebookPrep()
+    prep.get(tE)                                  # build the image once on the caller's stream
+    torch.cuda.synchronize()
+    inputs, expect = [], []
+    for i in range(2):
+        hf, hco = synth.z_tokens(E, B, 32, 32, 7100 + i), synth.z_tokens(E, B, 16, 16, 7110 + i)
+        ent = synth.entropy_map(7120 + i, B, 16, 16)
+        og = oracle_mod.entropy_gate(ent, THR)
+        o_sel = oracle_mod.route_select_dual(og, hco, hf)
+        o = oracle_mod.vq_assign_nchw(o_sel["h_dual"], E, o_sel["codebook_mask"])
+        inputs.append((t(hco), t(hf), t(ent)))
+        expect.append((o_sel, o))
+    results = [[], []]
+    errors = []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(dev)
+            start.wait()
+            with torch.cuda.stream(st):
+                for _ in range(ROUNDS):
+                    thc, thf, tent = inputs[i]
+                    results[i].append(vq_assign_routed_dual(thc, thf, tE, prep, entropy=tent, threshold=THR))
+            st.synchronize()
+        except Exception as e:                     # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == ROUNDS
+        for r in results[i]:
+            _check_dual(r, expect[i][0], expect[i][1], B, oracle_mod=oracle_mod)
+    # an invalid call on one thread leaves its message on THAT thread only
+    from dynamicvectorquantization_amd import _lib
+    msgs = {}
+
+    def bad(i):
+        if i == 0:
+            _lib.lib.dvq_vq_assign_nchw_f32(0, 0, 0, 0, 1, 256, 1, 1, 0.25, 0, 0, 0, 0, 0, 0, 0)
+        msgs[i] = _lib.lib.dvq_last_error_string()
+
+    th = [threading.Thread(target=bad, args=(i,)) for i in range(2)]
+    th[0].start(); th[0].join(); th[1].start(); th[1].join()
+    assert b"null" in msgs[0] and b"null" not in msgs[1]
