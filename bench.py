@@ -46,19 +46,26 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region is measured this many times back to back inside one run (each block = exactly --steps "
+                         "steps, barrier + synchronize on both sides, max over ranks); ms_per_step / value are the MEDIAN block, "
+                         "min / max are reported beside it (a 20-step block is 4 ms: launch ramp and box variance dominate one block)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--batch", type=int, default=None,
                     help="weak: images per GPU (default 256); strong: GLOBAL batch (default 1024)")
     ap.add_argument("--codes", type=int, default=1024)
     ap.add_argument("--mode", choices=["exact", "filter"], default="filter")
-    ap.add_argument("--path", choices=["routed", "select", "model", "model2", "tokens", "tokens_model"], default="routed",
+    ap.add_argument("--path", choices=["routed", "select", "model", "model2", "tokens", "tokens_model", "tokens_fold", "model_fold"], default="routed",
                     help="routed: ONE assign op straight from the encoder branches (the router select is fused into "
                          "pass 1, h_dual is never written); select: route-select kernel writing h_dual, then the "
                          "dense assign (round-1 path); model: select -> the models' 1x1 quant_conv -> assign, the order a "
                          "reference checkpoint runs, as ONE op (the conv is pass 1's prologue; neither h_dual nor the conv's "
                          "output is written); model2: the same order as two kernels (select + conv kernel writing h, then the "
                          "dense assign); tokens: routed assign, codes only, + permuter; tokens_model: the same behind the models' "
-                         "quant_conv (the fused op, codes only), what stage 2's encode_to_z runs on a stage-1 checkpoint")
+                         "quant_conv (the fused op, codes only), what stage 2's encode_to_z runs on a stage-1 checkpoint; "
+                         "tokens_fold: that tokenisation with the quant_conv FOLDED into the codebook (opt-in fold=True: pass 1 "
+                         "scores the branches against E W, no conv is computed for decided tokens; same codes); model_fold: the "
+                         "model order for loss-free inference by the fold (codes + z_q = codebook[code], no loss)")
     ap.add_argument("--no-model-order", action="store_true",
                     help="default command only (1 GPU, weak, --path routed): skip the short second measurement of the "
                          "model order (--path model: the same step behind the models' 1x1 quant_conv, as one op) that is "
@@ -266,7 +273,7 @@ class WeakDual:
         self.rank = rank
         self.conv = None
         self.conv_q = None
-        if a.path in ("model", "model2", "tokens_model"):
+        if a.path in ("model", "model2", "tokens_model", "tokens_fold", "model_fold"):
             # the models' quant_conv: a random orthogonal 256 x 256 matrix and a bias.  The encoder-branch inputs are generated as
             # x = Q^T (t - b) from tokens t of the usual z_tokens distribution (inputs_np), so that the QUANTIZER sees the same
             # distribution as on the other paths -- conv(x) = t up to rounding, as in a trained model whose conv output sits near
@@ -280,7 +287,7 @@ class WeakDual:
                 self.conv.weight.copy_(torch.from_numpy(self.conv_q.reshape(D, D, 1, 1)).to(dev))
                 self.conv.bias.copy_(torch.from_numpy(self.conv_b).to(dev))
         self.permuter = None
-        if a.path in ("tokens", "tokens_model"):
+        if a.path in ("tokens", "tokens_model", "tokens_fold"):
             from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
             self.permuter = DualGrainSeperatePermuter(coarse_hw=H // 2, fine_hw=H, content_pad_code=K, content_eos_code=K + 1)
         # one set of inputs AND outputs per stream slot, preallocated: the step allocates nothing and no step reads the
@@ -326,12 +333,12 @@ class WeakDual:
         o.h_dual = torch.empty_like(o.h_fine) if self.a.path == "select" else None
         o.grain = torch.empty((B, H // 2, W // 2), dtype=torch.int64, device=dev)
         o.cmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        o.zq = torch.empty_like(o.h_fine) if self.a.path not in ("tokens", "tokens_model") else None
+        o.zq = torch.empty_like(o.h_fine) if self.a.path not in ("tokens", "tokens_model", "tokens_fold") else None
         o.codes = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         o.loss = torch.empty(2, dtype=torch.float32, device=dev)
         o.gate = torch.empty((B, H // 2, W // 2, 2), dtype=torch.int64, device=dev)
         o.h_full = torch.empty_like(o.h_fine) if self.a.path == "model2" else None       # the conv's output (two-kernel form)
-        if self.a.path in ("tokens", "tokens_model"):
+        if self.a.path in ("tokens", "tokens_model", "tokens_fold"):
             Lc, Lf = self.permuter.max_lengths()
             o.seq = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
                     [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]
@@ -347,7 +354,12 @@ class WeakDual:
                 "tokens": "entropy gate + dual routing + VectorQuantize2 assign (codes only) + DualGrainSeperatePermuter: "
                           "the tokenisation stage 2 consumes",
                 "tokens_model": "entropy gate + dual routing + 1x1 quant_conv + VectorQuantize2 assign (ONE op, codes only) + "
-                                "DualGrainSeperatePermuter: the tokenisation stage 2 runs on a stage-1 checkpoint"}[self.a.path]
+                                "DualGrainSeperatePermuter: the tokenisation stage 2 runs on a stage-1 checkpoint",
+                "tokens_fold": "entropy gate + dual routing + VectorQuantize2 assign with the 1x1 quant_conv FOLDED into the "
+                               "codebook (ONE op, codes only; no conv for decided tokens) + DualGrainSeperatePermuter: the "
+                               "tokenisation stage 2 runs on a stage-1 checkpoint, opt-in fold=True form",
+                "model_fold": "entropy gate + dual routing + VectorQuantize2 assign with the 1x1 quant_conv FOLDED into the "
+                              "codebook (ONE op: codes + z_q = codebook[code], no loss): loss-free inference in the model order"}[self.a.path]
         return "BASELINE configs[2]: dqvae-entropy-dual-r05, B=%d per GPU, 32x32x256 latents, K=%d, %s" % (self.B, self.K, tail)
 
     def step(self, o, ev=None):
@@ -368,10 +380,14 @@ class WeakDual:
             qconv.quant_conv_select(self.conv, o.h_coarse, o.h_fine, entropy=o.ent, threshold=THR_R05,
                                     out=(o.h_full, o.grain, o.cmask, o.gate))
             vq_assign(o.h_full, self.E, self.prep, o.cmask, beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss))
-        elif path in ("tokens", "tokens_model"):
+        elif path in ("tokens", "tokens_model", "tokens_fold"):
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05, beta=0.25,
-                                  mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv)
+                                  mode=self.mode, out=(None, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv,
+                                  fold=(path == "tokens_fold"))
             self.permuter(o.codes, o.grain, max_len=self.permuter.max_lengths(), out=o.seq)
+        elif path == "model_fold":
+            vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05,
+                                  mode=self.mode, out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv, fold=True)
         else:
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep, entropy=o.ent, threshold=THR_R05,
                                   beta=0.25, mode=self.mode, out=(o.zq, o.codes, o.loss, o.grain, o.cmask, o.gate))
@@ -395,11 +411,12 @@ class WeakDual:
             vq_assign(src, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                       out=(o.zq, o.codes, None))
             ev[1].record()
-        elif path in ("model", "tokens_model"):
+        elif path in ("model", "tokens_model", "tokens_fold", "model_fold"):
             ev[0].record()
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
-                                  out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv)
+                                  out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv,
+                                  fold=path in ("tokens_fold", "model_fold"))
             ev[1].record()
         else:
             ev[0].record()
@@ -419,6 +436,9 @@ class WeakDual:
             return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)"
         if self.a.path in ("model", "tokens_model"):
             return "vq_assign_filter_kernel<256, 1, true> (pass 1 with the router select and the 1x1 quant_conv fused in)"
+        if self.a.path in ("tokens_fold", "model_fold"):
+            return ("vq_assign_filter_kernel<256, 2, false, true> (pass 1 on the conv-folded codebook E W, router select fused in, "
+                    "coarse branch staged through LDS)")
         return "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, coarse branch staged through LDS)"
 
     def parity(self, slot):
@@ -436,7 +456,29 @@ class WeakDual:
                "grain_mismatches": int((slot.grain.cpu().numpy() != osel["indices"]).sum()),
                "mask_mismatches": int((slot.cmask.cpu().numpy() != osel["codebook_mask"]).sum()),
                "gate_mismatches": int((slot.gate.cpu().numpy() != og).sum())}
-        if self.a.path in ("model", "model2", "tokens_model"):
+        if self.a.path in ("tokens_fold", "model_fold"):
+            # the fold's contract: codes = the reference chain on h = dvq_qconv_f32(x) for every token (decided ones by the bound,
+            # the others because resolver / list kernel compute that h); h itself within 1e-5 * sum |w||x| of the float64 conv
+            import torch
+
+            from dynamicvectorquantization_amd import qconv
+            h = qconv.quant_conv_select(self.conv, slot.h_coarse, slot.h_fine, entropy=slot.ent, threshold=THR_R05)["h"].cpu().numpy()
+            w64 = self.conv.weight.detach().double().cpu().numpy()[:, :, 0, 0]
+            x64 = osel["h_dual"][:8].astype(np.float64)
+            ref = np.einsum("ok,bkhw->bohw", w64, x64) + self.conv.bias.detach().double().cpu().numpy()[None, :, None, None]
+            bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64))
+            res["h_max_err_over_bound"] = float((np.abs(h[:8] - ref) / (1e-5 * bound + 1e-30)).max())
+            res["h_bound_mismatches"] = int(not res["h_max_err_over_bound"] <= 1.0)
+            o = oracle.vq_assign_nchw(h, self.E_np, osel["codebook_mask"])
+            ref_fp64 = oracle.vq_assign_nchw(ref.astype(np.float32), self.E_np, osel["codebook_mask"][:8])
+            res["codes_match_rate_vs_fp64_conv"] = float((slot.codes.cpu().numpy()[:8].reshape(8, -1) == ref_fp64["codes"]).mean())
+            res["loss_rel_err"] = 0.0
+            q, ls = self.prep.fallback_count()
+            res["tokens_resolved_with_a_conv"] = int(q + ls)
+            if slot.zq is not None:                              # z_q := codebook[code]: within 1e-6 of the reference's z + (e - z)
+                e = np.moveaxis(self.E_np[o["codes"]], 2, 1).reshape(slot.zq.shape)
+                res["zq_mismatches"] = int((np.abs(slot.zq.cpu().numpy() - e) > 1e-6 * np.maximum(1.0, np.abs(e))).sum())
+        elif self.a.path in ("model", "model2", "tokens_model"):
             # h is a tolerance-level quantity (1e-5 * sum |w||x| vs the conv in float64, checked on 8 images); codes, z_q and
             # the loss are exact GIVEN the h the kernels scored.  Two-kernel form: h is the conv kernel's output tensor.  One-op
             # form: h exists only inside pass 1 -- the op is run once more with an h_buf, which makes it write the conv output
@@ -475,9 +517,9 @@ class WeakDual:
         self.oracle_seconds = time.perf_counter() - t0          # one cold pass of the CPU port over the FULL batch
         codes = slot.codes.cpu().numpy().reshape(self.B, -1)
         res["code_mismatches"] = int((codes != o["codes"]).sum())
-        if slot.zq is not None:
+        if slot.zq is not None and self.a.path != "model_fold":
             res["zq_mismatches"] = int((slot.zq.cpu().numpy() != o["zq"]).sum())
-        if self.a.path in ("tokens", "tokens_model"):
+        if self.a.path in ("tokens", "tokens_model", "tokens_fold"):
             from oracle import permuter as operm
             ref = operm.forward(o["codes"].reshape(self.B, self.H, self.W), osel["indices"], coarse_hw=self.H // 2,
                                 fine_hw=self.H, content_pad=self.K, content_eos=self.K + 1)
@@ -491,7 +533,7 @@ class WeakDual:
                 bad += int((got[:, :L] != want).sum()) + int((got[:, L:] != pads[nme]).sum())   # beyond the batch maximum: PAD
             res["token_stream_mismatches"] = bad
             res["loss_rel_err"] = 0.0
-        elif self.a.path not in ("model", "model2"):
+        elif self.a.path not in ("model", "model2", "model_fold"):
             ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
             res["loss_rel_err"] = abs(float(slot.loss[1]) - ol) / abs(ol)
         return res
@@ -698,17 +740,22 @@ def run_rank(a):
         step()
     for _ in range(a.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    t_issue = time.perf_counter() - t0        # host time to queue the K steps (launch-bound if close to dt)
-    fence()
-    dt = time.perf_counter() - t0
+    R = max(1, a.repeats)
+    dts, t_issue = [], 0.0
+    for r in range(R):                            # R blocks of exactly K steps, each fenced on both sides
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        if r == 0:
+            t_issue = time.perf_counter() - t0    # host time to queue the K steps (launch-bound if close to dt)
+        fence()
+        dts.append(time.perf_counter() - t0)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor(dts, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # per block: the slowest rank
+        dts = [float(v) for v in tt.tolist()]
+    dt = float(np.median(dts))
 
     parity = None
     if not a.no_parity:
@@ -773,12 +820,17 @@ def run_rank(a):
             step2()
         torch.cuda.synchronize()
         k2 = min(a.steps, 200)
-        t2 = time.perf_counter()
-        for _ in range(k2):
-            step2()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t2
-        model_order = {"path": "model", "workload": wl2.describe(), "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+        dts2 = []
+        for _ in range(R):
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                step2()
+            torch.cuda.synchronize()
+            dts2.append(time.perf_counter() - t2)
+        dt2 = float(np.median(dts2))
+        model_order = {"path": "model", "workload": wl2.describe(), "steps": k2, "repeats": R, "ms_per_step": dt2 / k2 * 1e3,
+                       "ms_per_step_min_max": [min(dts2) / k2 * 1e3, max(dts2) / k2 * 1e3],
                        "value": wl2.Bglobal * k2 / dt2, "unit": "images/s",
                        "note": "bench.py --path model is the full measurement of this path (own roofline, serial step, all slots checked)"}
         if not a.no_parity:
@@ -791,14 +843,19 @@ def run_rank(a):
         torch.cuda.empty_cache()
 
     # the same K steps strictly serial (one stream, one slot's buffers): what a caller without stream slots gets
-    serial_ms = None
+    serial_ms, serial_blocks = None, None
     if S > 1:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
+        serial_blocks = []
+        for _ in range(3):
             wl.step(wl.slots[0])
-        torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - t1) / a.steps * 1e3
+        for r in range(R):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                wl.step(wl.slots[0])
+            torch.cuda.synchronize()
+            serial_blocks.append((time.perf_counter() - t1) / a.steps * 1e3)
+        serial_ms = float(np.median(serial_blocks))
     # the step's ops (all their kernels) and, below, the dominant kernel alone: HIP events on the launch stream, serial,
     # after the timed region (inside it the ops of consecutive steps overlap across the stream slots)
     nev = min(a.steps, 200)
@@ -817,7 +874,7 @@ def run_rank(a):
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
     N = wl.dominant_tokens()                                  # tokens per launch of the dominant kernel
-    per_token = D * 4 + 8 + 4 + (D * 4 if a.path not in ("tokens", "tokens_model") else 0)   # z read + int64 code + mask (+ z_q write)
+    per_token = D * 4 + 8 + 4 + (D * 4 if a.path not in ("tokens", "tokens_model", "tokens_fold") else 0)   # z read + int64 code + mask (+ z_q write)
     alg_bytes = N * per_token + K * D * 4                     # codebook once per launch
     alg_flops = 2.0 * K * D * N
     gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -827,7 +884,7 @@ def run_rank(a):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(a.mode if a.path in ("select", "model2") else ("routed" if a.path != "model" else "model"), {}).get("hbm_bytes_per_launch")
+            traffic = tj.get(a.mode if a.path in ("select", "model2") else ("routed" if a.path not in ("model", "tokens_fold", "model_fold") else a.path), {}).get("hbm_bytes_per_launch")
             tsrc = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected by tools/pmc_traffic.py; not re-measured in this run)"
         except Exception:
             traffic = None
@@ -864,12 +921,18 @@ def run_rank(a):
         out = {
             "metric": "images encoded/sec (VQ hot path: gate + routing + VQ assign), 256x256 inputs, K=%d" % K,
             "value": wl.Bglobal * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "serial_ms_per_step": serial_ms,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step_min": min(dts) / a.steps * 1e3, "ms_per_step_max": max(dts) / a.steps * 1e3,
+            "ms_per_step_blocks": [d / a.steps * 1e3 for d in dts],
+            "serial_ms_per_step": serial_ms,
+            "serial_ms_per_step_min_max": [min(serial_blocks), max(serial_blocks)] if serial_blocks else None,
             "serial_value": wl.Bglobal / (serial_ms * 1e-3) if world == 1 else None, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
                        "source_sha16": source_sha16(), "inputs": "one input set per stream slot (seeds differ)",
-                       "spinup_steps": a.spinup, "streams": S, "host_issue_ms_per_step": t_issue / a.steps * 1e3,
+                       "spinup_steps": a.spinup, "streams": S, "repeats": R,
+                       "timing": "median of `repeats` back-to-back blocks of exactly `steps` steps, each bracketed by barrier + "
+                                 "synchronize, max over ranks per block", "host_issue_ms_per_step": t_issue / a.steps * 1e3,
                        "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
                                       "per step" % world},
             "roofline": roof,

@@ -37,6 +37,8 @@ EXPORTS = (
     "dvq_exchange_bytes", "dvq_exchange_pack", "dvq_exchange_unpack", "dvq_debug_filter_scores_f32",
     "dvq_qconv_prep_bytes", "dvq_qconv_prepare_f32", "dvq_qconv_f32", "dvq_qconv_select_f32",
     "dvq_vq_backward_nchw_f32", "dvq_vq_backward_codebook_nchw_f32", "dvq_vq_assign_qconv_f32", "dvq_vq_assign_routed_qconv_dual_f32", "dvq_vq_assign_routed_qconv_triple_f32",
+    "dvq_fold_prep_bytes", "dvq_fold_prepare_f32", "dvq_vq_assign_fold_f32", "dvq_vq_assign_routed_fold_dual_f32",
+    "dvq_vq_assign_routed_fold_triple_f32", "dvq_debug_fold_scores_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
     "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_prep_bytes", "dvq_router_gate_prepare_f32", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
@@ -99,6 +101,20 @@ def _load():
     lib.dvq_vq_assign_routed_qconv_triple_f32.restype = i32
     lib.dvq_vq_assign_routed_qconv_triple_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32,
                                                           vp, vp, vp, vp, vp, vp, i32, vp, sz, i32, vp]
+    lib.dvq_fold_prep_bytes.restype = sz
+    lib.dvq_fold_prep_bytes.argtypes = [i32, i32]
+    lib.dvq_fold_prepare_f32.restype = i32
+    lib.dvq_fold_prepare_f32.argtypes = [vp, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.dvq_vq_assign_fold_f32.restype = i32
+    lib.dvq_vq_assign_fold_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, i32, vp]
+    lib.dvq_vq_assign_routed_fold_dual_f32.restype = i32
+    lib.dvq_vq_assign_routed_fold_dual_f32.argtypes = [vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                                                       vp, vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_vq_assign_routed_fold_triple_f32.restype = i32
+    lib.dvq_vq_assign_routed_fold_triple_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                                                         vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_debug_fold_scores_f32.restype = i32
+    lib.dvq_debug_fold_scores_f32.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.dvq_qconv_prep_bytes.restype = sz
     lib.dvq_qconv_prep_bytes.argtypes = [i32]
     lib.dvq_qconv_prepare_f32.restype = i32

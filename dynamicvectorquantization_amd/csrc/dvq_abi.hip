@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 310   // 0.3.1: the fused conv ops
+#define DVQ_VERSION 400   // 0.4.0: the conv folded into the codebook (dvq_fold_*, dvq_vq_assign_*fold*)
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -28,12 +28,16 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv);
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd = nullptr);
 int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
-                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv);
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv,
+                      const DvqFold *fd = nullptr);
+size_t dvq_fold_prep_bytes_impl(int K, int D);
+int dvq_launch_fold_prep(const float *E, int K, int D, const void *cbprep, const float *Wt, const float *bias, void *fprep,
+                         hipStream_t st);
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N);
 bool dvq_filter_supported(int D, int HW, int K, long N);
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,
@@ -75,7 +79,7 @@ int dvq_launch_qconv_prep(const float *Wt, const float *bias, int D, void *prep,
 int dvq_launch_qconv(const float *x, const DvqRouted *rv, const void *prep, int D, int HW, long N, float *hout,
                      hipStream_t st);
 int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
-                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st);
+                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st, int fold = 0);
 size_t dvq_xch_bytes(long cpi, long gpi, int b_max, int num_codes);
 int dvq_launch_xch_pack(const long long *codes, const long long *grain, const float *loss, double numel, int b_local,
                         int b_max, long cpi, long gpi, int num_codes, void *buf, hipStream_t st);
@@ -227,6 +231,63 @@ int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float 
     return hip_rc(rc, fn);
 }
 
+// ---- the conv folded into the codebook (vq_fold.hip; filter path, codes [+ z_q := e[code]], no loss) -------------------------
+static int fold_desc(const char *fn, const void *qconv_prep, const void *fold_prep, int D, DvqFold *fd)
+{
+    if (!qconv_prep || !fold_prep) { dvq_set_error("%s: qconv_prep and fold_prep are required", fn); return DVQ_EINVAL; }
+    if (((uintptr_t)qconv_prep & 255) != 0 || ((uintptr_t)fold_prep & 255) != 0) { dvq_set_error("%s: qconv_prep / fold_prep must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    fd->fprep = (const char *)fold_prep;
+    fd->cv.meta = (const QconvMeta *)qconv_prep;
+    fd->cv.wimg = (const char *)qconv_prep + 256;
+    fd->cv.bias = (const float *)((const char *)qconv_prep + 256 + (size_t)(D / 32) * qconv_tile_bytes(D));
+    fd->cv.h_buf = nullptr;
+    fd->cv.h_all = 0;
+    return DVQ_OK;
+}
+
+size_t dvq_fold_prep_bytes(int K, int D)
+{
+    if (K <= 0 || !dim_ok(D)) return 0;
+    return (dvq_fold_prep_bytes_impl(K, D) + 255) / 256 * 256;
+}
+
+int dvq_fold_prepare_f32(const float *codebook, int K, int D, const void *codebook_prep, const float *conv_weight,
+                         const float *conv_bias, void *fold_prep, size_t fold_prep_bytes, void *stream)
+{
+    const char *fn = "dvq_fold_prepare_f32";
+    if (!codebook || !codebook_prep || !conv_weight || !fold_prep || K <= 0) { dvq_set_error("%s: null pointer or K <= 0", fn); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    if (fold_prep_bytes < dvq_fold_prep_bytes(K, D)) { dvq_set_error("%s: fold_prep buffer %zu < %zu bytes", fn, fold_prep_bytes, dvq_fold_prep_bytes(K, D)); return DVQ_EWORKSPACE; }
+    if (((uintptr_t)fold_prep & 255) != 0 || ((uintptr_t)codebook_prep & 255) != 0) { dvq_set_error("%s: prep buffers must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_fold_prep(codebook, K, D, codebook_prep, conv_weight, conv_bias, fold_prep, (hipStream_t)stream), fn);
+}
+
+int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *fold_prep, const float *codebook,
+                           const void *prep, int B, int D, int HW, int K, float *zq, int64_t *codes,
+                           void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    const char *fn = "dvq_vq_assign_fold_f32";
+    if (!x || !codebook || !prep || !codes) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
+    if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("%s: B=%d HW=%d K=%d must be positive", fn, B, HW, K); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    DvqFold fd;
+    int rc = fold_desc(fn, qconv_prep, fold_prep, D, &fd);
+    if (rc) return rc;
+    const long N = (long)B * HW;
+    if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!ws || ws_bytes < dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER)) {
+        dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER));
+        return DVQ_EWORKSPACE;
+    }
+    if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
+    if (mode != DVQ_MODE_FILTER && mode != DVQ_MODE_FILTER_PASS1) { dvq_set_error("%s: mode %d (the fold is a form of the filter path)", fn, mode); return DVQ_EINVAL; }
+    rc = dvq_launch_filter(x, prep, codebook, nullptr, D, HW, K, N, zq, (long long *)codes, nullptr,
+                           (char *)ws + partials_bytes_for(N), mode == DVQ_MODE_FILTER_PASS1, false, nullptr, 0.0f, nullptr,
+                           (hipStream_t)stream, nullptr, &fd);
+    return hip_rc(rc, fn);
+}
+
 // token ids of a routed batch: at most one per output position
 static long routed_ids(int nb, int B, long N) { (void)nb; (void)B; return N; }
 
@@ -259,7 +320,8 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
                          const float *codebook, const void *prep, int B, int D, int hc, int wc, int K, float beta,
                          float *zq, int64_t *codes, float *loss, int64_t *indices, float *cmask, int64_t *gate_out,
                          void *ws, size_t ws_bytes, int mode, void *stream,
-                         const void *qconv_prep = nullptr, float *h_buf = nullptr, int h_all = 0, bool conv = false)
+                         const void *qconv_prep = nullptr, float *h_buf = nullptr, int h_all = 0, bool conv = false,
+                         const void *fold_prep = nullptr)
 {
     if (!gate || !h_coarse || !h_fine || !codebook || !prep || !codes || !indices || !cmask || (nb == 3 && !h_median)) {
         dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL;
@@ -279,6 +341,12 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
         const int rcv = conv_desc(fn, qconv_prep, h_buf, h_all, D, &cv);
         if (rcv) return rcv;
     }
+    DvqFold fd;
+    if (fold_prep != nullptr) {
+        if (mode != DVQ_MODE_FILTER) { dvq_set_error("%s: mode %d (the fold is a form of the filter path)", fn, mode); return DVQ_EINVAL; }
+        const int rcf = fold_desc(fn, qconv_prep, fold_prep, D, &fd);
+        if (rcf) return rcf;
+    }
     const long N = (long)B * SC * hc * SC * wc;
     if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40) || B > 32768) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
     if (!dvq_filter_supported(D, SC * hc * SC * wc, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
@@ -293,7 +361,8 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     const int gmode = (gate_kind == DVQ_GATE_ENTROPY) ? 2 : (gate_kind == DVQ_GATE_I64 ? 1 : 0);
     int rc = dvq_launch_routed(nb, gmode, gate, threshold, h_coarse, h_median, h_fine, prep, codebook, B, D, hc, wc, K,
                                beta, zq, (long long *)codes, loss, (long long *)indices, cmask, (long long *)gate_out,
-                               partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st, conv ? &cv : nullptr);
+                               partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st, conv ? &cv : nullptr,
+                               fold_prep != nullptr ? &fd : nullptr);
     return hip_rc(rc, fn);                                   // the loss finalize is part of the op in both modes
 }
 
@@ -349,6 +418,33 @@ int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kind,
     return routed_common("dvq_vq_assign_routed_qconv_triple_f32", 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine,
                          codebook, prep, B, D, hc, wc, K, beta, zq, codes, loss, indices, cmask, nullptr, ws, ws_bytes,
                          mode, stream, qconv_prep, h_buf, h_all, true);
+}
+
+int dvq_vq_assign_routed_fold_dual_f32(const void *gate, int gate_kind, float threshold,
+                                       const float *h_coarse, const float *h_fine, const void *qconv_prep,
+                                       const void *fold_prep, const float *codebook, const void *prep,
+                                       int B, int D, int hc, int wc, int K, float *zq, int64_t *codes,
+                                       int64_t *indices, float *cmask, int64_t *gate_out,
+                                       void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    const char *fn = "dvq_vq_assign_routed_fold_dual_f32";
+    if (!fold_prep) { dvq_set_error("%s: null fold_prep", fn); return DVQ_EINVAL; }
+    return routed_common(fn, 2, gate, gate_kind, threshold, h_coarse, nullptr, h_fine, codebook, prep, B, D, hc, wc, K, 0.0f,
+                         zq, codes, nullptr, indices, cmask, gate_out, ws, ws_bytes, mode, stream, qconv_prep,
+                         nullptr, 0, false, fold_prep);
+}
+
+int dvq_vq_assign_routed_fold_triple_f32(const void *gate, int gate_kind,
+                                         const float *h_coarse, const float *h_median, const float *h_fine,
+                                         const void *qconv_prep, const void *fold_prep, const float *codebook, const void *prep,
+                                         int B, int D, int hc, int wc, int K, float *zq, int64_t *codes,
+                                         int64_t *indices, float *cmask, void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    const char *fn = "dvq_vq_assign_routed_fold_triple_f32";
+    if (!h_median || !fold_prep) { dvq_set_error("%s: null h_median / fold_prep", fn); return DVQ_EINVAL; }
+    return routed_common(fn, 3, gate, gate_kind, 0.0f, h_coarse, h_median, h_fine, codebook, prep, B, D, hc, wc, K, 0.0f,
+                         zq, codes, nullptr, indices, cmask, nullptr, ws, ws_bytes, mode, stream, qconv_prep,
+                         nullptr, 0, false, fold_prep);
 }
 
 int dvq_vq_backward_nchw_f32(const float *z, const float *codebook, const int64_t *codes, const float *mask,
@@ -631,6 +727,16 @@ int dvq_debug_filter_scores_f32(const float *tokens, int n, const void *prep, in
     if (!dim_ok(D)) { dvq_set_error("dvq_debug_filter_scores_f32: D=%d unsupported", D); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_filter_scores_debug(tokens, n, prep, D, K, scores, threshold, xn, scale, (hipStream_t)stream),
                   "filter_scores_debug");
+}
+
+int dvq_debug_fold_scores_f32(const float *tokens, int n, const void *fold_prep, int D, int K, float *scores,
+                              float *threshold, float *xn, float *scale, void *stream)
+{
+    if (!tokens || !fold_prep || !scores || !threshold || !xn) { dvq_set_error("dvq_debug_fold_scores_f32: null pointer"); return DVQ_EINVAL; }
+    if (n <= 0 || K <= 0) { dvq_set_error("dvq_debug_fold_scores_f32: n, K must be positive"); return DVQ_EINVAL; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_debug_fold_scores_f32: D=%d unsupported", D); return DVQ_EUNSUPPORTED; }
+    return hip_rc(dvq_launch_filter_scores_debug(tokens, n, fold_prep, D, K, scores, threshold, xn, scale, (hipStream_t)stream, 1),
+                  "fold_scores_debug");
 }
 
 size_t dvq_exchange_bytes(int64_t codes_per_image, int64_t grain_per_image, int b_max, int num_codes)

@@ -1,5 +1,5 @@
 // dvq_filter.h -- declarations shared by the fp16-filter assign kernels (vq_assign_filter.hip: pass 1,
-// resolver), the routing prepass of the exact routed mode (vq_assign_routed.hip), the 1x1 conv with the select
+// resolver), the conv-folded codebook (vq_fold.hip), the routing prepass of the exact routed mode (vq_assign_routed.hip), the 1x1 conv with the select
 // fused in (qconv.hip) and the exact kernel's routed list mode (vq_assign_exact.hip).
 #pragma once
 #include "dvq_common.h"
@@ -47,6 +47,58 @@ __device__ __forceinline__ float dvq_filter_threshold(float xn, float amax, floa
                      + GAMMA_P * (zn_ * ehn + 0.5f * sB * enmax)
                      + PACK_E * sB * (Rh * emax + 0.5f * enmax)
                      + sB * (REF_XN * (xn + enmax) + REF_RE * Rh * emax);
+    return bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FOLD: the model's 1x1 quant_conv folded into the codebook (vq_fold.hip; opt-in, loss-free inference / stage-2 tokenisation).
+// With h = W x + bias,  h.e_j - en_j/2  =  x.(W^T e_j) + (bias.e_j - en_j/2): pass 1 scores the conv's INPUT x against the
+// image of E' = E W with accumulator seeds 2^b' (bias.e_j - en_j/2) and never computes h; only tokens that are not provably
+// decided get their h (resolver / exact-list kernel: the split-fp16 conv arithmetic of qconv.hip, then the reference chain).
+// A token is final when best - second > 2 W', where W' bounds |G_j - truth_j| for EVERY h within the conv's tolerance of
+// the real-number conv (|h - (W x + bias)|_o <= 1e-5 sum_k |W_ok||x_k|, the contract of dvq_qconv_f32), truth_j being the
+// reference's fp32 distance chain evaluated on that h:
+//   fp16 rounding of x and of 2^b' e'_j (actual residual norms)       zeta (2^b' emax' + eta') + (||x|| + zeta) eta'
+//   MFMA fp32 accumulation                                             gamma' ((||x|| + zeta)(2^b' emax' + eta') + seedmax)
+//   index bits in the mantissa                                         2^-19 (2^b' ||x|| emax' + seedmax)
+//   seed rounded to fp32 (E' and the seeds are computed in fp64)       u seedmax
+//   conv tolerance: |delta.e_j| <= 1e-5 (||x|| || |W|^T |e_j| || + ||bias|| ||e_j||)      2^b' 1e-5 (||x|| qmax + bnorm emax)
+//   reference side on h, ||h|| <= sigma ||x|| (1 + 2e-4) + ||bias||    2^b' [2u (||h||^2 + enmax) + (u + gamma_D) ||h|| emax]
+// (DvqFoldMeta shares its first six fields with DvqF16Meta, so pass 1 / the resolver read the scale the same way.)
+// ---------------------------------------------------------------------------------------------
+struct DvqFoldMeta {
+    int ok;         // 1: codebook, conv weight, bias and E W finite and representable; 0: every token goes to the exact list
+    int b_exp;      // eh' = fp16(2^b' e'),  2^b' max|e'| in [2^14, 2^15)
+    float scale_b;  // 2^b'
+    float emax;     // >= max_j ||e'_j||,  e'_j = W^T e_j
+    float enmax;    // max_j en_j (the codebook's own)
+    float etamax;   // >= max_j ||2^b' e'_j - eh'_j||
+    float seedmax;  // >= max_j |2^b' (bias.e_j - en_j/2)|
+    float qmax;     // >= max_j || |W|^T |e_j| ||
+    float sigma;    // >= ||W||_2: min(||W||_F, sqrt(||W^T W||_inf))
+    float bnorm;    // >= ||bias||_2
+    float emax0;    // >= max_j ||e_j||
+    float pad[5];
+};
+static_assert(sizeof(DvqFoldMeta) == sizeof(DvqF16Meta), "pass 1 reads either through the same pointer");
+static constexpr float CONV_TOL = 1.0e-5f;        // contract of the conv's output, relative to sum |w||x| (dvq.h: dvq_qconv_f32)
+
+__device__ __forceinline__ float dvq_fold_threshold(float xn, float amax, float zeta2, float sB,
+                                                    const DvqFoldMeta *__restrict__ meta)
+{
+    const float emaxp = meta->emax, enmax = meta->enmax, etamax = meta->etamax, seedmax = meta->seedmax;
+    const bool bad = !(xn < __builtin_inff()) || !(amax < 60000.0f) || !meta->ok || !(seedmax < 1.0e37f);
+    const float zeta = sqrtf(zeta2) * 1.001f;
+    const float Rx = sqrtf(xn) * 1.00001f;
+    const float xn_ = Rx + zeta;
+    const float ehn = sB * emaxp + etamax;
+    const float Hn = meta->sigma * Rx * 1.0002f + meta->bnorm;
+    const float Wv = zeta * ehn + xn_ * etamax
+                     + GAMMA_P * (xn_ * ehn + seedmax)
+                     + PACK_E * (sB * Rx * emaxp + seedmax)
+                     + 6.1e-8f * seedmax
+                     + sB * (CONV_TOL * 1.001f) * (Rx * meta->qmax + meta->bnorm * meta->emax0)
+                     + sB * (REF_XN * (Hn * Hn * 1.00001f + enmax) + REF_RE * Hn * meta->emax0);
     return bad ? __builtin_nanf("") : 2.0f * Wv * 1.001f;
 }
 
@@ -129,6 +181,13 @@ struct DvqConv {
     const float *bias;     // channel order
     float *h_buf;
     int h_all;
+};
+
+// the conv folded into the codebook (vq_fold.hip): the buffer of dvq_fold_prepare_f32 (meta + the two images of E W) and
+// the conv itself, which the resolver and the exact-list kernel run on the few tokens they handle
+struct DvqFold {
+    const char *fprep;
+    DvqConv cv;            // h_buf unused
 };
 
 struct DvqGateRaw { float f[3]; long long i[3]; };

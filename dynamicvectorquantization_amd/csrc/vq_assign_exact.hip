@@ -24,13 +24,18 @@
 
 // ROUTED: token = output position of a routed batch (dvq_filter.h: DvqRouted), read from the encoder branch that
 // won its cell.
-template <int D, bool LIST, bool ROUTED>
-__global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
+// FOLDCONV (list mode of the conv-folded filter path, vq_fold.hip): z / the branches hold the conv's INPUT; a wave first
+// computes h = W x + bias for its 32 tokens (qconv.hip's split-fp16 arithmetic on the matrix cores, weight fragments straight
+// from the L2-resident images; bit-identical to dvq_qconv_f32 and to the resolver's h) and moves the accumulators into the
+// (even / odd channel per lane half) layout of zr by one cross-half exchange per register pair.  A rare path: one workgroup
+// per CU (512 registers), no attempt at overlap.
+template <int D, bool LIST, bool ROUTED, bool FOLDCONV = false>
+__global__ __launch_bounds__(256, FOLDCONV ? 1 : 2) void vq_assign_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ tiles, const float *__restrict__ E,
     const float *__restrict__ mask, int HW, int K, long N,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     const int *__restrict__ list, const int *__restrict__ list_count,
-    DvqLossTail tail, const DvqRouted rv)
+    DvqLossTail tail, const DvqRouted rv, const DvqConv cv)
 {
     constexpr int S = D / 2;                         // MFMA steps (2 k each)
     constexpr int TILE_FLOATS = 32 * D + 64;
@@ -82,8 +87,81 @@ __global__ __launch_bounds__(256, 2) void vq_assign_exact_kernel(
     const size_t zqbase = ((size_t)bout * D + h) * HWo + (size_t)(nn - bout * HWo);
 
     float zr[S];
+    if constexpr (FOLDCONV) {
+        constexpr int S16 = D / 16, T8 = D / 32;
+        constexpr int QIMG = S16 * 1024, QTILE = 2 * QIMG + 256;
+        const float *xb = zp - (size_t)h * stride;            // channel 0 of the token
+        f16x8 xh[S16], xl[S16];
+        float unscale;
+        {
+            float xf[S16][8];
+            float amax = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S16; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xf[s][j] = xb[(size_t)(16 * s + 8 * h + j) * stride];
+                    amax = vmax_abs(amax, xf[s][j]);
+                }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            int ea = 0;
+            if (amax > 0.0f && amax < __builtin_inff()) { int e; (void)frexpf(amax, &e); ea = 14 - e; }
+            ea = ea > 100 ? 100 : (ea < -100 ? -100 : ea);
+            const float sa = ldexpf(1.0f, ea);
+            unscale = ldexpf(cv.meta->inv_scale_w, -ea);
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                u32x4 ph, pl;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const float v0 = xf[s][2 * j2] * sa, v1 = xf[s][2 * j2 + 1] * sa;
+                    const f32x2 vv = {v0, v1};
+                    const f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};
+                    const f16x2 ll = __builtin_convertvector(rr, f16x2);
+                    ph[j2] = __builtin_bit_cast(unsigned, hh);
+                    pl[j2] = __builtin_bit_cast(unsigned, ll);
+                }
+                xh[s] = __builtin_bit_cast(f16x8, ph);
+                xl[s] = __builtin_bit_cast(f16x8, pl);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t8 = 0; t8 < T8; ++t8) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S16; ++s) {
+                const char *wt = cv.wimg + (size_t)t8 * QTILE + s * 1024 + lane * 16;
+                const f16x8 ah = *(const f16x8 *)wt, al = *(const f16x8 *)(wt + QIMG);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], acc, 0, 0, 0);     // small terms first (qconv.hip)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[s], acc, 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // at most four k-steps of weight fragments in flight
+            }
+            // register r of lane half h holds channel 32 t8 + 16 (r >> 3) + 8 h + (r & 7); zr[s] of lane half h is channel
+            // 2 s + h: of each register pair (j = 2m, 2m + 1) a lane keeps the channel of its own parity and hands the other
+            // one to its partner lane (lane ^ 32), whose channel of that parity sits in the same pair 8 channels away
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int r0 = 8 * a + 2 * m, ch0 = 32 * t8 + 16 * a + 8 * h + 2 * m;
+                    const float v0 = __builtin_fmaf(acc[r0], unscale, cv.bias[ch0]);
+                    const float v1 = __builtin_fmaf(acc[r0 + 1], unscale, cv.bias[ch0 + 1]);
+                    const float keep = h ? v1 : v0, send = h ? v0 : v1;
+                    const float recv = __shfl_xor(send, 32);
+                    zr[16 * t8 + 8 * a + m] = h ? recv : keep;
+                    zr[16 * t8 + 8 * a + 4 + m] = h ? keep : recv;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < S; ++s) zr[s] = zp[(size_t)2 * s * stride];
+    }
 
     auto stage = [&](int t, float *buf) {
         const char *src = (const char *)(tiles + (size_t)t * TILE_FLOATS);
@@ -357,22 +435,29 @@ template <int D, bool ROUTED>
 static int launch_exact(const float *z, const float *tiles, const float *E, const float *mask,
                         int HW, int K, long N, float *zq, long long *codes, double *partials,
                         const int *list, const int *list_count, DvqLossTail tail, const DvqRouted &rv,
-                        hipStream_t st)
+                        hipStream_t st, const DvqConv *fold_conv)
 {
-    static unsigned long long done_dense = 0, done_list = 0;
+    static unsigned long long done_dense = 0, done_list = 0, done_fold = 0;
     const size_t shmem = 2 * (32 * D + 64) * sizeof(float);
     int rc = dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, false, ROUTED>, (int)shmem, &done_dense);
     if (rc) return rc;
     rc = dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, true, ROUTED>, (int)shmem, &done_list);
     if (rc) return rc;
     int blocks = (int)((N + 127) / 128);
-    if (list != nullptr) {
+    const DvqConv nocv = {};
+    if (list != nullptr && fold_conv != nullptr) {
+        rc = dvq_allow_dynamic_lds((const void *)vq_assign_exact_kernel<D, true, ROUTED, true>, (int)shmem, &done_fold);
+        if (rc) return rc;
+        if (blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
+        hipLaunchKernelGGL((vq_assign_exact_kernel<D, true, ROUTED, true>), dim3(blocks), dim3(256), shmem, st,
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv, *fold_conv);
+    } else if (list != nullptr) {
         if (blocks > DVQ_EXACT_LIST_BLOCKS) blocks = DVQ_EXACT_LIST_BLOCKS;
         hipLaunchKernelGGL((vq_assign_exact_kernel<D, true, ROUTED>), dim3(blocks), dim3(256), shmem, st,
-                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv);
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv, nocv);
     } else {
         hipLaunchKernelGGL((vq_assign_exact_kernel<D, false, ROUTED>), dim3(blocks), dim3(256), shmem, st,
-                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv);
+                           z, tiles, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, rv, nocv);
     }
     return (int)hipGetLastError();
 }
@@ -383,20 +468,20 @@ static const DvqRouted kNoRoute = {};
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                           const int *list, const int *list_count, DvqLossTail tail, const DvqRouted *rv,
-                          hipStream_t st)
+                          hipStream_t st, const DvqConv *fold_conv)
 {
     if (rv != nullptr) {
         switch (D) {
-        case 64:  return launch_exact<64, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
-        case 128: return launch_exact<128, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
-        case 256: return launch_exact<256, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st);
+        case 64:  return launch_exact<64, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st, fold_conv);
+        case 128: return launch_exact<128, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st, fold_conv);
+        case 256: return launch_exact<256, true>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, *rv, st, fold_conv);
         default:  return -1000;
         }
     }
     switch (D) {
-    case 64:  return launch_exact<64, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
-    case 128: return launch_exact<128, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
-    case 256: return launch_exact<256, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st);
+    case 64:  return launch_exact<64, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st, fold_conv);
+    case 128: return launch_exact<128, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st, fold_conv);
+    case 256: return launch_exact<256, false>(z, prep, E, mask, HW, K, N, zq, codes, partials, list, list_count, tail, kNoRoute, st, fold_conv);
     default:  return -1000;
     }
 }
@@ -408,7 +493,7 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      const DvqRouted *rv, hipStream_t st)
 {
     const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f, nullptr, 0};
-    return dvq_launch_exact_list(z, prep, E, mask, D, HW, K, N, zq, codes, partials, nullptr, nullptr, none, rv, st);
+    return dvq_launch_exact_list(z, prep, E, mask, D, HW, K, N, zq, codes, partials, nullptr, nullptr, none, rv, st, nullptr);
 }
 
 int dvq_launch_loss_finalize(const double *partials, int nparts, double inv_numel, float beta,

@@ -268,7 +268,7 @@ __device__ __forceinline__ int dvq_cu_slot()
     return (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu));
 }
 
-template <int D, int SEL, bool CONV>
+template <int D, int SEL, bool CONV, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     char *__restrict__ records, int rec_cap, const DvqRouted rv, int *__restrict__ cu_lock, const DvqConv cv)
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
+    static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
     constexpr int NW = 4;
     constexpr int S16 = D / 16;
     constexpr int S32 = S16 / 2;
@@ -659,7 +660,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         zeta2 += __shfl_xor(zeta2, 32);
-        thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
+        // FOLD: z is the conv's input, `img` / `meta` the folded codebook E W (vq_fold.hip), and the bound also covers the conv
+        thr2W = FOLD ? dvq_fold_threshold(xn, amax, zeta2, sB, (const DvqFoldMeta *)meta)
+                     : dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     }
     if (SEL == 2) {
         __builtin_amdgcn_s_barrier();                        // every wave has read the branch images: the slots join the ring
@@ -900,9 +903,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             float e = eg[q][j >> 2][j & 3];
+                            if constexpr (FOLD) {           // the registers hold the conv's INPUT: z_q := e[code] (within 1e-6 of
+                                if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, e);   // fl(h + fl(e - h))), no loss term
+                            } else {
                             float diff = __fsub_rn(e, zf[s][j]);
                             if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[s][j], diff));
                             lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                            }
                         }
                     }
                 }
@@ -1328,13 +1335,35 @@ __device__ __forceinline__ unsigned long long order_key(float d, int code)
 #ifndef DVQ_RES_WAVES
 #define DVQ_RES_WAVES 4          // waves per resolver workgroup (they split the code tiles)
 #endif
-template <int D>
+// ATen-order sum of squares of v[0 .. D) (oracle/dvq_oracle.c: dvq_oracle_sumsq; D a multiple of 32)
+__device__ __forceinline__ float aten_sumsq(const float *v, int D)
+{
+    float a[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) a[m] = 0.0f;
+    for (int k0 = 0; k0 < D; k0 += 32)
+#pragma unroll
+        for (int m = 0; m < 32; ++m) a[m] = __fadd_rn(a[m], sq_rn(v[k0 + m]));
+    float s = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float tl = __fadd_rn(__fadd_rn(__fadd_rn(a[l], a[l + 8]), a[l + 16]), a[l + 24]);
+        s = (l == 0) ? tl : __fadd_rn(s, tl);
+    }
+    return s;
+}
+
+// FOLD (vq_fold.hip): the records hold the conv's INPUT x and `img` / `meta` are the folded codebook: the enumeration below
+// runs on x exactly as pass 1 scored it (its candidate set contains the reference's winner for every h inside the conv's
+// tolerance); the workgroup then computes h = W x + bias for its 32 tokens -- qconv.hip's split-fp16 arithmetic, bit-identical
+// to dvq_qconv_f32 -- in place over x, and the exact chains / the rewrite run on that h against the codebook itself.
+template <int D, bool FOLD>
 __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
     const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    int nslice, int *__restrict__ chunk_sync, int Wout, float *__restrict__ h_spill)
+    int nslice, int *__restrict__ chunk_sync, int Wout, float *__restrict__ h_spill, const DvqConv cv)
 {
     // h_spill (conv fused into pass 1; null otherwise): [B, D, HW] buffer the exact-list kernel reads its tokens' latents from.
     // Pass 1 spills the rows of ITS hand-offs; the tokens the resolver itself sends to that list (candidate overflow, no
@@ -1402,7 +1431,6 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const RecMeta rm = *(const RecMeta *)(rec + (size_t)D * 4);
     const float thr = live ? rm.thr : __builtin_inff();
     __syncthreads();
-
     // ---- enumerate: every code whose approximate score reaches best - 2W.  The A fragments of a tile come
     // straight from L2 (16 KiB per tile) and a workgroup is one latency chain (about one workgroup per CU is
     // active), so the next tile's sixteen loads are in flight while this tile's MFMAs run (two fragment sets;
@@ -1450,6 +1478,76 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
                 if (t + RW < t_end) score(t + RW, a1, e1);
             }
         }
+    }
+    if constexpr (FOLD) {
+        constexpr int T8 = D / 32, NT = (T8 + RW - 1) / RW;      // row tiles of the weight; this wave takes wave, wave + RW, ..
+        constexpr int QIMG = S16 * 1024, QTILE = 2 * QIMG + 256;
+        float amax = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S16; ++s) {
+            const f32x4 lo = *(const f32x4 *)(rec + (16 * s + 8 * h) * 4);
+            const f32x4 hi = *(const f32x4 *)(rec + (16 * s + 8 * h + 4) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { amax = vmax_abs(amax, lo[j]); amax = vmax_abs(amax, hi[j]); }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        int ea = 0;                                              // per-token power-of-two scale, as qconv_kernel
+        if (amax > 0.0f && amax < __builtin_inff()) { int e; (void)frexpf(amax, &e); ea = 14 - e; }
+        ea = ea > 100 ? 100 : (ea < -100 ? -100 : ea);
+        const float sa = ldexpf(1.0f, ea);
+        const float unscale = ldexpf(cv.meta->inv_scale_w, -ea);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < S16; ++s) {
+            const f32x4 lo = *(const f32x4 *)(rec + (16 * s + 8 * h) * 4);
+            const f32x4 hi = *(const f32x4 *)(rec + (16 * s + 8 * h + 4) * 4);
+            u32x4 ph, pl;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float v0 = (j2 < 2 ? lo[2 * j2] : hi[2 * j2 - 4]) * sa, v1 = (j2 < 2 ? lo[2 * j2 + 1] : hi[2 * j2 - 3]) * sa;
+                const f32x2 vv = {v0, v1};
+                const f16x2 hh = __builtin_convertvector(vv, f16x2);
+                const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};
+                const f16x2 ll = __builtin_convertvector(rr, f16x2);
+                ph[j2] = __builtin_bit_cast(unsigned, hh);
+                pl[j2] = __builtin_bit_cast(unsigned, ll);
+            }
+            const f16x8 xh = __builtin_bit_cast(f16x8, ph), xl = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t8 = wave + i * RW;
+                if (t8 < T8) {
+                    const char *wt = cv.wimg + (size_t)t8 * QTILE + s * 1024 + lane * 16;
+                    const f16x8 ah = *(const f16x8 *)wt, al = *(const f16x8 *)(wt + QIMG);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[i], 0, 0, 0);     // small terms first (qconv.hip)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                         // every wave has read x: h takes its place
+        if (live) {
+            float *hrow = (float *)(srec + c * RB);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t8 = wave + i * RW;
+                if (t8 < T8) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = 32 * t8 + 16 * (r >> 3) + 8 * h + (r & 7);     // qconv_row_channel's inverse
+                        hrow[ch] = __builtin_fmaf(acc[i][r], unscale, cv.bias[ch]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < RES_SLOTS && base + tid < total)               // the reference's norm of h (ATen order), for the exact chains
+            ((RecMeta *)(srec + tid * RB + (size_t)D * 4))->xn = aten_sumsq((const float *)(srec + tid * RB), D);
+        __syncthreads();
     }
     __syncthreads();
     const int ncand_raw = misc[0];
@@ -1589,7 +1687,7 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
 // written out instead of reduced to a top-2.  One wave per 32 tokens; A fragments straight from the prep image.
 // (The tuning build can also dump best / second / 2W of the PRODUCTION kernel per token: g_dvq_tokdbg.)
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool FOLD>
 __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     const float *__restrict__ tokens, int n, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     int K, float *__restrict__ G, float *__restrict__ thr2W_out, float *__restrict__ xn_out)
@@ -1636,7 +1734,8 @@ __global__ __launch_bounds__(64) void filter_scores_debug_kernel(
     for (int l = 1; l < 8; ++l) xn = __fadd_rn(xn, t8[l]);
     amax = fmaxf(amax, __shfl_xor(amax, 32));
     zeta2 += __shfl_xor(zeta2, 32);
-    const float thr2W = dvq_filter_threshold(xn, amax, zeta2, sB, meta);
+    const float thr2W = FOLD ? dvq_fold_threshold(xn, amax, zeta2, sB, (const DvqFoldMeta *)meta)
+                             : dvq_filter_threshold(xn, amax, zeta2, sB, meta);
     if (valid && h == 0) { thr2W_out[tok] = thr2W; xn_out[tok] = xn; }
     // the 16x16x32 code loop of pass 1: lane (c16, q) holds tokens c16 / 16 + c16 of the block, k = 32 s' + 8 q + j --
     // the same fp16 values pass 1 permutes into this order
@@ -1697,18 +1796,28 @@ static size_t dvq_img16_offset(int K, int D)
     return ((size_t)dvq_num_tiles(K) * tile + 255) / 256 * 256;
 }
 
+// fold != 0: `prep` is the buffer of dvq_fold_prepare_f32, `tokens` the conv's inputs
 int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep, int D, int K, float *G,
-                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st)
+                                   float *thr2W, float *xn, float *scale_b_out, hipStream_t st, int fold)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
+    if (fold) base = (char *)prep;
     const DvqF16Meta *meta = (const DvqF16Meta *)base;
     const char *im = base + 256 + dvq_img16_offset(K, D);
     const int blocks = (n + 31) / 32;
+    if (fold) {
+        switch (D) {
+        case 64:  hipLaunchKernelGGL((filter_scores_debug_kernel<64, true>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+        case 128: hipLaunchKernelGGL((filter_scores_debug_kernel<128, true>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+        case 256: hipLaunchKernelGGL((filter_scores_debug_kernel<256, true>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+        default:  return -1000;
+        }
+    } else
     switch (D) {
-    case 64:  hipLaunchKernelGGL(filter_scores_debug_kernel<64>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
-    case 128: hipLaunchKernelGGL(filter_scores_debug_kernel<128>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
-    case 256: hipLaunchKernelGGL(filter_scores_debug_kernel<256>, dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+    case 64:  hipLaunchKernelGGL((filter_scores_debug_kernel<64, false>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+    case 128: hipLaunchKernelGGL((filter_scores_debug_kernel<128, false>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
+    case 256: hipLaunchKernelGGL((filter_scores_debug_kernel<256, false>), dim3(blocks), dim3(64), 0, st, tokens, n, im, meta, K, G, thr2W, xn); break;
     default:  return -1000;
     }
     if (scale_b_out != nullptr)
@@ -1731,7 +1840,7 @@ __global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict
 int dvq_launch_exact_list(const float *z, const float *prep, const float *E, const float *mask,
                           int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                           const int *list, const int *list_count, DvqLossTail tail, const DvqRouted *rv,
-                          hipStream_t st);
+                          hipStream_t st, const DvqConv *fold_conv = nullptr);
 
 // Launch-time choices of the filter path.  They are compile-time constants of the production library; only the
 // tuning build (-DDVQ_TUNING: libdvq_tuning.so, tools/) can change them, through dvq_tuning_set().
@@ -1872,7 +1981,7 @@ static bool staged_select_ok(const DvqRouted &rv)
     return true;
 }
 
-template <int D, int SEL, bool CONV = false>
+template <int D, int SEL, bool CONV = false, bool FOLD = false>
 static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta *meta, const float *E,
                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
                              double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st,
@@ -1880,12 +1989,12 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
-    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, CONV>, (int)shmem1, &done);
+    int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, CONV, FOLD>, (int)shmem1, &done);
     if (rc) return rc;
     const unsigned grid = (unsigned)((N + 127) / 128);
     // anti-phase pays when every CU holds two workgroups for more than one generation
     int *lock = (g_tune.antiphase && grid >= 1024) ? w.counters + DVQ_LOCK0 : nullptr;
-    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV>), dim3(grid), dim3(256), shmem1, st,
+    hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV, FOLD>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
                        w.cap / DVQ_QSHARDS, rv, lock, cv);
     return (int)hipGetLastError();
@@ -1895,10 +2004,18 @@ template <int D>
 static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                         const float *mask, int HW, int K, long N, float *zq, long long *codes,
                         double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
-                        hipStream_t st, const DvqConv *cv = nullptr)
+                        hipStream_t st, const DvqConv *cv = nullptr, bool fold = false)
 {
     const int nb1 = (int)((N + 127) / 128);
     const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
+    if (fold) {                                              // img / meta: the folded codebook; z (or the branches): the conv's input
+        const DvqRouted none = {};
+        if (rv == nullptr)
+            return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
+        if (staged_select_ok(*rv))
+            return launch_pass1_form<D, 2, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+        return launch_pass1_form<D, 1, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+    }
     if (cv != nullptr) {                                     // the 1x1 conv as the prologue (D = 256; the ABI layer checked)
         if constexpr (D == 256) {
             const DvqRouted none = {};
@@ -1941,23 +2058,28 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
 template <int D>
 static int launch_resolver(const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                            const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                           const FilterWs &w, int Wout, float *h_spill, hipStream_t st)
+                           const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st)
 {
     const int nslice = resolver_slices(K);
-    hipLaunchKernelGGL(vq_resolve_kernel<D>, dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img, meta,
-                       en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill);
+    if (fd != nullptr)
+        hipLaunchKernelGGL((vq_resolve_kernel<D, true>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
+                           meta, en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, fd->cv);
+    else
+        hipLaunchKernelGGL((vq_resolve_kernel<D, false>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
+                           meta, en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, DvqConv{});
     return (int)hipGetLastError();
 }
 
 static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                              const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                             const FilterWs &w, int Wout, float *h_spill, hipStream_t st)
+                             const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st)
 {
     switch (D) {
-    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
-    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
-    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, st);
+    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
+    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
+    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
     default:  return -1000;
     }
 }
@@ -1967,12 +2089,14 @@ static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, con
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv)
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
-    const DvqF16Meta *meta = (const DvqF16Meta *)base;
-    const char *img = base + 256;
+    // fd: pass 1 and the resolver's enumeration run on the folded codebook (same section layout); the exact chains, the
+    // gathers and the exact-list kernel on the codebook itself
+    const DvqF16Meta *meta = (fd != nullptr) ? (const DvqF16Meta *)fd->fprep : (const DvqF16Meta *)base;
+    const char *img = (fd != nullptr) ? fd->fprep + 256 : base + 256;
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     const FilterWs w = carve_ws(ws_extra, N, D);
     const bool routed = rv != nullptr;
@@ -1984,22 +2108,26 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     if (rc) return rc;
     const int np1 = (int)((N + 127) / 128);
     switch (D) {
-    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
-    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
-    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv); break;
+    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
+    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
+    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;
     const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
     // (h_all: pass 1 already wrote every token's row)
     rc = launch_resolver_d(D, img, meta, en_all, E, mask, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
-                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, st);
+                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, fd, st);
     if (rc) return rc;
     double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
     // the list kernel is the last of the op: it also sums all partials into loss[0..1]
     const DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + 4,
                               np1 + w.cap / RES_SLOTS + list_blocks(N),
                               1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS};
+    // conv folded in: the list kernel computes its tokens' h itself, from the conv's input (dense z or the branches)
+    if (fd != nullptr)
+        return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
+                                     w.exact_list, w.counters + 1, tail, rv, st, &fd->cv);
     // conv fused in: the tokens on the list have their conv output in cv->h_buf (dense layout), written by pass 1
     if (cv != nullptr)
         return dvq_launch_exact_list(cv->h_buf, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
@@ -2022,7 +2150,8 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
-                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv)
+                      double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv,
+                      const DvqFold *fd)
 {
     const int SC = (G == 2) ? 2 : 4;
     const int Wout = SC * wc, HWout = SC * hc * Wout;
@@ -2051,5 +2180,5 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
         return dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
     }
     return dvq_launch_filter(nullptr, prep, E, cmask, D, HWout, K, N, zq, codes, partials, ws_extra, pass1_only, false,
-                             loss, beta, &rv, st, cv);
+                             loss, beta, &rv, st, cv, fd);
 }

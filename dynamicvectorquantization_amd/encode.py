@@ -51,6 +51,13 @@ def _can_fuse_conv(quantize, quant_conv, *feats):
     return all(t.is_cuda and t.dtype == torch.float32 for t in feats)
 
 
+def _can_fold(quantize, quant_conv, *feats):
+    """the conv folded into the codebook (quantize.vq_assign*(fold=True)): the routed op's preconditions, a fusable conv of the
+    codebook's width (64 / 128 / 256 channels), the filter path.  Loss-free: callers ask for it."""
+    return (_can_fuse_conv(quantize, quant_conv, *feats) and _can_route(quantize, None, *feats)
+            and quantize.assign_mode == _lib.MODE_FILTER and quant_conv.out_channels == quantize.codebook.weight.shape[1])
+
+
 def _can_route_conv(quantize, quant_conv, *feats):
     """the whole chain select -> 1x1 quant_conv -> quantizer as ONE routed op with the conv as pass 1's prologue
     (dvq_vq_assign_routed_qconv_*): the routed op's preconditions, a fusable conv, 256 channels, the filter path"""
@@ -58,14 +65,28 @@ def _can_route_conv(quantize, quant_conv, *feats):
             and _can_route(quantize, None, *feats) and quantize.assign_mode == _lib.MODE_FILTER)
 
 
-def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0):
+def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=None, temp=0.0, fold=False):
     """-> (quant, emb_loss, info, grain_indices, gate) as DualGrainVQModel.encode
-    (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).  Inference paths (no autograd):
+    (dqvae_dual_feat.py:59-68, dqvae_dual_entropy.py:124-134).
+    fold=True (opt-in, inference that needs no loss: reconstruction, tokenisation): the quant_conv folded into the codebook --
+    no conv is computed for tokens the filter decides; emb_loss comes back as None, quant = codebook[codes] (within 1e-6 of the
+    reference's z + (z_q - z)).  Falls back to the default paths when its preconditions do not hold.
+    Inference paths (no autograd):
       * no quant_conv: gate + routing tail + quantizer as ONE routed op (the select fused into the assign);
       * a 1x1 quant_conv on 256 channels: the same ONE op with the conv as its prologue (h_dual and the conv's output are
         never written); other channel counts: select + conv as one kernel, then the dense assign;
     otherwise route select -> quant_conv -> dense assign as differentiable pieces."""
     fixed = isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda
+    if fold and _can_fold(quantize, quant_conv, h_coarse, h_fine):
+        cb = quantize.codebook
+        kw = dict(mode=quantize.assign_mode, conv=quant_conv, fold=True, want_loss=False)
+        if fixed:
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
+                                      threshold=router.fine_grain_threshold, **kw)
+        else:
+            gate = router(h_fine=h_fine, h_coarse=h_coarse, entropy=entropy)
+            r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, gate=gate, **kw)
+        return r["zq"], None, (None, None, r["codes"]), r["indices"], r["gate"].permute(0, 3, 1, 2)
     if _can_route_conv(quantize, quant_conv, h_coarse, h_fine):
         cb = quantize.codebook
         kw = dict(beta=quantize.beta, mode=quantize.assign_mode, conv=quant_conv)
@@ -107,9 +128,15 @@ def encode_dual(router, quantize, h_fine, h_coarse, entropy=None, quant_conv=Non
     return quant, emb_loss, info, sel["indices"], sel["gate"]
 
 
-def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None, temp=0.0):
-    """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77)."""
+def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None, temp=0.0, fold=False):
+    """-> (quant, emb_loss, info, grain_indices, gate) as TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77).
+    fold=True: see encode_dual (emb_loss = None)."""
     gate = router(h_fine=h_fine, h_median=h_median, h_coarse=h_coarse, entropy=None)
+    if fold and _can_fold(quantize, quant_conv, h_coarse, h_median, h_fine):
+        cb = quantize.codebook
+        r = vq_assign_routed_triple(h_coarse, h_median, h_fine, cb.codes, cb._prep, gate, mode=quantize.assign_mode,
+                                    conv=quant_conv, fold=True, want_loss=False)
+        return r["zq"], None, (None, None, r["codes"]), r["indices"], gate.permute(0, 3, 1, 2)
     if _can_route_conv(quantize, quant_conv, h_coarse, h_median, h_fine):
         cb = quantize.codebook
         r = vq_assign_routed_triple(h_coarse, h_median, h_fine, cb.codes, cb._prep, gate, beta=quantize.beta,
@@ -132,9 +159,15 @@ def encode_triple(router, quantize, h_fine, h_median, h_coarse, quant_conv=None,
     return quant, emb_loss, info, sel["indices"], sel["gate"]
 
 
-def encode_fixed(quantize, h, quant_conv=None):
+def encode_fixed(quantize, h, quant_conv=None, fold=False):
     """-> (quant, emb_loss, info) as VQModel.encode (fixed granularity, models/stage1/vqgan.py:68-72).  An eval-mode
-    VectorQuantize2 behind a 1x1 conv on 256 channels runs as one op (the conv is the assign's prologue)."""
+    VectorQuantize2 behind a 1x1 conv on 256 channels runs as one op (the conv is the assign's prologue).
+    fold=True: the conv folded into the codebook (emb_loss = None), see encode_dual."""
+    if fold and quant_conv is not None and h.dim() == 4 and _can_fold(quantize, quant_conv, h):
+        from .quantize import vq_assign
+        cb = quantize.codebook
+        zq, codes, _ = vq_assign(h, cb.codes, cb._prep, None, mode=quantize.assign_mode, conv=quant_conv, fold=True, want_loss=False)
+        return zq, None, (None, None, codes)
     if quant_conv is not None and h.dim() == 4 and _can_route_conv(quantize, quant_conv, h):
         from .quantize import vq_assign
         cb = quantize.codebook
@@ -145,7 +178,8 @@ def encode_fixed(quantize, h, quant_conv=None):
     return quantize(h)
 
 
-def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None, max_len=None, out=None, quant_conv=None):
+def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None, max_len=None, out=None, quant_conv=None,
+                     fold=False):
     """Codes-only tokenisation for stage 2 (reference models/stage2_dynamic/dqtransformer_uncond_entropy.py:166-171,182:
     `_, z_out = self.encode_to_z(x)` keeps only `permuter(indices, grain_indices)` and discards quant): the routed assign
     with want_zq = False / want_loss = False (pass 1 writes no z_q: 1032 B per token instead of 2060) followed by the
@@ -153,14 +187,18 @@ def encode_to_tokens(router, quantize, permuter, h_fine, h_coarse, entropy=None,
     is read back to the host: three kernels (counter zero, pass 1, resolver + list) and one permuter kernel, all queued.
     -> (permuter dict, grain_indices [B, hc, wc] int64, codes [B, 2hc, 2wc] int64).
     quant_conv: the first stage's 1x1 conv between select and quantizer (what `encode_to_z` runs through the stage-1 `encode`):
-    fused into the same op (256 channels).
+    fused into the same op (256 channels).  fold=True: that conv FOLDED into the codebook instead (64 / 128 / 256 channels):
+    pass 1 scores the branches against E W and computes no conv at all -- the same codes as the fused op (both evaluate the
+    reference chain on dvq_qconv_f32's h), at the speed of the conv-free tokenisation.
     Needs the fused routed op's preconditions (eval-mode VectorQuantize2, no autograd)."""
     if not _can_route(quantize, None, h_coarse, h_fine):
         raise _lib.DvqError("encode_to_tokens: needs an eval-mode VectorQuantize2 on fp32 GPU feature maps without autograd")
-    if quant_conv is not None and not _can_route_conv(quantize, quant_conv, h_coarse, h_fine):
+    if fold and (quant_conv is None or not _can_fold(quantize, quant_conv, h_coarse, h_fine)):
+        raise _lib.DvqError("encode_to_tokens(fold=True): needs a 1x1 nn.Conv2d(D, D) quant_conv on the GPU and the filter mode")
+    if quant_conv is not None and not fold and not _can_route_conv(quantize, quant_conv, h_coarse, h_fine):
         raise _lib.DvqError("encode_to_tokens: the quant_conv must be a 1x1 nn.Conv2d(256, 256) on the GPU (filter mode)")
     cb = quantize.codebook
-    kw = dict(beta=quantize.beta, mode=quantize.assign_mode, want_zq=False, want_loss=False, conv=quant_conv)
+    kw = dict(beta=quantize.beta, mode=quantize.assign_mode, want_zq=False, want_loss=False, conv=quant_conv, fold=bool(fold))
     if isinstance(router, DualGrainFixedEntropyRouter) and entropy is not None and entropy.is_cuda:
         r = vq_assign_routed_dual(h_coarse, h_fine, cb.codes, cb._prep, entropy=entropy,
                                   threshold=router.fine_grain_threshold, **kw)

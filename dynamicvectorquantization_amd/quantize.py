@@ -47,6 +47,8 @@ class _CodebookPrep:
         self._ws = {}            # (B, D, HW, K, mode, device, stream) -> uint8 tensor
         self._hbuf = {}          # (shape, device, stream) -> f32 tensor: h rows of exact-list tokens (ops with the conv fused in)
         self._last_ws = None
+        self._retired = []       # images replaced outside training: kept alive for readers other streams may still have queued
+        self._fold = {}          # id(conv) -> (key, buffer, (stream, event)): the conv folded into this codebook (vq_fold.hip)
 
     def invalidate(self):
         self.key = None
@@ -59,12 +61,18 @@ class _CodebookPrep:
             nbytes = _lib_handle.dvq_codebook_prep_bytes(K, D)
             if nbytes == 0:
                 raise _lib.DvqError("unsupported codebook shape K=%d D=%d" % (K, D))
-            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != codebook.device:
+            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != codebook.device or not self.track_users:
+                # outside training (load_state_dict, invalidate, .to()) no use events exist: the new image goes to a FRESH
+                # buffer and the old one is kept for whatever other streams still have queued against it
+                if self.buf is not None:
+                    self._retired = (self._retired + [self.buf])[-4:]
                 self.buf = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
             for h, ev in self._users.items():        # other streams may still be reading the old image
                 if h != cur.cuda_stream:
                     cur.wait_event(ev)
             self._users.clear()
+            self._retired = (self._retired + [ent[1] for ent in self._fold.values()])[-4:]
+            self._fold.clear()
             _lib.check(_lib_handle.dvq_codebook_prepare_f32(
                 codebook.data_ptr(), K, D, self.buf.data_ptr(), self.buf.numel(),
                 cur.cuda_stream), "dvq_codebook_prepare_f32")
@@ -79,6 +87,40 @@ class _CodebookPrep:
             else:
                 cur.wait_event(self._built[1])
         return self.buf
+
+    def fold(self, codebook, conv):
+        """the image of `codebook` with the 1x1 `conv` folded in (dvq_fold_prepare_f32: E W, seeds, bound constants), built once
+        per (codebook, conv weight) pair; rebuilt into a fresh buffer when either changes.  Inference only."""
+        from . import qconv as _qconv
+        pbuf = self.get(codebook)
+        w, bias = conv.weight, conv.bias
+        K, D = codebook.shape
+        key = (self.key, w.data_ptr(), w._version, None if bias is None else (bias.data_ptr(), bias._version))
+        cur = torch.cuda.current_stream(codebook.device)
+        ent = self._fold.get(id(conv))
+        if ent is None or ent[0] != key or conv.training:
+            nbytes = _lib_handle.dvq_fold_prep_bytes(K, D)
+            if nbytes == 0:
+                raise _lib.DvqError("fold: unsupported codebook shape K=%d D=%d" % (K, D))
+            if ent is not None:
+                self._retired = (self._retired + [ent[1]])[-4:]
+            if len(self._fold) >= 4:
+                self._fold.clear()
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
+            w2 = _lib.require_cuda_f32(w.detach().reshape(D, D), "quant_conv.weight")
+            b2 = None if bias is None else _lib.require_cuda_f32(bias.detach(), "quant_conv.bias")
+            _lib.check(_lib_handle.dvq_fold_prepare_f32(codebook.data_ptr(), K, D, pbuf.data_ptr(), w2.data_ptr(), _lib.ptr(b2),
+                                                        buf.data_ptr(), buf.numel(), cur.cuda_stream), "dvq_fold_prepare_f32")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            ent = (key, buf, [cur.cuda_stream, ev])
+            self._fold[id(conv)] = ent
+        elif ent[2] is not None and ent[2][0] != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
+            if ent[2][1].query():
+                self._fold[id(conv)] = (ent[0], ent[1], None)
+            else:
+                cur.wait_event(ent[2][1])
+        return pbuf, ent[1]
 
     def used(self, device):
         """called after an op that read the image was queued on the current stream (only needed while the codebook can
@@ -148,14 +190,33 @@ def _conv_args(conv, prep, shape, device, h_buf):
     return _qconv._prep_of(conv).get(conv), h_buf, h_all
 
 
+def _fold_args(conv, prep, codebook, want_loss, mode):
+    """(qconv prep, codebook prep, fold prep) for the ops with the quant_conv FOLDED into the codebook (opt-in `fold=True`)"""
+    from . import qconv as _qconv
+    if conv is None or not _qconv.usable(conv) or conv.in_channels != codebook.shape[1]:
+        raise _lib.DvqError("fold=True needs conv = a 1x1 nn.Conv2d(D, D) on the GPU, D = the codebook dim (64, 128, 256)")
+    if want_loss:
+        raise ValueError("fold=True computes no loss (the conv's output does not exist for decided tokens): pass want_loss=False")
+    if mode not in (_lib.MODE_FILTER, _lib.MODE_FILTER_PASS1):
+        raise ValueError("fold=True is a form of the filter path (mode=MODE_FILTER)")
+    qbuf = _qconv._prep_of(conv).get(conv)
+    pbuf, fbuf = prep.fold(codebook, conv)
+    return qbuf, pbuf, fbuf
+
+
 def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=True,
-              mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
+              mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None, fold=False):
     """z [B, D, *spatial] f32 cuda, codebook [K, D] -> (zq or None, codes [B, *spatial] i64, loss[2] or None).
 
     loss[0] = mean((e - z)^2 * mask), loss[1] = beta*mean + mean.  `out` may carry preallocated
     (zq, codes, loss) tensors (used by the benchmark / graph capture).
     conv: a 1x1 nn.Conv2d(256, 256) applied to z first INSIDE the assign kernel (`dvq_vq_assign_qconv_f32`: the model's
-    quant_conv; its output never reaches memory).  h_buf: see _conv_args."""
+    quant_conv; its output never reaches memory).  h_buf: see _conv_args.
+    fold=True (needs conv, want_loss=False): the conv FOLDED into the codebook (`dvq_vq_assign_fold_f32`; loss-free inference /
+    stage-2 tokenisation): pass 1 scores z against E W and computes no conv; only undecided tokens get their conv output and the
+    reference chain.  codes = the reference argmin for a conv output within 1e-5 sum |w||x| of the real-number conv (the same
+    contract as conv= alone: near-ties of that tolerance may resolve differently); z_q = codebook[code] (within 1e-6 relative of
+    fl(h + fl(e - h)))."""
     z = _lib.require_cuda_f32(z, "z")
     codebook = _lib.require_cuda_f32(codebook, "codebook")
     B, D = z.shape[0], z.shape[1]
@@ -181,6 +242,13 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
             loss.fill_(float("nan"))
         return zq, codes, loss
     ws = prep.workspace(B, D, HW, K, mode, z.device)
+    if fold:
+        with torch.cuda.device(z.device):
+            qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
+            _lib.check(_lib_handle.dvq_vq_assign_fold_f32(
+                z.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), B, D, HW, K,
+                _lib.ptr(zq), codes.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(z.device)), "dvq_vq_assign_fold_f32")
+        return zq, codes, loss
     if conv is not None:
         with torch.cuda.device(z.device):
             qbuf, hb, h_all = _conv_args(conv, prep, z.shape, z.device, h_buf)
@@ -222,7 +290,7 @@ def _routed_outputs(h_fine, B, hc, wc, S, want_zq, want_loss, with_gate):
 
 
 def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=None, threshold=None, beta=0.25,
-                          want_zq=True, want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
+                          want_zq=True, want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None, fold=False):
     """Routing tail of DualGrainEncoder (EncoderDual.py:134-149) + VectorQuantize2.forward
     (quantize2_mask.py:157-191) as ONE op on the unique tokens (`dvq_vq_assign_routed_dual_f32`):
     h_coarse [B, D, hc, wc], h_fine [B, D, 2hc, 2wc]; either `gate` [B, hc, wc, 2] (f32 logits / int64) or
@@ -267,6 +335,15 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
     if nbytes == 0:
         raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
     ws = prep.workspace(B, D, ("routed2", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    if fold:                                     # the conv folded into the codebook (see vq_assign): codes [+ z_q], no loss
+        with torch.cuda.device(h_fine.device):
+            qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
+            _lib.check(_lib_handle.dvq_vq_assign_routed_fold_dual_f32(
+                g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(),
+                codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, _lib.ptr(zq), codes.data_ptr(), indices.data_ptr(),
+                cmask.data_ptr(), _lib.ptr(gate_out), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+                "dvq_vq_assign_routed_fold_dual_f32")
+        return res
     if conv is not None:
         with torch.cuda.device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
@@ -288,7 +365,7 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
 
 
 def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, beta=0.25, want_zq=True,
-                            want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None):
+                            want_loss=True, mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None, fold=False):
     """Routing tail of TripleGrainEncoder (EncoderTriple.py:148-176) + VectorQuantize2.forward as ONE op on the
     unique tokens (`dvq_vq_assign_routed_triple_f32`): h_coarse [B, D, hc, wc], h_median [B, D, 2hc, 2wc],
     h_fine [B, D, 4hc, 4wc], gate [B, hc, wc, 3].  -> dict as vq_assign_routed_dual.
@@ -319,6 +396,15 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
     if nbytes == 0:
         raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
     ws = prep.workspace(B, D, ("routed3", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    if fold:
+        with torch.cuda.device(h_fine.device):
+            qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
+            _lib.check(_lib_handle.dvq_vq_assign_routed_fold_triple_f32(
+                g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
+                fbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, _lib.ptr(zq), codes.data_ptr(),
+                indices.data_ptr(), cmask.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+                "dvq_vq_assign_routed_fold_triple_f32")
+        return res
     if conv is not None:
         with torch.cuda.device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)

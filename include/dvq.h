@@ -227,6 +227,49 @@ DVQ_API int dvq_vq_assign_routed_qconv_triple_f32(const void *gate, int gate_kin
                                           void *ws, size_t ws_bytes, int mode, void *stream);
 
 /*
+ * The quant_conv FOLDED into the codebook -- opt-in form of the model order for callers that need no loss: loss-free
+ * inference and stage 2's tokenisation, which keeps the code indices only
+ * (models/stage2_dynamic/dqtransformer_uncond_entropy.py:166-171,182 around models/stage1_dynamic/dqvae_dual_entropy.py:124-134).
+ * With h = W x + bias the nearest code maximises  h.e_j - en_j/2 = x.(W^T e_j) + (bias.e_j - en_j/2):  pass 1 scores the conv's
+ * INPUT against the image of E W (built in float64 by dvq_fold_prepare_f32, once per codebook / conv pair) and computes NO conv;
+ * only tokens it cannot prove decided get their conv output (dvq_qconv_f32's arithmetic, bit for bit) and the reference's fp32
+ * distance chain on it (resolver / exact-list kernel).  The decision bound covers every h within the conv contract's tolerance
+ * (1e-5 * sum |w||x| of the real-number conv), so:
+ *   codes = the reference argmin (quantize2_mask.py:29-55) evaluated on h = dvq_qconv_f32(x) -- identical to
+ *           dvq_qconv_f32 followed by dvq_vq_assign_nchw_f32; versus another conv implementation within that tolerance, codes can
+ *           differ only at near-ties of that tolerance (as for dvq_vq_assign_qconv_f32);
+ *   zq    = nullable; codebook[code] for the tokens pass 1 / the resolver decide, fl(h + fl(e - h)) for the few the exact-list
+ *           kernel handles: within 1e-6 relative of the reference's z_q given h (north_star tolerance 1e-5);
+ *   no loss (the conv output of a decided token is never formed; use dvq_vq_assign_*qconv* when the loss is needed).
+ * dvq_fold_prepare_f32: codebook [K, D] and ITS prep (dvq_codebook_prepare_f32), conv_weight [D, D] (row = output channel),
+ * conv_bias nullable [D] -> fold_prep (>= dvq_fold_prep_bytes(K, D), 256-byte aligned).  qconv_prep: dvq_qconv_prepare_f32 of the
+ * same weight / bias.  D in {64, 128, 256}.  Workspaces: dvq_vq_assign_workspace_bytes(.., DVQ_MODE_FILTER) /
+ * dvq_vq_assign_routed_workspace_bytes; dvq_vq_assign_*fallback_count_offset apply.  mode: DVQ_MODE_FILTER (or
+ * DVQ_MODE_FILTER_PASS1, the profiling aid).  Other arguments as the qconv forms.
+ */
+DVQ_API size_t dvq_fold_prep_bytes(int K, int D);
+DVQ_API int dvq_fold_prepare_f32(const float *codebook, int K, int D, const void *codebook_prep, const float *conv_weight,
+                         const float *conv_bias, void *fold_prep, size_t fold_prep_bytes, void *stream);
+DVQ_API int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *fold_prep, const float *codebook,
+                           const void *prep, int B, int D, int HW, int K, float *zq, int64_t *codes,
+                           void *ws, size_t ws_bytes, int mode, void *stream);
+DVQ_API int dvq_vq_assign_routed_fold_dual_f32(const void *gate, int gate_kind, float threshold,
+                                       const float *h_coarse, const float *h_fine, const void *qconv_prep,
+                                       const void *fold_prep, const float *codebook, const void *prep,
+                                       int B, int D, int hc, int wc, int K, float *zq, int64_t *codes,
+                                       int64_t *indices, float *cmask, int64_t *gate_out,
+                                       void *ws, size_t ws_bytes, int mode, void *stream);
+DVQ_API int dvq_vq_assign_routed_fold_triple_f32(const void *gate, int gate_kind,
+                                         const float *h_coarse, const float *h_median, const float *h_fine,
+                                         const void *qconv_prep, const void *fold_prep, const float *codebook, const void *prep,
+                                         int B, int D, int hc, int wc, int K, float *zq, int64_t *codes,
+                                         int64_t *indices, float *cmask, void *ws, size_t ws_bytes, int mode, void *stream);
+/* audit aid, as dvq_debug_filter_scores_f32 for the folded image: tokens = the conv's inputs [n, D]; scores G'_j, the per-token
+ * threshold 2W' (which also covers the conv tolerance), ||x||^2 and the scale 2^b' */
+DVQ_API int dvq_debug_fold_scores_f32(const float *tokens, int n, const void *fold_prep, int D, int K, float *scores,
+                              float *threshold, float *xn, float *scale, void *stream);
+
+/*
  * Backward of the quantizer's forward with respect to its input -- what autograd derives from the reference graph
  * (quantize2_mask.py:172-182, quantize_vqgan.py:290-298): identity through z + (z_q - z).detach() plus the commitment term,
  *   g_z = g_zq + (g_loss * coef_scale) * ((z - e) * mask),   e = codebook[codes]  (the codebook AS IT WAS at forward time:

@@ -148,3 +148,24 @@ def test_oracle_chain_against_the_reference_models_own_encode(oracle_mod, golden
     assert rate > 0.995, rate
     ol = float(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
     assert abs(ol - float(g["emb_loss"])) <= 1e-4 * abs(float(g["emb_loss"]))
+
+
+def test_fold_identity_in_float64(oracle_mod):
+    """host logic behind the conv-folded codebook (csrc/vq_fold.hip): with h = W x + b,
+    argmin_j ||h - e_j||^2 = argmax_j [ x.(W^T e_j) + (b.e_j - ||e_j||^2 / 2) ]  -- checked in float64 on seeded data, and the
+    oracle's fp32 chain on fp32(h) picks the same codes wherever the float64 margin is not a near-tie"""
+    from dynamicvectorquantization_amd import synth
+    D, K, n = 256, 512, 200
+    E = synth.codebook_trained(K, D, seed=4401).astype(np.float64)
+    Wc = synth.normal(4402, (D, D), 0.0, 1.0 / 16.0).astype(np.float64)
+    b = synth.normal(4403, (D,), 0.0, 0.1).astype(np.float64)
+    x = synth.normal(4404, (n, D)).astype(np.float64)
+    h = x @ Wc.T + b
+    d = ((h[:, None, :] - E[None]) ** 2).sum(-1)
+    score = x @ (E @ Wc).T + (E @ b - 0.5 * (E ** 2).sum(1))[None]
+    assert np.array_equal(d.argmin(1), score.argmax(1))
+    assert np.allclose(-0.5 * (d - (h ** 2).sum(1, keepdims=True)), score, rtol=1e-10, atol=1e-9)
+    o = oracle_mod.vq_assign_nchw(np.ascontiguousarray(h.astype(np.float32).T[None]), E.astype(np.float32), None)
+    srt = np.sort(d, 1)
+    clear = (srt[:, 1] - srt[:, 0]) > 1e-3
+    assert clear.sum() > n // 2 and np.array_equal(o["codes"].reshape(-1)[clear], d.argmin(1)[clear])

@@ -105,6 +105,94 @@ def audit_case_production(name, tokens, E, dev):
             "decided": decided, "decided_but_wrong": wrong, "skipped_unscorable": skipped}
 
 
+def fold_scores(x, E, Wc, bc, dev):
+    """conv inputs x [n, D], codebook E [K, D], conv weight Wc [D, D] / bias bc [D] numpy -> (G' [n, K], W' [n], ||x||^2 [n], 2^b')
+    through dvq_fold_prepare_f32 + dvq_debug_fold_scores_f32 (the folded image pass 1 scores against)"""
+    n, D = x.shape
+    K = E.shape[0]
+    Kpad = (K + 31) // 32 * 32
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Et = t(E)
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(Wc.reshape(D, D, 1, 1)))
+        conv.bias.copy_(t(bc))
+    prep = _CodebookPrep()
+    _, fbuf = prep.fold(Et, conv)
+    G = torch.empty((n, Kpad), dtype=torch.float32, device=dev)
+    thr = torch.empty(n, dtype=torch.float32, device=dev)
+    xn = torch.empty(n, dtype=torch.float32, device=dev)
+    sc = torch.empty(1, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.dvq_debug_fold_scores_f32(t(x).data_ptr(), n, fbuf.data_ptr(), D, K, G.data_ptr(), thr.data_ptr(),
+                                                  xn.data_ptr(), sc.data_ptr(), _lib.stream_ptr(dev)), "dvq_debug_fold_scores_f32")
+    torch.cuda.synchronize()
+    meta = fbuf[:64].view(torch.float32).cpu().numpy()
+    return G.cpu().numpy()[:, :K], thr.cpu().numpy().astype(np.float64) / 2.0, xn.cpu().numpy(), float(sc.item()), meta, conv
+
+
+def audit_case_fold(name, x, E, Wc, bc, dev):
+    """the FOLD bound (dvq_filter.h: dvq_fold_threshold): |G'_j - truth_j(h)| <= W' for EVERY h inside the conv tolerance of the
+    real-number conv, truth_j(h) = -2^(b'-1) (d_j(h) - xn(h)) in the reference's fp32 arithmetic on h.  Audited on h = fp32 of the
+    float64 conv, on h = dvq_qconv_f32(x) (what the resolver computes) and on two h at the EDGE of the tolerance ball
+    (+- 1e-5 (sum |w||x| + |b|) per channel, random signs)."""
+    from oracle import oracle
+    from dynamicvectorquantization_amd.qconv import quant_conv
+    G, W, xnx, sB, meta, conv = fold_scores(x, E, Wc, bc, dev)
+    n, K = G.shape
+    D = x.shape[1]
+    x64, w64, b64 = x.astype(np.float64), Wc.astype(np.float64), bc.astype(np.float64)
+    h64 = x64 @ w64.T + b64
+    mag = np.abs(x64) @ np.abs(w64).T + np.abs(b64)
+    hq = quant_conv(conv, torch.from_numpy(np.ascontiguousarray(x.T[None])).to(dev).reshape(1, D, n, 1)).cpu().numpy()[0, :, :, 0].T
+    assert np.all(np.abs(hq - h64) <= 1e-5 * mag + 1e-30), "dvq_qconv_f32 outside its own tolerance"
+    rng = np.random.RandomState(12345)
+    hs = [h64.astype(np.float32), hq,
+          (h64 + 1e-5 * mag * rng.choice([-1.0, 1.0], size=h64.shape)).astype(np.float32),
+          (h64 - 1e-5 * mag * np.sign(h64)).astype(np.float32)]
+    worst, decided, wrong, skipped = 0.0, 0, 0, 0
+    for i in range(n):
+        if not np.isfinite(W[i]):
+            skipped += 1
+            continue
+        order = np.argsort(-G[i], kind="stable")
+        dec = G[i][order[0]] - G[i][order[1]] > 2 * W[i]
+        decided += int(dec)
+        for h in hs:
+            d = oracle.token_distances(h[i], E).astype(np.float64)
+            xn_h = np.float64(oracle.sumsq_rows(h[i][None])[0])      # the reference's own fp32 norm of h
+            truth = -0.5 * sB * (d - xn_h)
+            worst = max(worst, float(np.abs(G[i].astype(np.float64) - truth).max() / W[i]))
+            if dec:
+                wrong += int(order[0] != int(np.argmin(d)))
+    return {"case": name, "kernel": "fold scores", "tokens": n, "codes": K, "scale_b": sB, "max_err_over_W": worst,
+            "decided": decided, "decided_but_wrong": wrong, "skipped_unscorable": skipped,
+            "sigma": float(meta[8]), "qmax": float(meta[7]), "emax_fold": float(meta[3])}
+
+
+def fold_cases(n):
+    """(name, conv inputs [n, D], codebook, conv weight, conv bias)"""
+    out = []
+    D = 256
+    E = synth.codebook_trained(1024, D)
+    Wg = synth.normal(31, (D, D), 0.0, 1.0 / 16.0)
+    bg = synth.normal(32, (D,), 0.0, 0.1)
+    q, _ = np.linalg.qr(synth.normal(33, (D, D)).astype(np.float64))
+    Wo = np.ascontiguousarray(q.astype(np.float32))
+    pre = lambda Wc, bc, seed: np.ascontiguousarray(                                   # inputs whose conv output sits near the codebook
+        ((synth.z_tokens(E, 1, 1, n, seed)[0, :, 0, :].T.astype(np.float64) - bc) @ np.linalg.inv(Wc.astype(np.float64)).T).astype(np.float32))
+    out.append(("orthogonal conv + bias, h ~ trained-like tokens", pre(Wo, bg, 41), E, Wo, bg))
+    out.append(("gaussian conv N(0,1/16) + bias, x ~ N(0,1)", synth.normal(42, (n, D)), E, Wg, bg))
+    out.append(("gaussian conv, h ~ trained-like tokens", pre(Wg, bg, 43), E, Wg, bg))
+    out.append(("conv x 30, x ~ N(0, 0.03)", synth.normal(44, (n, D), 0.0, 0.03), E, Wg * np.float32(30), bg))
+    out.append(("conv x 1e-3, big x", synth.normal(45, (n, D), 0.0, 300.0), E, Wg * np.float32(1e-3), bg * 0))
+    Ed = synth.codebook_default_init(1024, D)
+    out.append(("default-init codebook, orthogonal conv", synth.normal(46, (n, D), 0.0, 1e-3), Ed, Wo, bg * np.float32(1e-3)))
+    E64 = synth.codebook_trained(512, 64, seed=77)
+    W64 = synth.normal(47, (64, 64), 0.0, 1.0 / 8.0)
+    out.append(("D=64", synth.normal(48, (n, 64)), E64, W64, synth.normal(49, (64,), 0.0, 0.1)))
+    return out
+
+
 def cases(n):
     """(name, tokens [n, D], codebook) -- trained-like data, the tie-stress default init, large / tiny magnitudes,
     fp16-subnormal territory, near-duplicate codes, K = 16384, D = 64"""
@@ -129,6 +217,15 @@ def cases(n):
     return out
 
 
+def run_fold(n=64, verbose=True):
+    dev = torch.device("cuda:0")
+    res = [audit_case_fold(name, x, E, Wc, bc, dev) for name, x, E, Wc, bc in fold_cases(n)]
+    if verbose:
+        for r in res:
+            print(json.dumps(r))
+    return res
+
+
 def run(n=96, verbose=True, production=False):
     dev = torch.device("cuda:0")
     if production:
@@ -143,6 +240,11 @@ def run(n=96, verbose=True, production=False):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--fold" in sys.argv:
+        r = run_fold(int(args[0]) if args else 128)
+        print(json.dumps({"max_err_over_W": max(x["max_err_over_W"] for x in r),
+                          "decided_but_wrong": sum(x["decided_but_wrong"] for x in r)}))
+        sys.exit(0)
     r = run(int(args[0]) if args else 256, production="--production" in sys.argv)
     print(json.dumps({"max_err_over_W": max(x["max_err_over_W"] for x in r),
                       "decided_but_wrong": sum(x["decided_but_wrong"] for x in r)}))

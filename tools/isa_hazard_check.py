@@ -31,7 +31,7 @@ def regs(tok):
 def check(path):
     s = open(path).read()
     names = [l.split(":")[0] for l in s.splitlines()
-             if l.startswith("_Z23vq_assign_filter_kernelILi256") and "Lb1E" in l.split(":")[0]]
+             if l.startswith("_Z23vq_assign_filter_kernelILi256") and "ELb1ELb0EE" in l.split(":")[0]]   # <256, SEL, CONV = true, FOLD = false>
     assert names, "no CONV instantiation of vq_assign_filter_kernel in %s" % path
     report = []
     for name in names:
