@@ -1479,6 +1479,9 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
             }
         }
     }
+#ifndef DVQ_FOLD_ABL
+#define DVQ_FOLD_ABL 0           // timing experiments of the tuning build only (results WRONG): 1 no conv loop, 2 no xn, 4 no h write-back
+#endif
     if constexpr (FOLD) {
         constexpr int T8 = D / 32, NT = (T8 + RW - 1) / RW;      // row tiles of the weight; this wave takes wave, wave + RW, ..
         constexpr int QIMG = S16 * 1024, QTILE = 2 * QIMG + 256;
@@ -1496,57 +1499,85 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         ea = ea > 100 ? 100 : (ea < -100 ? -100 : ea);
         const float sa = ldexpf(1.0f, ea);
         const float unscale = ldexpf(cv.meta->inv_scale_w, -ea);
+        // branch-free: a wave whose tile index runs past the last tile (D = 64: waves 2, 3) recomputes the last one and
+        // writes the same values again.  The weight fragments come straight from L2, SB k-steps (SB * NT * 2 loads of 16 B per
+        // lane) in flight at a time -- with a conditional per tile hipcc waited for every single load (12 us of the kernel).
+        constexpr int SB = S16 < 8 ? S16 : 8;
+        int tile_of[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tile_of[i] = (wave + i * RW < T8) ? wave + i * RW : T8 - 1;
         f32x16 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-#pragma unroll 4
-        for (int s = 0; s < S16; ++s) {
-            const f32x4 lo = *(const f32x4 *)(rec + (16 * s + 8 * h) * 4);
-            const f32x4 hi = *(const f32x4 *)(rec + (16 * s + 8 * h + 4) * 4);
-            u32x4 ph, pl;
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const float v0 = (j2 < 2 ? lo[2 * j2] : hi[2 * j2 - 4]) * sa, v1 = (j2 < 2 ? lo[2 * j2 + 1] : hi[2 * j2 - 3]) * sa;
-                const f32x2 vv = {v0, v1};
-                const f16x2 hh = __builtin_convertvector(vv, f16x2);
-                const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};
-                const f16x2 ll = __builtin_convertvector(rr, f16x2);
-                ph[j2] = __builtin_bit_cast(unsigned, hh);
-                pl[j2] = __builtin_bit_cast(unsigned, ll);
-            }
-            const f16x8 xh = __builtin_bit_cast(f16x8, ph), xl = __builtin_bit_cast(f16x8, pl);
+        for (int s0 = 0; s0 < ((DVQ_FOLD_ABL & 1) ? 0 : S16); s0 += SB) {
+            f16x8 wh[SB][NT], wl[SB][NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int t8 = wave + i * RW;
-                if (t8 < T8) {
-                    const char *wt = cv.wimg + (size_t)t8 * QTILE + s * 1024 + lane * 16;
-                    const f16x8 ah = *(const f16x8 *)wt, al = *(const f16x8 *)(wt + QIMG);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[i], 0, 0, 0);     // small terms first (qconv.hip)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[i], 0, 0, 0);
+            for (int q = 0; q < SB; ++q)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const char *wt = cv.wimg + (size_t)tile_of[i] * QTILE + (s0 + q) * 1024 + lane * 16;
+                    wh[q][i] = *(const f16x8 *)wt;
+                    wl[q][i] = *(const f16x8 *)(wt + QIMG);
+                }
+            __builtin_amdgcn_sched_barrier(0);                   // all of the batch's loads are issued before its first MFMA
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int s = s0 + q;
+                const f32x4 lo = *(const f32x4 *)(rec + (16 * s + 8 * h) * 4);
+                const f32x4 hi = *(const f32x4 *)(rec + (16 * s + 8 * h + 4) * 4);
+                u32x4 ph, pl;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const float v0 = (j2 < 2 ? lo[2 * j2] : hi[2 * j2 - 4]) * sa, v1 = (j2 < 2 ? lo[2 * j2 + 1] : hi[2 * j2 - 3]) * sa;
+                    const f32x2 vv = {v0, v1};
+                    const f16x2 hh = __builtin_convertvector(vv, f16x2);
+                    const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};
+                    const f16x2 ll = __builtin_convertvector(rr, f16x2);
+                    ph[j2] = __builtin_bit_cast(unsigned, hh);
+                    pl[j2] = __builtin_bit_cast(unsigned, ll);
+                }
+                const f16x8 xh = __builtin_bit_cast(f16x8, ph), xl = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q][i], xh, acc[i], 0, 0, 0);     // small terms first (qconv.hip)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q][i], xl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q][i], xh, acc[i], 0, 0, 0);
                 }
             }
         }
         __syncthreads();                                         // every wave has read x: h takes its place
-        if (live) {
+        if (live && !(DVQ_FOLD_ABL & 4)) {
             float *hrow = (float *)(srec + c * RB);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int t8 = wave + i * RW;
-                if (t8 < T8) {
+                const int t8 = tile_of[i];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = 32 * t8 + 16 * (r >> 3) + 8 * h + (r & 7);     // qconv_row_channel's inverse
-                        hrow[ch] = __builtin_fmaf(acc[i][r], unscale, cv.bias[ch]);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 32 * t8 + 16 * (r >> 3) + 8 * h + (r & 7);     // qconv_row_channel's inverse
+                    hrow[ch] = __builtin_fmaf(acc[i][r], unscale, cv.bias[ch]);
                 }
             }
         }
         __syncthreads();
-        if (tid < RES_SLOTS && base + tid < total)               // the reference's norm of h (ATen order), for the exact chains
-            ((RecMeta *)(srec + tid * RB + (size_t)D * 4))->xn = aten_sumsq((const float *)(srec + tid * RB), D);
+        if (!(DVQ_FOLD_ABL & 2)) {
+            // the reference's norm of h (ATen order: 32 partial sums a[i % 32], ((a[l] + a[l+8]) + a[l+16]) + a[l+24], then l = 0..7
+            // left to right) for the exact chains: 8 lanes per token, lane l owns a[l], a[l+8], a[l+16], a[l+24]
+            static_assert(RW * 64 == RES_SLOTS * 8, "8 lanes per queued token");
+            const int tk = tid >> 3, l8 = tid & 7;
+            const float *hv = (const float *)(srec + tk * RB);
+            float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k0 = 0; k0 < D; k0 += 32)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a4[g] = __fadd_rn(a4[g], sq_rn(hv[k0 + l8 + 8 * g]));
+            const float tl = __fadd_rn(__fadd_rn(__fadd_rn(a4[0], a4[1]), a4[2]), a4[3]);
+            float sn = __shfl(tl, lane & ~7);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) sn = __fadd_rn(sn, __shfl(tl, (lane & ~7) + i));
+            if (l8 == 0 && base + tk < total) ((RecMeta *)(srec + tk * RB + (size_t)D * 4))->xn = sn;
+        }
         __syncthreads();
     }
     __syncthreads();
