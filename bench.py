@@ -433,13 +433,13 @@ class WeakDual:
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
         if self.a.path in ("select", "model2"):
-            return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)"
+            return "vq_assign_filter_kernel<256, 0, false, false> (dense pass 1)"
         if self.a.path in ("model", "tokens_model"):
-            return "vq_assign_filter_kernel<256, 1, true> (pass 1 with the router select and the 1x1 quant_conv fused in)"
+            return "vq_assign_filter_kernel<256, 1, true, false> (pass 1 with the router select and the 1x1 quant_conv fused in)"
         if self.a.path in ("tokens_fold", "model_fold"):
             return ("vq_assign_filter_kernel<256, 2, false, true> (pass 1 on the conv-folded codebook E W, router select fused in, "
                     "coarse branch staged through LDS)")
-        return "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, coarse branch staged through LDS)"
+        return "vq_assign_filter_kernel<256, 2, false, false> (pass 1, router select fused in, coarse branch staged through LDS)"
 
     def parity(self, slot):
         """the step's outputs, still in HBM, against the oracle on ALL images of this rank (the slot's own inputs)"""
@@ -647,8 +647,8 @@ class StrongTriple:
     def dominant_kernel_name(self):
         if self.a.mode == "exact":
             return "vq_assign_exact_kernel<256>"
-        return "vq_assign_filter_kernel<256, 0, false> (dense pass 1)" if self.a.path == "select" else \
-            "vq_assign_filter_kernel<256, 2, false> (pass 1, router select fused in, median / coarse branches staged through LDS)"
+        return "vq_assign_filter_kernel<256, 0, false, false> (dense pass 1)" if self.a.path == "select" else \
+            "vq_assign_filter_kernel<256, 2, false, false> (pass 1, router select fused in, median / coarse branches staged through LDS)"
 
     def parity(self, slot):
         """select + assign against the oracle GIVEN the logits the GPU router produced (the feature router
@@ -909,7 +909,7 @@ def run_rank(a):
                  "counter-zero kernel precedes it in the same op and is inside the bracket), one launch at a time after "
                  "the timed region. Inside the timed region consecutive steps overlap on config.streams HIP streams, so a "
                  "kernel trace of THIS command shows stretched, overlapping per-kernel durations; the trace of the same "
-                 "command with --streams 1 (profiles/r03_bench_kernel_stats.csv) is the one this figure agrees with "
+                 "command with --streams 1 (profiles/r04_bench_kernel_stats.csv) is the one this figure agrees with "
                  "(kernel_ms_rocprof, when that summary was made from these sources)",
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                  "algorithmic_note": "SURVEY.md 8d count of the VQ forward per launch of this kernel: every position read once "

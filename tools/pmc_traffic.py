@@ -26,9 +26,10 @@ kernels = {}
 def find(per, prefix):
     ks = [k for k in per if k.startswith(prefix)]
     return ks[0] if ks else None
-for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0, false>"), ("fused_pass1", "vq_assign_filter_kernel<256, 2, false>"),
-                      ("fused_pass1_per_lane_select", "vq_assign_filter_kernel<256, 1, false>"),
-                      ("model_pass1", "vq_assign_filter_kernel<256, 1, true>"), ("resolver", "vq_resolve_kernel<256>")):
+for label, prefix in (("dense_pass1", "vq_assign_filter_kernel<256, 0, false, false>"), ("fused_pass1", "vq_assign_filter_kernel<256, 2, false, false>"),
+                      ("fused_pass1_per_lane_select", "vq_assign_filter_kernel<256, 1, false, false>"),
+                      ("model_pass1", "vq_assign_filter_kernel<256, 1, true, false>"), ("fold_pass1", "vq_assign_filter_kernel<256, 2, false, true>"),
+                      ("resolver", "vq_resolve_kernel<256, false>"), ("fold_resolver", "vq_resolve_kernel<256, true>")):
     kf, kw = find(fetch, prefix), find(write, prefix)
     if kf is None or kw is None:
         continue
@@ -60,5 +61,27 @@ if "model_pass1" in kernels:
                     "line_granular_floor_bytes": floor,
                     "ratio_to_line_granular_floor": kernels["model_pass1"]["hbm_bytes_per_launch"] / floor,
                     "note": "per-lane select form (the ring slots the staged form parks the coarse branch in carry the conv's weights)"}
+# the routed pass 1's fetch split by what it is.  Dispatches of vq_assign_filter_kernel<256, 2, false, false>
+# in tools/pmc_workload.py order: [0:4] the whole op (3), then -- after the per-lane-select runs, a different instantiation --
+# [4:8] pass 1 alone (6), [8:12] codes only (7: no e-row gather), [12:16] codes only against K = 32 (8: one code tile)
+kf = find(fetch, "vq_assign_filter_kernel<256, 2, false, false>")
+kw = find(write, "vq_assign_filter_kernel<256, 2, false, false>")
+if kf is not None and len(fetch[kf]) >= 16:
+    grp = lambda per, k, i: sum(per[k][4 * i + 1:4 * i + 4]) / 3.0 * 1024.0
+    full, codes_only, k32 = (grp(fetch, kf, i) * factor for i in (1, 2, 3))
+    branch_lines = N * (D * 4 + D)                      # every 128-B line of h_fine and of h_coarse once
+    out["routed_fetch_split"] = {
+        "pass1_full_fetch_bytes": full, "pass1_codes_only_fetch_bytes": codes_only, "pass1_codes_only_K32_fetch_bytes": k32,
+        "e_row_gather_fetch_bytes": full - codes_only, "code_image_refetch_bytes": codes_only - k32,
+        "branch_line_floor_bytes": branch_lines, "K32_fetch_over_branch_lines": k32 / branch_lines,
+        "write_bytes": {"full": grp(write, kw, 1), "codes_only": grp(write, kw, 2), "codes_only_K32": grp(write, kw, 3)} if kw else None,
+        "note": "fetch counters corrected by the calibration factor; e-row gather = full - codes only; code-image / seed "
+                "re-fetch from the Infinity Cache = codes only - (codes only at K = 32); what remains above the branch-line "
+                "floor at K = 32 is gate / uncalibrated 16-B DMA counting"}
+if "fold_pass1" in kernels:
+    floor = N * (D * 4 + D + D * 4 + 8 + 4) + N // 4 * 4 + 1024 * D * 4
+    out["model_fold"] = {"hbm_bytes_per_launch": kernels["fold_pass1"]["hbm_bytes_per_launch"], "algorithmic_bytes": alg,
+                         "ratio_dominant_kernel_to_algorithmic": kernels["fold_pass1"]["hbm_bytes_per_launch"] / alg,
+                         "line_granular_floor_bytes": floor}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: out.get(k) for k in ("filter", "routed", "model")}), "factor", factor)
+print(json.dumps({k: out.get(k) for k in ("filter", "routed", "model", "model_fold", "routed_fetch_split")}), "factor", factor)

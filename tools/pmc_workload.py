@@ -47,4 +47,27 @@ pm = _CodebookPrep()
 for _ in range(4):
     vq_assign_routed_dual(hc, z, Et, pm, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER, conv=conv)
 torch.cuda.synchronize()
-print("queued/exact dense", p.fallback_count(), "routed", pr.fallback_count())
+# (6)-(8) VERDICT r3 item 3: what of the routed pass 1's fetch is NOT branch lines.  Pass 1 only (DVQ_MODE_FILTER_PASS1), each
+# variant 4 launches of the SAME kernel as (3) -- tools/pmc_traffic.py tells them apart by dispatch order:
+#   (6) the full pass 1 (z_q + loss partials: e rows gathered)      (7) codes only: zq = NULL, partials = NULL -> no e-row gather
+#   (8) codes only against a K = 32 codebook (one code tile: the code-image stream is 16 KiB per workgroup instead of 512 KiB)
+pp = _CodebookPrep()
+for _ in range(4):
+    vq_assign_routed_dual(hc, z, Et, pp, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER_PASS1)
+torch.cuda.synchronize()
+for _ in range(4):
+    vq_assign_routed_dual(hc, z, Et, pp, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER_PASS1,
+                          want_zq=False, want_loss=False)
+torch.cuda.synchronize()
+pp32 = _CodebookPrep()
+for _ in range(4):
+    vq_assign_routed_dual(hc, z, E32, pp32, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER_PASS1,
+                          want_zq=False, want_loss=False)
+torch.cuda.synchronize()
+# (9) the conv folded into the codebook (bench.py --path model_fold / tokens_fold): pass 1 on E W, then the whole op
+pf = _CodebookPrep()
+for _ in range(4):
+    vq_assign_routed_dual(hc, z, Et, pf, entropy=ent, threshold=1.6777750253677368, mode=_lib.MODE_FILTER, conv=conv, fold=True,
+                          want_loss=False)
+torch.cuda.synchronize()
+print("queued/exact dense", p.fallback_count(), "routed", pr.fallback_count(), "fold", pf.fallback_count())

@@ -32,9 +32,9 @@ if has rocprof; then
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_model -o t -- python3 $R/bench.py --path model --streams 1 --no-cpu-baseline --no-parity > $O/trace_bench_model.json 2>> $O/trace.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tokens -o t -- python3 $R/bench.py --path tokens --streams 1 --no-cpu-baseline --no-parity > $O/trace_bench_tokens.json 2>> $O/trace.err
   cd $R
-  python3 tools/rocprof_meta.py $O/trace_s1 $O/r03_bench_kernel_stats.csv routed weak "vq_assign_filter_kernel<256, 2, false>" | tee $O/rocprof_meta.log
+  python3 tools/rocprof_meta.py $O/trace_s1 $O/r03_bench_kernel_stats.csv routed weak "vq_assign_filter_kernel<256, 2, false, false>" | tee $O/rocprof_meta.log
   cp $O/bench_kernel_stats.meta.json $O/r03_bench_kernel_stats.meta.json 2>/dev/null
-  python3 tools/rocprof_meta.py $O/trace_model $O/r03_bench_model_kernel_stats.csv model weak "vq_assign_filter_kernel<256, 1, true>" bench_kernel_stats.model.meta.json | tee -a $O/rocprof_meta.log
+  python3 tools/rocprof_meta.py $O/trace_model $O/r03_bench_model_kernel_stats.csv model weak "vq_assign_filter_kernel<256, 1, true, false>" bench_kernel_stats.model.meta.json | tee -a $O/rocprof_meta.log
   for p in tokens; do f=$(ls $O/trace_$p/*kernel_stats.csv $O/trace_$p/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/r03_bench_${p}_kernel_stats.csv; done
 fi
 if has pmc; then
