@@ -674,6 +674,7 @@ def run_rank(a):
     import torch
     import torch.distributed as dist
 
+    t_proc0 = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -736,6 +737,11 @@ def run_rank(a):
 
     step()
     torch.cuda.synchronize()               # codebook image built before a second stream reads it
+    setup_s = time.perf_counter() - t_proc0   # imports, rendezvous, synthetic inputs, first step: what a rank needs before it can time
+    if world > 1:
+        ts = torch.tensor([setup_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        setup_s = float(ts.item())
     for _ in range(a.spinup):              # clock / power-state ramp, see --spinup
         step()
     for _ in range(a.warmup):
@@ -930,7 +936,7 @@ def run_rank(a):
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
                        "source_sha16": source_sha16(), "inputs": "one input set per stream slot (seeds differ)",
-                       "spinup_steps": a.spinup, "streams": S, "repeats": R,
+                       "spinup_steps": a.spinup, "streams": S, "repeats": R, "setup_seconds_slowest_rank": setup_s,
                        "timing": "median of `repeats` back-to-back blocks of exactly `steps` steps, each bracketed by barrier + "
                                  "synchronize, max over ranks per block", "host_issue_ms_per_step": t_issue / a.steps * 1e3,
                        "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "

@@ -74,6 +74,13 @@ def vq2_case(name, B, H, W, K, kind, seed, masked, full_codes=True, D=256):
     save(name, **kw)
 
 
+def vq2_small_dims():
+    """round 4: the kernels' other channel counts pinned by fixtures of their own (until now D = 64 / 128 were compared with the
+    oracle only, and the oracle with the reference by oracle/validate_against_reference.py in the build container)"""
+    vq2_case("vq2_D64_B2", 2, 16, 16, 512, "trained", 2064, masked=True, D=64)
+    vq2_case("vq2_D128_B2", 2, 16, 16, 512, "trained", 2128, masked=True, D=128)
+
+
 def vqgan_case(name, B, H, W, K, seed, legacy, sane):
     _, VQG = refimport.quantizers()
     D = 256
@@ -215,5 +222,6 @@ if __name__ == "__main__":
     vq2_case("vq2_nomask_B2", 2, 32, 32, 1024, "trained", 2022, masked=False)
     vq2_case("vq2_K16384_B2", 2, 32, 32, 16384, "trained", 2005, masked=True)
     vq2_case("vq2_16x16_B2", 2, 16, 16, 1024, "trained", 2032, masked=True)
+    vq2_small_dims()
     vq2_case("vq2_cfg2_B64_crc", 64, 32, 32, 1024, "trained", 2042, masked=True, full_codes=False)
     vq2_case("vq2_cfg3_B256_crc", 256, 32, 32, 1024, "trained", 2003, masked=True, full_codes=False)

@@ -61,7 +61,7 @@ def route_triple_inputs(g):
     return g["logits"], hc, hm, hf
 
 
-VQ2_FULL = ["vq2_cfg2_B4", "vq2_tiestress_B2", "vq2_nomask_B2", "vq2_16x16_B2", "vq2_K16384_B2"]
+VQ2_FULL = ["vq2_cfg2_B4", "vq2_tiestress_B2", "vq2_nomask_B2", "vq2_16x16_B2", "vq2_K16384_B2", "vq2_D64_B2", "vq2_D128_B2"]
 VQ2_CRC = ["vq2_cfg2_B64_crc", "vq2_cfg3_B256_crc"]
 VQGAN = ["vqgan_cfg1_B4", "vqgan_legacy_sane_B2"]
 

@@ -122,20 +122,26 @@ def test_oracle_properties(oracle_mod):
     assert np.array_equal(c[0::2, 0::2], c[1::2, 1::2]) and np.array_equal(c[0::2, 0::2], c[0::2, 1::2])
 
 
-def test_oracle_chain_against_the_reference_models_own_encode(oracle_mod, golden_dir):
+@pytest.mark.parametrize("fixture", ["encode_dual_entropy_model_B1.npz", "encode_dual_entropy_model_B4.npz"])
+def test_oracle_chain_against_the_reference_models_own_encode(oracle_mod, golden_dir, fixture):
     """the oracle's gate -> select -> (float64 conv, rounded to f32) -> assign chain against the golden captured from the reference's
-    own `DualGrainVQModel.encode` on CPU (oracle/gen_golden_encode.py): grain map and gate bit-equal, codes equal up to near-ties of
-    the conv's rounding (> 99.5 %), loss within 1e-4"""
+    own `DualGrainVQModel.encode` on CPU (oracle/gen_golden_encode.py; round 4: B = 4 with mixed grains): grain map and gate
+    bit-equal, codes equal up to near-ties of the conv's rounding (> 99.5 %), loss within 1e-4"""
     import json
     import os
     import zlib
     from dynamicvectorquantization_amd import synth
-    g = np.load(os.path.join(golden_dir, "encode_dual_entropy_model_B1.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
     K, D = 1024, 256
     E = synth.codebook_trained(K, D)
     cw, cb = synth.normal(9501, (D, D, 1, 1), 0.0, 1.0 / 16.0), synth.normal(9502, (D,), 0.0, 0.1)
     assert crc(E) == g["cb_crc"] and crc(cw) == g["conv_w_crc"] and crc(cb) == g["conv_b_crc"]
+    meta = json.loads(str(g["meta"]))
+    if "image_crc" in meta:                                   # the PIXELS regenerate from the seed (the GPU test starts from them)
+        img, _ = synth.images_flat_noise(meta["seeds"]["image"], g["h_fine"].shape[0])
+        assert int(crc(img)) == meta["image_crc"]
+        assert 0.2 < float(g["fine_ratio"]) < 0.8            # mixed grains
     thr = json.load(open(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json")))["50"]
     og = oracle_mod.entropy_gate(g["x_entropy"], thr)
     osel = oracle_mod.route_select_dual(og, g["h_coarse"], g["h_fine"])

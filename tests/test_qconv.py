@@ -506,3 +506,109 @@ def test_fused_conv_resolver_overflow_hands_h_to_the_exact_list(dev, oracle_mod,
         assert np.array_equal(codes.cpu().numpy().reshape(B, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
         if torch.equal(hb, h):                                 # the two conv kernels agree bit for bit on this data: so must the ops
             assert torch.equal(codes, codes0) and torch.equal(zq, zq0)
+
+
+def test_pixels_to_codes_against_the_reference_models_encode_B4(dev, golden_dir):
+    """the WHOLE chain of the entropy-router model from PIXELS -- images regenerated from the stored seed ->
+    `Entropy` kernel (dvq_entropy_map_f32) -> DualGrainFixedEntropyRouter -> routing tail + 1x1 quant_conv + VectorQuantize2 as one
+    op -- against the golden of the reference's own `DualGrainVQModel.encode` at B = 4 with mixed grains
+    (tests/golden/encode_dual_entropy_model_B4.npz, oracle/gen_golden_encode.py): entropy map within 1e-5, grain map and gate
+    equal, codes > 99.5 % (near-ties of the two convs' roundings only), loss 1e-4; the fold form gives the same codes as the
+    fused-conv form"""
+    import json
+    import zlib
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual
+    from dynamicvectorquantization_amd.entropy import Entropy
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, _CodebookPrep, vq_assign_routed_dual
+    from dynamicvectorquantization_amd.router import DualGrainFixedEntropyRouter
+    g = np.load(os.path.join(golden_dir, "encode_dual_entropy_model_B4.npz"))
+    meta = json.loads(str(g["meta"]))
+    crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    K, D, B = 1024, 256, 4
+    E = synth.codebook_trained(K, D)
+    cw, cb = synth.normal(9501, (D, D, 1, 1), 0.0, 1.0 / 16.0), synth.normal(9502, (D,), 0.0, 0.1)
+    assert crc(E) == g["cb_crc"] and crc(cw) == g["conv_w_crc"] and crc(cb) == g["conv_b_crc"]
+    img, _ = synth.images_flat_noise(meta["seeds"]["image"], B)
+    assert int(crc(img)) == meta["image_crc"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(cw)); conv.bias.copy_(t(cb))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    router = DualGrainFixedEntropyRouter(os.path.join(golden_dir, "entropy_thresholds_imagenet_train_patch-16.json"), 0.5)
+    hf, hc = t(g["h_fine"]), t(g["h_coarse"])
+    with torch.no_grad():
+        ent = Entropy(16, 256, 256)(t(img))                                  # from the pixels, on the fused kernel
+        assert np.abs(ent.cpu().numpy() - g["x_entropy"]).max() < 1e-5
+        assert np.abs(g["x_entropy"] - router.fine_grain_threshold).min() > 1e-3   # no patch sits at the threshold
+        quant, loss, info, grain, gate = encode_dual(router, vq, hf, hc, entropy=ent, quant_conv=conv)
+        qf, lf, infof, grainf, gatef = encode_dual(router, vq, hf, hc, entropy=ent, quant_conv=conv, fold=True)
+        hb = torch.empty_like(hf)
+        vq_assign_routed_dual(hc, hf, t(E), _CodebookPrep(), entropy=ent, threshold=router.fine_grain_threshold, conv=conv, h_buf=hb)
+    assert np.array_equal(grain.cpu().numpy(), g["grain"].astype(np.int64)) and 0.2 < float(g["fine_ratio"]) < 0.8
+    assert np.array_equal(gate.cpu().numpy(), g["gate"].astype(np.int64))
+    assert lf is None and torch.equal(infof[2], info[2]) and torch.equal(grainf, grain) and torch.equal(gatef, gate)
+    assert torch.all((qf - quant).abs() <= 1e-6 * torch.clamp(quant.abs(), min=1.0))
+    codes, ref = info[2].cpu().numpy().reshape(-1), g["codes"].astype(np.int64).reshape(-1)
+    rate = float((codes == ref).mean())
+    print("B = 4 from pixels: codes equal to the reference model's encode: %.5f (%d of %d differ)" % (rate, int((codes != ref).sum()), codes.size))
+    assert rate > 0.995
+    h = np.moveaxis(hb.cpu().numpy().reshape(B, D, -1), 1, 2).reshape(-1, D).astype(np.float64)
+    bad = np.nonzero(codes != ref)[0]
+    if bad.size:
+        d_ours = ((h[bad] - E[codes[bad]].astype(np.float64)) ** 2).sum(1)
+        d_ref = ((h[bad] - E[ref[bad]].astype(np.float64)) ** 2).sum(1)
+        assert np.all(np.abs(d_ref - d_ours) <= 1e-5 * np.maximum(d_ours, 1.0)), (d_ref - d_ours)
+    assert abs(float(loss) - float(g["emb_loss"])) <= 1e-4 * abs(float(g["emb_loss"]))
+
+
+@pytest.mark.parametrize("kind", ["dual", "triple"])
+def test_feature_router_models_B2_against_the_reference_models_own_encode(dev, golden_dir, kind):
+    """the feature-router models at B = 2 (tests/golden/encode_{dual,triple}_feature_model_B2.npz): gate logits within 1e-4 of the
+    reference's, the grain map equal in every cell whose argmax margin exceeds 1e-3 (the fixtures hold cells down to 3e-4: those may
+    flip inside the logits' tolerance and are excluded, with their tokens), codes > 99.5 % on the compared tokens"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.encode import encode_dual, encode_triple
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    import zlib
+    g = np.load(os.path.join(golden_dir, "encode_%s_feature_model_B2.npz" % kind))
+    crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    G = 2 if kind == "dual" else 3
+    K, D = 1024, 256
+    F = G * D
+    E = synth.codebook_trained(K, D)
+    cw, cb = synth.normal(9501, (D, D, 1, 1), 0.0, 1.0 / 16.0), synth.normal(9502, (D,), 0.0, 0.1)
+    w1, b1 = synth.normal(9600 + G, (F, F), 0.0, 1.0 / np.sqrt(F)), synth.normal(9610 + G, (F,), 0.0, 0.1)
+    w2, b2 = synth.normal(9620 + G, (G, F), 0.0, 1.0 / np.sqrt(F)), synth.normal(9630 + G, (G,), 0.0, 0.1)
+    for a, k in ((E, "cb"), (cw, "conv_w"), (cb, "conv_b"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        assert crc(a) == g[k + "_crc"], k
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    router = (DualGrainFeatureRouter if G == 2 else TripleGrainFeatureRouter)(D, "group-32", "2layer-fc-SiLu").to(dev).eval()
+    with torch.no_grad():
+        router.gate[0].weight.copy_(t(w1)); router.gate[0].bias.copy_(t(b1))
+        router.gate[2].weight.copy_(t(w2)); router.gate[2].bias.copy_(t(b2))
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(t(cw)); conv.bias.copy_(t(cb))
+    vq = VectorQuantize2(K, D).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(t(E))
+    hf, hc = t(g["h_fine"]), t(g["h_coarse"])
+    with torch.no_grad():
+        if G == 2:
+            quant, loss, info, grain, gate = encode_dual(router, vq, hf, hc, quant_conv=conv)
+        else:
+            quant, loss, info, grain, gate = encode_triple(router, vq, hf, t(g["h_median"]), hc, quant_conv=conv)
+    assert np.abs(gate.cpu().numpy() - g["gate"]).max() < 1e-4
+    top2 = np.sort(g["gate"], axis=1)[:, -2:]
+    sure = (top2[:, 1] - top2[:, 0]) > 1e-3                                  # [B, hc, wc]
+    assert sure.mean() > 0.98
+    assert np.array_equal(grain.cpu().numpy()[sure], g["grain"].astype(np.int64)[sure])
+    S = 32 // sure.shape[1]
+    tok_ok = np.repeat(np.repeat(sure & (grain.cpu().numpy() == g["grain"]), S, 1), S, 2).reshape(-1)
+    codes, ref = info[2].cpu().numpy().reshape(-1), g["codes"].astype(np.int64).reshape(-1)
+    rate = float((codes[tok_ok] == ref[tok_ok]).mean())
+    print("%s feature model B = 2: codes equal to the reference's on %d compared tokens: %.5f" % (kind, int(tok_ok.sum()), rate))
+    assert rate > 0.995

@@ -154,6 +154,33 @@ def test_bench_launcher_spawns_ranks_and_exchanges_on_device():
 
 
 @pytest.mark.gpu
+def test_bench_launcher_eight_ranks_on_one_device():
+    """the world size the launcher exists for.  `bench.py --gpus 8` on the ONE visible GPU (gloo rendezvous):
+    8-way rendezvous, BASELINE configs[3] strong scaling (global B = 1024 -> 128-image shards, fused feature-router gate + triple
+    routing + assign) and weak scaling at 16 images per rank; every rank checks its own images against the oracle, the gathered
+    global tensors against its shard (exchange_ok), and rank 0 reports the slowest rank's set-up time, so that the real 8-GPU run
+    is known to fit the driver's timeout on 16 host cores.  NOT a scaling measurement: eight ranks share one device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DVQ_BENCH_BACKEND="gloo")
+    env.pop("RANK", None)
+    for extra, nimg in ((["--scaling", "strong", "--batch", "1024"], 1024), (["--batch", "16"], 128)):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                            "--spinup", "1", "--repeats", "2", "--no-cpu-baseline"] + extra, env=env, capture_output=True,
+                           text=True, timeout=1500)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 8 and d["config"]["global_batch"] == nimg
+        assert d["parity_checked"] is True and d["code_mismatches"] == 0 and d["parity"]["exchange_ok"] is True
+        assert d["parity"]["images_checked"] == nimg
+        print("8 ranks on one device, %s: slowest rank's set-up %.1f s, %.3f ms per step (not a scaling figure)"
+              % (" ".join(extra), d["config"]["setup_seconds_slowest_rank"], d["ms_per_step"]))
+        assert d["config"]["setup_seconds_slowest_rank"] < 600
+
+
+@pytest.mark.gpu
 def test_code_exchange_rccl_world1(dev):
     """the REAL nccl (= RCCL) backend through CodeExchange at world size 1 (what a 1-GPU box can run): pack kernel ->
     ncclAllGather -> unpack kernel on the device, two exchanges in flight, against the local tensors.  In a child
