@@ -20,7 +20,7 @@ def _run(*extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("path", ["model", "model2", "tokens_model", "tokens"])
+@pytest.mark.parametrize("path", ["model", "model2", "tokens_model", "tokens", "tokens_fold", "model_fold"])
 def test_bench_path_runs_and_checks_itself(path):
     d = _run("--path", path)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -29,11 +29,15 @@ def test_bench_path_runs_and_checks_itself(path):
     assert d["config"]["path"] == path and d["steps"] == 6 and d["n_gpus"] == 1 and d["value"] > 0
     assert d["parity_checked"] is True, d["parity"]
     assert d["parity"]["code_mismatches"] == 0 and d["parity"]["slots_checked"] == 3
-    if path in ("model", "model2", "tokens_model"):
+    assert d["config"]["repeats"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    if path in ("model", "model2", "tokens_model", "tokens_fold", "model_fold"):
         assert d["parity"]["h_max_err_over_bound"] < 1.0 and d["parity"]["codes_match_rate_vs_fp64_conv"] > 0.995
     if path in ("model", "tokens_model"):
         assert d["parity"]["rerun_with_h_buf_mismatches"] == 0
-        assert "1, true>" in d["roofline"]["kernel"]
+        assert "1, true, false>" in d["roofline"]["kernel"]
+    if path in ("tokens_fold", "model_fold"):
+        assert "2, false, true>" in d["roofline"]["kernel"] and d["parity"]["tokens_resolved_with_a_conv"] > 0
+        assert d["parity"].get("zq_mismatches", 0) == 0
 
 
 def test_default_bench_reports_the_model_order_too():
