@@ -27,6 +27,7 @@
 // (logits within 1e-4 of the reference, ~1e-6 in practice), by design.
 #include "dvq_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 struct DvqGateArgs {
     const float *h[3];        // branches, coarse -> fine
@@ -46,22 +47,59 @@ struct DvqGateArgs {
 // thread owns whole (channel, cell) pairs, so a pooled value is summed in a fixed order by one thread (deterministic,
 // and the same expression as before the split) and neighbouring threads read neighbouring cells: every load
 // instruction covers whole rows of cells.  groups == 0 (no normalisation): pseudo-groups of 8 channels, no stats.
-__global__ __launch_bounds__(256) void gate_pool_kernel(DvqGateArgs a, float2 *__restrict__ ab,
-                                                        float *__restrict__ pool)
+// IMG (the GEMM form of the gate, gate_gemm_kernel): the pooled averages of the workgroup's channels stay in LDS until the group's
+// statistics are known, and are written ONCE, normalised and split hi + lo, straight into the MFMA B-operand images
+//   ximg[block = cell / 32][k-step s][hi 1 KiB | lo 1 KiB][lane = 32 h + cell % 32][j < 8] = feature k = 16 s + 8 h + j of the cell
+// (cell = global cell index b * hc * wc + y * wc + x), so that the matrix kernel streams them with plain LDS-DMA and no
+// workgroup rebuilds a tile.  fp16 range: every workgroup derives the SAME power-of-two scale from the GroupNorm parameters
+// alone -- |normalised value| <= |w| sqrt(n) + |b| for every element of a group of n values, and an average of such values
+// obeys the same bound -- so no workgroup needs another's data; xs[0] = that scale's inverse for the matrix kernel.
+#ifndef DVQ_POOL_WPE
+#define DVQ_POOL_WPE 8           // workgroups per CU the pooling pass is compiled for (a streaming pass lives on occupancy)
+#endif
+template <bool IMG>
+__global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArgs a, float2 *__restrict__ ab,
+                                                        float *__restrict__ pool, char *__restrict__ ximg,
+                                                        float *__restrict__ xs)
 {
     const int G = a.groups > 0 ? a.groups : a.C / 8;
     const int cpg = a.C / G;
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int ncell = a.hc * a.wc, F = a.nb * a.C;
     const int npair = cpg * ncell;
-    __shared__ double red[2][4];
+    __shared__ double red[3][2][4];                          // [branch (IMG; else 0)][sum | sum of squares][wave]
+    __shared__ float s_bound[4];
+    __shared__ float2 s_aff[3 * 64];                         // IMG: (scale, shift) of the group's channels, per branch
+    extern __shared__ float lp[];                            // IMG: [branch][cpg][ncell] pooled averages
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float xscale = 1.0f;
+    if (IMG) {
+        float bound = 0.0f;
+        for (int k = tid; k < F; k += 256) {
+            const int br = k / a.C, ch = k - br * a.C;
+            const float n = (float)cpg * (float)(a.hc * a.scale[br]) * (float)(a.wc * a.scale[br]);
+            bound = fmaxf(bound, fabsf(a.gn_w[br][ch]) * sqrtf(n) * 1.0001f + fabsf(a.gn_b[br][ch]));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
+        if (lane == 0) s_bound[wave] = bound;
+        __syncthreads();
+        bound = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3]));
+        float inv = 1.0f;
+        if (!(bound < 16384.0f) && bound < __builtin_inff()) {
+            int e;
+            (void)frexpf(bound, &e);                         // bound = m 2^e, m in [0.5, 1)
+            xscale = ldexpf(1.0f, 13 - e);                   // brings the bound below 2^13
+            inv = ldexpf(1.0f, e - 13);
+        }
+        if (blockIdx.x == 0 && tid == 0) xs[0] = inv;
+    }
     for (int br = 0; br < a.nb; ++br) {
         const int sc = a.scale[br];
         const int Wb = a.wc * sc;
         const size_t plane = (size_t)(a.hc * sc) * Wb;
         const float *p0 = a.h[br] + ((size_t)b * a.C + (size_t)g * cpg) * plane;
-        float *o0 = pool + ((size_t)b * F + (size_t)br * a.C + (size_t)g * cpg) * ncell;
+        float *o0 = IMG ? lp + (size_t)br * npair : pool + ((size_t)b * F + (size_t)br * a.C + (size_t)g * cpg) * ncell;
         double s = 0.0, ss = 0.0;
         if (a.vec && (Wb & 3) == 0) {
             // rows are whole float4s: a thread takes 4 consecutive source columns = 4 / sc cells of one row of cells
@@ -135,22 +173,53 @@ __global__ __launch_bounds__(256) void gate_pool_kernel(DvqGateArgs a, float2 *_
             }
             o0[pr] = v;
         }
+        auto affine = [&](int brr, int chl) -> float2 {      // the group's statistics of branch brr folded with channel chl's affine
+            const double n = (double)cpg * (double)(a.hc * a.scale[brr]) * (double)(a.wc * a.scale[brr]);
+            const int rb = IMG ? brr : 0;
+            const double mean = ((red[rb][0][0] + red[rb][0][1]) + (red[rb][0][2] + red[rb][0][3])) / n;
+            double var = ((red[rb][1][0] + red[rb][1][1]) + (red[rb][1][2] + red[rb][1][3])) / n - mean * mean;   // biased, as GroupNorm
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            const int ch = g * cpg + chl;
+            const float sc_ = rstd * a.gn_w[brr][ch];
+            return make_float2(sc_, a.gn_b[brr][ch] - mf * sc_);
+        };
         if (a.groups > 0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ss += __shfl_xor(ss, off); }
-            __syncthreads();                                 // red[] of the previous branch consumed
-            if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
-            __syncthreads();
-            if (tid < cpg) {                                 // the group's channels: normalisation folded into one affine
-                const double n = (double)cpg * (double)plane;
-                const double mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
-                double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mean * mean;   // biased, as GroupNorm
-                if (var < 0.0) var = 0.0;
-                const float mf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-                const int ch = g * cpg + tid;
-                const float sc_ = rstd * a.gn_w[br][ch];
-                ab[(size_t)b * F + (size_t)br * a.C + ch] = make_float2(sc_, a.gn_b[br][ch] - mf * sc_);
+            if (IMG) {                                       // one barrier for all branches, after the loop
+                if (lane == 0) { red[br][0][wave] = s; red[br][1][wave] = ss; }
+            } else {
+                __syncthreads();                             // red[] of the previous branch consumed
+                if (lane == 0) { red[0][0][wave] = s; red[0][1][wave] = ss; }
+                __syncthreads();
+                if (tid < cpg) ab[(size_t)b * F + (size_t)br * a.C + g * cpg + tid] = affine(br, tid);
             }
+        }
+        if (!IMG || br + 1 < a.nb) continue;
+        // IMG, after the last branch: every branch's pooled averages are in LDS and its sums in red[]
+        __syncthreads();
+        for (int i = tid; i < a.nb * cpg; i += 256) s_aff[(i / cpg) * 64 + (i % cpg)] = affine(i / cpg, i % cpg);
+        __syncthreads();
+        // one thread per (branch, cell, octet of channels): 8 LDS reads, normalise, scale, split, two 16-B stores
+        const int noct = cpg / 8;
+        for (int u = tid; u < a.nb * ncell * noct; u += 256) {
+            const int brr = u / (ncell * noct), r2 = u - brr * (ncell * noct);
+            const int o = r2 / ncell, cell = r2 - o * ncell;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 af = s_aff[brr * 64 + 8 * o + j];
+                const float x = (lp[(size_t)brr * npair + (8 * o + j) * ncell + cell] * af.x + af.y) * xscale;
+                const _Float16 hh = (_Float16)x;
+                hi[j] = hh;
+                lo[j] = (_Float16)(x - (float)hh);
+            }
+            const int kk = brr * a.C + g * cpg + 8 * o;      // first feature of the octet
+            const long cg = (long)b * ncell + cell;
+            char *dst = ximg + ((size_t)(cg >> 5) * (F / 16) + (kk >> 4)) * 2048 + (((kk >> 3) & 1) * 32 + (int)(cg & 31)) * 16;
+            *(f16x8 *)dst = hi;
+            *(f16x8 *)(dst + 1024) = lo;
         }
     }
 }
@@ -476,6 +545,197 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     }
 }
 
+// ---- 3b. the gate's hidden layer as a tiled GEMM: cells x hidden units, the WEIGHTS resident in registers.
+// router_gate_kernel above keeps a 32- or 64-cell feature tile in LDS and streams the whole hidden layer past it: every
+// workgroup re-reads the 1 - 2.4 MB of hi / lo weight images from L2 (604 MB at B = 128, triple) and rebuilds its tile from
+// the pooled averages.  Here a wave owns ONE 32-row tile of the hidden layer for the whole launch -- its hi / lo A fragments
+// (S k-steps x 2 x 4 registers: 256 VGPRs dual, 384 triple; one wave per SIMD, 512 registers) are loaded once -- and the cells
+// stream past it: the feature images the pooling pass wrote (gate_pool_kernel<true>) move through an LDS ring of 16-KiB chunks
+// (8 k-steps, hi | lo) by LDS-DMA, shared by the workgroup's four waves (four row tiles = 128 hidden units).  Per k-step a
+// wave issues two ds_read_b128 and three MFMAs; nothing else is in the loop.  grid = (cell-block groups, hidden groups of 128);
+// a workgroup walks its cell blocks with stride gridDim.x.  The output layer is contracted in the epilogue (bias, activation,
+// W2 rows from LDS); the partial logits of the hidden groups go to part[hg][cell][g] and are summed in a fixed order by
+// gate_finalize_kernel (deterministic; no float atomics).
+#ifndef DVQ_GEMM_ABL
+#define DVQ_GEMM_ABL 0           // timing experiments of the tuning build only (results WRONG): 1 no ring DMA in the loop, 2 no MFMAs,
+#endif                           // 4 no epilogue, 8 no B-fragment reads
+template <int G, int S>
+__global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
+    const char *__restrict__ ximg, const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL,
+    const float *__restrict__ b1, const float *__restrict__ W2, int Hid, int act, long ncell, int nblocks,
+    const float *__restrict__ xs, float *__restrict__ part)
+{
+    constexpr int CH = (S % 8 == 0) ? 8 : 4;                 // k-steps per ring chunk
+    constexpr int NCH = S / CH;                              // chunks per cell block
+    constexpr int CHB = CH * 2048;                           // bytes per chunk (hi + lo)
+    constexpr int RING = 8;
+    constexpr int PPW = CH * 2 / 4;                          // 1-KiB DMA pieces per wave and chunk
+    static_assert(S % CH == 0 && PPW >= 1, "S is a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) char glds[];       // [RING][CHB] | PB [4 waves][1 + G][32] | red [4][G][32]
+    float *PB = (float *)(glds + RING * CHB);
+    float *red = PB + 4 * (1 + G) * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int T = (Hid + 31) / 32;
+    const int hg = blockIdx.y;
+    const int t_raw = hg * 4 + wave;
+    const bool tile_ok = t_raw < T;
+    const int t = tile_ok ? t_raw : T - 1;
+    const int nmine = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // cell blocks of this workgroup
+    const int total = nmine * NCH;                           // chunks it streams
+
+    const char *isrc = ximg;                                 // source / ring address of the chunk being issued (this wave's pieces)
+    char *idst = glds;
+    auto issue_begin = [&](int q) {                          // chunk q of this workgroup's stream; past the end: harmless repeat
+        const int qq = q < total ? q : total - 1;
+        const int bi = (int)blockIdx.x + (qq / NCH) * (int)gridDim.x;
+        isrc = ximg + ((size_t)bi * S + (size_t)(qq % NCH) * CH) * 2048 + (wave * PPW) * 1024 + lane * 16;
+        idst = glds + (q & (RING - 1)) * CHB + (wave * PPW) * 1024;
+    };
+    auto issue_piece = [&](int p_) { glds16(isrc + p_ * 1024, idst + p_ * 1024); };
+    auto issue = [&](int q) {
+        issue_begin(q);
+#pragma unroll
+        for (int p_ = 0; p_ < PPW; ++p_) issue_piece(p_);
+    };
+    if (total <= 0) return;
+#pragma unroll
+    for (int q = 0; q < RING - 2; ++q) issue(q);
+    // this wave's rows of the hidden layer: A fragments, once
+    f16x8 ah[S], al[S];
+    {
+        const f16x8 *gh = (const f16x8 *)imgH + (size_t)t * S * 64 + lane;
+        const f16x8 *gl = (const f16x8 *)imgL + (size_t)t * S * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { ah[s] = gh[s * 64]; al[s] = gl[s * 64]; }
+    }
+    // bias and output-layer rows of this wave's 32 hidden units (rows past Hid: zeros -> contribute nothing)
+    for (int i = lane; i < (1 + G) * 32; i += 64) {
+        const int row = i >> 5, j = t * 32 + (i & 31);
+        float v = 0.0f;
+        if (j < Hid && tile_ok) v = (row == 0) ? b1[j] : W2[(size_t)(row - 1) * Hid + j];
+        PB[wave * (1 + G) * 32 + i] = v;
+    }
+    const float inv_scale = xs[0];
+    const float *pb = PB + wave * (1 + G) * 32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // A fragments and the first RING - 2 chunks (mine) are here
+
+    // The k-steps of all of this workgroup's cell blocks form ONE stream.  B fragments (hi, lo) are read from the ring four
+    // k-steps ahead of their MFMAs with hand-placed ds_read_b128 behind a counted lgkmcnt (a lone wave per SIMD has nobody to
+    // hide an LDS round trip behind); when the read-ahead enters a new chunk, the chunk's arrival is waited for (counted vmcnt
+    // + barrier) and the chunk RING - 2 further on is issued into the slot everybody left two chunks ago.
+    const unsigned lds_lane = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)glds + lane * 16;
+    f16x8 bh[4], bl[4];
+#define GG_RD(U, KOFF)                                                                                                  \
+    asm volatile("ds_read_b128 %0, %2 offset:%c3\n\tds_read_b128 %1, %2 offset:%c4"                                      \
+                 : "=v"(bh[(U) & 3]), "=v"(bl[(U) & 3]) : "v"(rd_base), "i"((KOFF) * 2048), "i"((KOFF) * 2048 + 1024))
+    unsigned rd_base;                                        // LDS address of the chunk the read-ahead is in (+ lane * 16)
+    auto enter_chunk = [&](int qn) {                         // the read-ahead moves into chunk qn
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (RING - 3)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_begin(qn + RING - 2);                          // its pieces ride between the MFMAs of the next k-steps
+        if (!(DVQ_GEMM_ABL & 1)) issue_piece(0);
+        rd_base = lds_lane + (unsigned)((qn & (RING - 1)) * CHB);
+    };
+    __builtin_amdgcn_s_barrier();                            // everybody's pieces of the first chunks (and PB) are in LDS
+    asm volatile("" ::: "memory");
+    if (!(DVQ_GEMM_ABL & 1)) issue(RING - 2);
+    rd_base = lds_lane;
+    GG_RD(0, 0); GG_RD(1, 1); GG_RD(2, 2); GG_RD(3, 3);
+    for (int i = 0; i < nmine; ++i) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int sk = 0; sk < S; ++sk) {
+            // read-ahead: k-step sk + 4 of this block = k-step (sk + 4) % S of block i or i + 1
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int u = sk + 4;                            // compile-time after unrolling
+            // four pairs (k-steps sk .. sk + 3) are in flight: the oldest has landed when at most six reads are outstanding
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[sk & 3]), "+v"(bl[sk & 3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(DVQ_GEMM_ABL & 2)) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sk], bh[sk & 3], acc, 0, 0, 0);     // small terms first
+                __builtin_amdgcn_sched_barrier(0);
+                // one ring piece per k-step, behind an MFMA that keeps the pipe busy while the DMA instruction issues
+                if (u % CH > 0 && u % CH < PPW && !(DVQ_GEMM_ABL & 1)) issue_piece(u % CH);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bl[sk & 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bh[sk & 3], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // k-step sk + 4 takes over the pair's registers (an output of these reads must always have a later use -- here the
+            // counted wait four k-steps on, at the end of a block the drain below: hipcc reuses the registers of a dead asm
+            // output while the read is still in flight)
+            if (u % CH == 0) enter_chunk(i * NCH + u / CH);  // (past the last chunk: the ring repeats the last one)
+            GG_RD(u, u % CH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DVQ_GEMM_ABL & 4) { if (acc[0] == 12345.678f) part[0] = acc[1]; continue; }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]),
+                     "+v"(bh[3]), "+v"(bl[3]) :: "memory");  // the next block's first four pairs: landed before other LDS traffic
+        // epilogue: bias, activation, contraction with the output layer (register r of lane half h = hidden row
+        // (r & 3) + 8 (r >> 2) + 4 h of the tile, cell c).  SiLU = y / (1 + 2^(-y log2 e)) on v_exp_f32 / v_rcp_f32 (~2 ulp; the
+        // logits' tolerance is 1e-4): the IEEE division sequence and a branch per element were a quarter of the kernel
+        float pt[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) pt[g] = 0.0f;
+        auto contract = [&](auto silu_tag) {
+            constexpr bool SILU = decltype(silu_tag)::value;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 bb = *(const f32x4 *)(pb + 8 * q4 + 4 * h);
+                f32x4 ww[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) ww[g] = *(const f32x4 *)(pb + (1 + g) * 32 + 8 * q4 + 4 * h);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float yv = acc[4 * q4 + r4] * inv_scale + bb[r4];
+                    const float hv = SILU ? yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * yv))
+                                          : (yv > 0.0f ? yv : 0.0f);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) pt[g] = __builtin_fmaf(ww[g][r4], hv, pt[g]);
+                }
+            }
+        };
+        if (act == 1) contract(std::true_type{});
+        else contract(std::false_type{});
+        // every wave (row tile) writes its own slice part[4 hg + wave][cell][g]: no workgroup barrier in the epilogue; the
+        // finalize kernel adds the slices in a fixed order
+        {
+            const long cgl = ((long)blockIdx.x + (long)i * gridDim.x) * 32 + c;
+            float *po = part + ((size_t)(hg * 4 + wave) * ncell + cgl) * G;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float v = pt[g] + __shfl_xor(pt[g], 32);
+                if (h == 0 && cgl < ncell) po[g] = v;
+            }
+        }
+    }
+    (void)red;
+#undef GG_RD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // surplus ring DMA
+}
+
+// gate[cell][g] = b2[g] + the row tiles' partial logits in tile order (slices past the hidden layer's last tile hold zeros)
+__global__ __launch_bounds__(256) void gate_finalize_kernel(const float *__restrict__ part, int HG, long n, int G,
+                                                            const float *__restrict__ b2, float *__restrict__ gate)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.0f;
+    for (int h0 = 0; h0 < HG; h0 += 8) {                     // eight independent loads at a time, added in slice order
+        float pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = (h0 + k < HG) ? part[(size_t)(h0 + k) * n + i] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += pv[k];
+    }
+    gate[i] = v + b2[i % G];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -489,11 +749,24 @@ static size_t gate_img_bytes(int nb, int C, int Hid)
     return align256r((size_t)((Hid + 31) / 32) * 32 * Fp * 2 * sizeof(_Float16));
 }
 size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid) { return gate_img_bytes(nb, C, Hid) + 256; }
+// the GEMM form: feature images (as many bytes as the pooled averages they replace, rounded up to whole 32-cell blocks) and the
+// hidden groups' partial logits
+static size_t gate_ximg_bytes(int nb, int B, int C, int hc, int wc)
+{
+    const size_t nblocks = ((size_t)B * hc * wc + 31) / 32;
+    return align256r(nblocks * (size_t)((nb * C + 15) / 16) * 2048);
+}
+static size_t gate_part_bytes(int nb, int B, int hc, int wc, int Hid)
+{
+    return align256r((size_t)((Hid + 127) / 128) * 4 * B * hc * wc * nb * sizeof(float));       // one slice per row tile
+}
 size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid)
 {
     (void)groups;
-    return align256r((size_t)B * nb * C * sizeof(float2)) +
-           align256r((size_t)B * nb * C * hc * wc * sizeof(float)) + gate_img_bytes(nb, C, Hid) + 256;
+    const size_t pool = align256r((size_t)B * nb * C * hc * wc * sizeof(float));
+    const size_t ximg = gate_ximg_bytes(nb, B, C, hc, wc);
+    return align256r((size_t)B * nb * C * sizeof(float2)) + (pool > ximg ? pool : ximg) + gate_img_bytes(nb, C, Hid) +
+           gate_part_bytes(nb, B, hc, wc, Hid) + 512;
 }
 
 // hidden-layer weight -> split fp16 tile images (kept by the caller across calls while the weight is unchanged)
@@ -532,16 +805,78 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     const int F = nb * C, Fp = (F + 15) & ~15;
     float2 *stats = (float2 *)ws;                            // (scale, shift) per (image, feature)
     float *pool = (float *)((char *)ws + align256r((size_t)B * F * sizeof(float2)));
+    // ws: [folded GroupNorm affine][pooled averages (direct form) OR feature images (GEMM form)][W1 images, when the caller
+    //      passes none][partial logits of the GEMM form][its scale word]
+    const long ncell = (long)B * hc * wc;
+    const size_t pool_area = align256r((size_t)B * F * hc * wc * sizeof(float));
+    const size_t ximg_area = gate_ximg_bytes(nb, B, C, hc, wc);
+    char *after = (char *)pool + (pool_area > ximg_area ? pool_area : ximg_area);
     const _Float16 *imgH = (const _Float16 *)w1_prep;
     if (act != 0 && imgH == nullptr) {
-        void *own = (char *)pool + align256r((size_t)B * F * hc * wc * sizeof(float));
-        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, own, st);
+        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, after, st);
         if (rc) return rc;
-        imgH = (const _Float16 *)own;
+        imgH = (const _Float16 *)after;
     }
     const _Float16 *imgL = imgH ? imgH + (size_t)((Hid + 31) / 32) * 32 * Fp : nullptr;
-    hipLaunchKernelGGL(gate_pool_kernel, dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool);
-    const long ncell = (long)B * hc * wc;
+    // the GEMM form (gate_gemm_kernel): a hidden layer with GroupNorm'd inputs whose groups are whole octets of channels that fit the
+    // pooling workgroup's LDS, F a multiple of 16 with an instantiated number of k-steps
+    const int cpg = groups > 0 ? C / groups : 0;
+    const int S16 = F / 16;
+    const bool gemm_form = act != 0 && groups > 0 && cpg % 8 == 0 && cpg <= 64 && (size_t)nb * cpg * hc * wc * 4 <= 48 * 1024 &&
+                           F % 16 == 0 && (S16 == 8 || S16 == 12 || S16 == 16 || S16 == 24 || S16 == 32 || S16 == 48);
+    if (gemm_form) {
+        char *ximg = (char *)pool;
+        const _Float16 *imgLg = imgL;
+        float *part = (float *)(after + gate_img_bytes(nb, C, Hid));
+        float *xs = (float *)((char *)part + gate_part_bytes(nb, B, hc, wc, Hid));
+        const int nblocks = (int)((ncell + 31) / 32);
+        if ((ncell & 31) != 0)                               // the last block's unused cell columns must hold finite values
+            (void)hipMemsetAsync(ximg + (size_t)(nblocks - 1) * S16 * 2048, 0, (size_t)S16 * 2048, st);
+        hipLaunchKernelGGL(gate_pool_kernel<true>, dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
+                           stats, pool, ximg, xs);
+        int ncu = 256;
+        {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            ncu = n > 0 ? n : 256;
+        }
+        const int HG = (Hid + 127) / 128;
+        int CG = ncu / HG;
+        if (CG < 1) CG = 1;
+        if (CG > nblocks) CG = nblocks;
+#define DVQ_GEMM_LAUNCH(GG, SS)                                                                                        \
+        do {                                                                                                           \
+            static unsigned long long done_ = 0;                                                                       \
+            constexpr int CHB_ = ((SS % 8 == 0) ? 8 : 4) * 2048;                                                       \
+            const size_t shm = 8 * (size_t)CHB_ + (4 * (1 + GG) * 32 + 4 * GG * 32) * sizeof(float);                   \
+            int rc = dvq_allow_dynamic_lds((const void *)gate_gemm_kernel<GG, SS>, (int)shm, &done_);                  \
+            if (rc) return rc;                                                                                         \
+            hipLaunchKernelGGL((gate_gemm_kernel<GG, SS>), dim3(CG, HG), dim3(256), shm, st, ximg, imgH, imgLg, b1, W2, \
+                               Hid, act, ncell, nblocks, xs, part);                                                    \
+        } while (0)
+        if (nb == 2) {
+            switch (S16) {
+            case 8:  DVQ_GEMM_LAUNCH(2, 8); break;
+            case 16: DVQ_GEMM_LAUNCH(2, 16); break;
+            case 24: DVQ_GEMM_LAUNCH(2, 24); break;
+            case 32: DVQ_GEMM_LAUNCH(2, 32); break;
+            default: return -1000;
+            }
+        } else {
+            switch (S16) {
+            case 12: DVQ_GEMM_LAUNCH(3, 12); break;
+            case 24: DVQ_GEMM_LAUNCH(3, 24); break;
+            case 48: DVQ_GEMM_LAUNCH(3, 48); break;
+            default: return -1000;
+            }
+        }
+#undef DVQ_GEMM_LAUNCH
+        const long nout = ncell * nb;
+        hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, part, HG * 4, nout, nb, b2, gate);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(gate_pool_kernel<false>, dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
+                       nullptr, nullptr);
     // two blocks of 32 cells per workgroup when the split tile of 64 cells fits the LDS and there are enough cells to keep
     // every CU busy that way
     const size_t shmem2 = ((size_t)2 * 32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);
