@@ -644,46 +644,93 @@ __global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
     if (!(DVQ_GEMM_ABL & 1)) issue(RING - 2);
     rd_base = lds_lane;
     GG_RD(0, 0); GG_RD(1, 1); GG_RD(2, 2); GG_RD(3, 3);
-    for (int i = 0; i < nmine; ++i) {
-        f32x16 acc;
+    // Epilogue of a cell block = bias, activation, contraction with the output layer: register r of lane half h is hidden row
+    // (r & 3) + 8 (r >> 2) + 4 h of the tile, cell c.  SiLU = y / (1 + 2^(-y log2 e)) on v_exp_f32 / v_rcp_f32 (~2 ulp; the logits'
+    // tolerance is 1e-4): the IEEE division sequence and a branch per element were a quarter of the kernel.  PIPE (dual router,
+    // >= 20 k-steps): the ~150 vector instructions of block i's epilogue ride in the MFMA shadows of block i + 1's first 17
+    // k-steps, one accumulator row per k-step, with the bias / output-layer rows resident in registers (a lone wave per SIMD
+    // has nothing else to fill the matrix pipe with meanwhile: 0.6 us per block otherwise).
+    constexpr bool PIPE = (G == 2) && (S >= 20);
+    float cb[16], cw[G][16];
+    if (PIPE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+            cb[r] = pb[j];
 #pragma unroll
-        for (int sk = 0; sk < S; ++sk) {
-            // read-ahead: k-step sk + 4 of this block = k-step (sk + 4) % S of block i or i + 1
-            constexpr int dummy_ = 0; (void)dummy_;
-            const int u = sk + 4;                            // compile-time after unrolling
-            // four pairs (k-steps sk .. sk + 3) are in flight: the oldest has landed when at most six reads are outstanding
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[sk & 3]), "+v"(bl[sk & 3]) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(DVQ_GEMM_ABL & 2)) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sk], bh[sk & 3], acc, 0, 0, 0);     // small terms first
-                __builtin_amdgcn_sched_barrier(0);
-                // one ring piece per k-step, behind an MFMA that keeps the pipe busy while the DMA instruction issues
-                if (u % CH > 0 && u % CH < PPW && !(DVQ_GEMM_ABL & 1)) issue_piece(u % CH);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bl[sk & 3], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bh[sk & 3], acc, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // k-step sk + 4 takes over the pair's registers (an output of these reads must always have a later use -- here the
-            // counted wait four k-steps on, at the end of a block the drain below: hipcc reuses the registers of a dead asm
-            // output while the read is still in flight)
-            if (u % CH == 0) enter_chunk(i * NCH + u / CH);  // (past the last chunk: the ring repeats the last one)
-            GG_RD(u, u % CH);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < G; ++g) cw[g][r] = pb[(1 + g) * 32 + j];
         }
-        if (DVQ_GEMM_ABL & 4) { if (acc[0] == 12345.678f) part[0] = acc[1]; continue; }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]),
-                     "+v"(bh[3]), "+v"(bl[3]) :: "memory");  // the next block's first four pairs: landed before other LDS traffic
-        // epilogue: bias, activation, contraction with the output layer (register r of lane half h = hidden row
-        // (r & 3) + 8 (r >> 2) + 4 h of the tile, cell c).  SiLU = y / (1 + 2^(-y log2 e)) on v_exp_f32 / v_rcp_f32 (~2 ulp; the
-        // logits' tolerance is 1e-4): the IEEE division sequence and a branch per element were a quarter of the kernel
-        float pt[G];
+    }
+    auto store_part = [&](int ib, const float (&pt)[G]) {    // this wave's (row tile's) slice part[4 hg + wave][cell][g]: no workgroup
+        const long cgl = ((long)blockIdx.x + (long)ib * gridDim.x) * 32 + c;      // barrier; gate_finalize_kernel adds the slices in order
+        float *po = part + ((size_t)(hg * 4 + wave) * ncell + cgl) * G;
 #pragma unroll
-        for (int g = 0; g < G; ++g) pt[g] = 0.0f;
-        auto contract = [&](auto silu_tag) {
-            constexpr bool SILU = decltype(silu_tag)::value;
+        for (int g = 0; g < G; ++g) {
+            const float v = pt[g] + __shfl_xor(pt[g], 32);
+            if (h == 0 && cgl < ncell) po[g] = v;
+        }
+    };
+    auto run = [&](auto silu_tag) {
+        constexpr bool SILU = decltype(silu_tag)::value;
+        auto activ = [&](float yv) -> float {
+            return SILU ? yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * yv)) : (yv > 0.0f ? yv : 0.0f);
+        };
+        f32x16 accp;                                         // PIPE: the previous block's accumulators
+        float ptp[G];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ptp[g] = 0.0f;
+        auto epi_row = [&](int r) {
+            const float hv = activ(__builtin_fmaf(accp[r], inv_scale, cb[r]));
+#pragma unroll
+            for (int g = 0; g < G; ++g) ptp[g] = __builtin_fmaf(cw[g][r], hv, ptp[g]);
+        };
+        auto block = [&](int i, auto prev_tag) {
+            constexpr bool PREV = decltype(prev_tag)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int sk = 0; sk < S; ++sk) {
+                const int u = sk + 4;                        // read-ahead: k-step sk + 4 of this block = k-step (sk + 4) % S of block i or i + 1
+                // four pairs (k-steps sk .. sk + 3) are in flight: the oldest has landed when at most six reads are outstanding
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[sk & 3]), "+v"(bl[sk & 3]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(DVQ_GEMM_ABL & 2)) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sk], bh[sk & 3], acc, 0, 0, 0);     // small terms first
+                    __builtin_amdgcn_sched_barrier(0);
+                    // one ring piece per k-step, behind an MFMA that keeps the pipe busy while the DMA instruction issues
+                    if (u % CH > 0 && u % CH < PPW && !(DVQ_GEMM_ABL & 1)) issue_piece(u % CH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bl[sk & 3], acc, 0, 0, 0);
+                    if (PIPE && PREV && sk < 16 && !(DVQ_GEMM_ABL & 4)) { __builtin_amdgcn_sched_barrier(0); epi_row(sk); __builtin_amdgcn_sched_barrier(0); }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bh[sk & 3], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE && PREV && sk == 16 && !(DVQ_GEMM_ABL & 4)) {
+                    store_part(i - 1, ptp);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) ptp[g] = 0.0f;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // k-step sk + 4 takes over the pair's registers (an output of these reads must always have a later use -- here
+                // the counted wait four k-steps on, at the end of a block the drain below: hipcc reuses the registers of a dead
+                // asm output while the read is still in flight)
+                if (u % CH == 0) enter_chunk(i * NCH + u / CH);  // (past the last chunk: the ring repeats the last one)
+                GG_RD(u, u % CH);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DVQ_GEMM_ABL & 4) { if (acc[0] == 12345.678f) part[0] = acc[1]; return; }
+            if (PIPE) {
+                accp = acc;                                  // consumed during the next block (or after the loop)
+                return;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]),
+                         "+v"(bh[3]), "+v"(bl[3]) :: "memory");  // the next block's first four pairs: landed before other LDS traffic
+            float pt[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) pt[g] = 0.0f;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const f32x4 bb = *(const f32x4 *)(pb + 8 * q4 + 4 * h);
@@ -692,26 +739,83 @@ __global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
                 for (int g = 0; g < G; ++g) ww[g] = *(const f32x4 *)(pb + (1 + g) * 32 + 8 * q4 + 4 * h);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float yv = acc[4 * q4 + r4] * inv_scale + bb[r4];
-                    const float hv = SILU ? yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * yv))
-                                          : (yv > 0.0f ? yv : 0.0f);
+                    const float hv = activ(acc[4 * q4 + r4] * inv_scale + bb[r4]);
 #pragma unroll
                     for (int g = 0; g < G; ++g) pt[g] = __builtin_fmaf(ww[g][r4], hv, pt[g]);
                 }
             }
+            store_part(i, pt);
         };
-        if (act == 1) contract(std::true_type{});
-        else contract(std::false_type{});
-        // every wave (row tile) writes its own slice part[4 hg + wave][cell][g]: no workgroup barrier in the epilogue; the
-        // finalize kernel adds the slices in a fixed order
-        {
-            const long cgl = ((long)blockIdx.x + (long)i * gridDim.x) * 32 + c;
-            float *po = part + ((size_t)(hg * 4 + wave) * ncell + cgl) * G;
+        if constexpr (PIPE) {
+            block(0, std::false_type{});
+            for (int i = 1; i < nmine; ++i) block(i, std::true_type{});
+        } else {
+            for (int i = 0; i < nmine; ++i) block(i, std::false_type{});
+        }
+        // drain the read-ahead (its last four pairs are never consumed) and, PIPE, the last block's epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]),
+                     "+v"(bh[3]), "+v"(bl[3]) :: "memory");
+        if (PIPE && !(DVQ_GEMM_ABL & 4)) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float v = pt[g] + __shfl_xor(pt[g], 32);
-                if (h == 0 && cgl < ncell) po[g] = v;
+            for (int r = 0; r < 16; ++r) epi_row(r);
+            store_part(nmine - 1, ptp);
+        }
+    };
+    if constexpr (PIPE) {
+        if (act == 1) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+        // one copy of the k-loop (the triple router's 384 fragment registers leave no room for a second live one); the
+        // activation is chosen inside the epilogue
+        for (int i = 0; i < nmine; ++i) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int sk = 0; sk < S; ++sk) {
+                const int u = sk + 4;
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[sk & 3]), "+v"(bl[sk & 3]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(DVQ_GEMM_ABL & 2)) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sk], bh[sk & 3], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u % CH > 0 && u % CH < PPW && !(DVQ_GEMM_ABL & 1)) issue_piece(u % CH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bl[sk & 3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sk], bh[sk & 3], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u % CH == 0) enter_chunk(i * NCH + u / CH);
+                GG_RD(u, u % CH);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (DVQ_GEMM_ABL & 4) { if (acc[0] == 12345.678f) part[0] = acc[1]; continue; }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]),
+                         "+v"(bh[3]), "+v"(bl[3]) :: "memory");
+            float pt[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) pt[g] = 0.0f;
+            auto contract = [&](auto silu_tag) {
+                constexpr bool SILU = decltype(silu_tag)::value;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bb = *(const f32x4 *)(pb + 8 * q4 + 4 * h);
+                    f32x4 ww[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) ww[g] = *(const f32x4 *)(pb + (1 + g) * 32 + 8 * q4 + 4 * h);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float yv = acc[4 * q4 + r4] * inv_scale + bb[r4];
+                        const float hv = SILU ? yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * yv))
+                                              : (yv > 0.0f ? yv : 0.0f);
+#pragma unroll
+                        for (int g = 0; g < G; ++g) pt[g] = __builtin_fmaf(ww[g][r4], hv, pt[g]);
+                    }
+                }
+            };
+            if (act == 1) contract(std::true_type{});
+            else contract(std::false_type{});
+            store_part(i, pt);
         }
     }
     (void)red;
@@ -726,12 +830,12 @@ __global__ __launch_bounds__(256) void gate_finalize_kernel(const float *__restr
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float v = 0.0f;
-    for (int h0 = 0; h0 < HG; h0 += 8) {                     // eight independent loads at a time, added in slice order
-        float pv[8];
+    for (int h0 = 0; h0 < HG; h0 += 24) {                    // 24 independent loads at a time (dual 16 slices, triple 24: ONE round
+        float pv[24];                                        // trip to the memory the other XCDs' workgroups wrote), added in slice order
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pv[k] = (h0 + k < HG) ? part[(size_t)(h0 + k) * n + i] : 0.0f;
+        for (int k = 0; k < 24; ++k) pv[k] = (h0 + k < HG) ? part[(size_t)(h0 + k) * n + i] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += pv[k];
+        for (int k = 0; k < 24; ++k) v += pv[k];
     }
     gate[i] = v + b2[i % G];
 }
