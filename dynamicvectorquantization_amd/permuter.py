@@ -55,8 +55,10 @@ class DualGrainSeperatePermuter(nn.Module):
     def forward(self, indices, grain_indices, max_len=None, out=None):
         """max_len = (Lc, Lf): pad to these lengths (>= the batch maxima + 1; `max_lengths()` always suffices) instead of
         reading the batch maxima back -- the extra columns hold PAD, exactly what pad_sequence would put there in a longer
-        batch.  out: six preallocated [B, Lc] / [B, Lf] int64 tensors in the order coarse content / position / segment,
-        fine content / position / segment (benchmark / graph capture)."""
+        batch.  The lengths are the CALLER's promise (checking them would need the host round trip this argument exists to avoid):
+        entries that do not fit are dropped by the kernel, EOS included; lengths below 1 are rejected.
+        out: six preallocated contiguous int64 [B, Lc] / [B, Lf] tensors on the inputs' device, in the order coarse content /
+        position / segment, fine content / position / segment (benchmark / graph capture)."""
         indices = _i64_cuda(indices, "indices")
         grain = _i64_cuda(grain_indices, "grain_indices")
         B = indices.shape[0]
@@ -69,6 +71,8 @@ class DualGrainSeperatePermuter(nn.Module):
             st = _lib.stream_ptr(dev)
             if max_len is not None:
                 Lc, Lf = int(max_len[0]), int(max_len[1])
+                if Lc < 1 or Lf < 1:
+                    raise ValueError("max_len must be at least (1, 1), got %s" % (tuple(max_len),))
             else:
                 counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
                 maxes = torch.empty(2, dtype=torch.int32, device=dev)
@@ -78,8 +82,9 @@ class DualGrainSeperatePermuter(nn.Module):
                 Lc, Lf = mc + 1, 4 * mf + 1
             if out is not None:
                 outs = list(out)
-                if [tuple(o.shape) for o in outs] != [(B, Lc)] * 3 + [(B, Lf)] * 3:
-                    raise ValueError("out tensors must be 3 x [B, Lc] and 3 x [B, Lf] int64")
+                if [tuple(o.shape) for o in outs] != [(B, Lc)] * 3 + [(B, Lf)] * 3 or \
+                        any(o.dtype != torch.int64 or o.device != dev or not o.is_contiguous() for o in outs):
+                    raise ValueError("out tensors must be 3 x [B, Lc] and 3 x [B, Lf], contiguous int64 on %s" % dev)
             else:
                 outs = [torch.empty((B, Lc), dtype=torch.int64, device=dev) for _ in range(3)] + \
                        [torch.empty((B, Lf), dtype=torch.int64, device=dev) for _ in range(3)]

@@ -25,6 +25,7 @@ class _ConvPrep:
 
     def __init__(self):
         self.key, self.buf = None, None
+        self._retired = []                   # replaced image buffers other streams may still be reading
         self._built = None                   # (stream handle, event) of the last build: other streams wait for it once
 
     def get(self, conv):
@@ -36,8 +37,11 @@ class _ConvPrep:
             nbytes = _lib_handle.dvq_qconv_prep_bytes(D)
             if nbytes == 0:
                 raise _lib.DvqError("quant_conv: unsupported channel count %d" % D)
-            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != w.device:
-                self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            # a FRESH buffer per rebuild: streams that still have kernels queued against the old images keep reading the old buffer
+            # (kept alive here until two more rebuilds have happened)
+            if self.buf is not None:
+                self._retired = (self._retired + [self.buf])[-2:]
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             w2 = _lib.require_cuda_f32(w.detach().reshape(D, D), "quant_conv.weight")
             b2 = None if bias is None else _lib.require_cuda_f32(bias.detach(), "quant_conv.bias")
             with torch.cuda.device(w.device):

@@ -52,6 +52,7 @@ class _CodebookPrep:
 
     def invalidate(self):
         self.key = None
+        self._hbuf.clear()       # the [B, D, *spatial] scratch tensors of the fused-conv ops (one per shape and stream) are re-made on demand
 
     def get(self, codebook):
         K, D = codebook.shape
@@ -149,8 +150,10 @@ class _CodebookPrep:
         return ws
 
     def h_scratch(self, shape, device):
-        """[B, D, *spatial] f32 buffer of the ops with the quant_conv fused in, PER STREAM like the workspaces (pass 1 writes the
-        conv output of its exact-list tokens there and the list kernel of the same op reads them back)"""
+        """[B, D, *spatial] f32 buffer of the ops with the quant_conv fused in, PER STREAM like the workspaces (pass 1 and the
+        resolver write the conv output of their exact-list tokens there and the list kernel of the same op reads them back).
+        Memory: a full feature map per (shape, stream) -- 256 MiB at B = 256 on a 32 x 32 grid -- of which a handful of rows
+        is ever touched; at most 8 are cached and `invalidate()` frees them.  The fold form (fold=True) needs none."""
         key = (tuple(shape), device, _lib.stream_ptr(device))
         hb = self._hbuf.get(key)
         if hb is None:
@@ -460,8 +463,14 @@ class _VQStraightThrough(torch.autograd.Function):
         if prep.track_users:
             prep.used(z.device)
         need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if need_z or need_w:
-            ctx.save_for_backward(z, codebook.detach().clone(), mask, codes)      # forward-time codebook
+        # forward-time codebook: a [K, D] snapshot -- or, when the call has fewer tokens than the codebook has codes and no
+        # codebook gradient is wanted (the items of VectorQuantize2List: one snapshot per item would be 16 MiB each at K = 16384),
+        # just the rows the tokens chose, addressed in backward by position
+        ctx.compact = bool((need_z and not need_w) and codes.numel() < K and z.is_cuda)
+        if ctx.compact:
+            ctx.save_for_backward(z, embed_gather(codebook.detach(), codes.reshape(-1)), mask, codes)
+        elif need_z or need_w:
+            ctx.save_for_backward(z, codebook.detach().clone(), mask, codes)
         ctx.wshape, ctx.coef_z, ctx.coef_e = tuple(weight.shape), coef_z, coef_e
         ctx.mark_non_differentiable(codes)
         return zq, loss[1], codes
@@ -469,6 +478,8 @@ class _VQStraightThrough(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zq, g_loss, _g_codes):
         z, snap, mask, codes = ctx.saved_tensors
+        if ctx.compact:                                   # snap = the chosen rows [N, D]: token n's row is row n
+            codes = torch.arange(codes.numel(), dtype=torch.int64, device=codes.device).reshape(codes.shape)
         B, D = z.shape[0], z.shape[1]
         need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         scale = 2.0 / z.numel()

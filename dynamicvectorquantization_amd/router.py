@@ -240,6 +240,7 @@ class _GateWeightPrep:
     def __init__(self):
         self.key = None
         self.buf = None
+        self._retired = []
         self._built = None                   # (stream handle, event) of the last build: other streams wait for it once
 
     def invalidate(self):
@@ -252,8 +253,11 @@ class _GateWeightPrep:
             nbytes = _lib_handle.dvq_router_gate_prep_bytes(nb, C, hidden)
             if nbytes == 0:
                 raise _lib.DvqError("unsupported gate shape nb=%d C=%d hidden=%d" % (nb, C, hidden))
-            if self.buf is None or self.buf.numel() < nbytes or self.buf.device != w1.device:
-                self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+            # a FRESH buffer per rebuild (other streams may still have kernels queued against the old images; the last two
+            # replaced buffers are kept alive)
+            if self.buf is not None:
+                self._retired = (self._retired + [self.buf])[-2:]
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
             with torch.cuda.device(w1.device):
                 _lib.check(_lib_handle.dvq_router_gate_prepare_f32(
                     w1.data_ptr(), nb, C, hidden, self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
