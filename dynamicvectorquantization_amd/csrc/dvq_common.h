@@ -108,8 +108,7 @@ struct DvqLossTail {
 };
 #define DVQ_QSHARDS 64        // the pass-1 -> resolver queue is sharded this many ways (power of two)
 #define DVQ_QCOUNT0 8         // counters[DVQ_QCOUNT0 + shard] = tokens queued in that shard
-#define DVQ_LOCK0 128          // counters[DVQ_LOCK0 + slot]: anti-phase lock word of one CU, slot = XCC_ID << 8 | HW_ID[15:8]
-#define DVQ_COUNTER_BYTES (512 + 2048 * 4)
+#define DVQ_COUNTER_BYTES 512
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
 // Kernels with more than 64 KiB of dynamic LDS need the per-device opt-in once; `done` is the caller's

@@ -43,16 +43,9 @@
 #ifndef DVQ_WIDE_MIN_K
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
-#ifndef DVQ_DMA_EARLY
-#define DVQ_DMA_EARLY 0          // 1: the next ring tile's DMA pieces are issued in one run before the MFMA chain instead of between its MFMAs
-#endif
-#ifndef DVQ_ABLATE
-#define DVQ_ABLATE 0             // timing experiments of the tuning build only (results are WRONG): 1 no top-2 update, 2 no ring DMA in the
-#endif                           // loop, 4 no per-tile barrier, 8 no MFMAs, 16 no A-fragment reads, 32 no seed reads; conv prologue: 64 no x loads,
-                                 // 128 no weight DMA, 256 no weight-fragment reads, 512 no barrier, 1024 no hi / lo conversion, 2048 no MFMAs
-#ifndef DVQ_LOCK_MAX_SPINS
-#define DVQ_LOCK_MAX_SPINS 4000  // anti-phase lock: give up waiting after about 3 ms
-#endif
+// (Round 3's timing-only ablation switches, the per-CU anti-phase lock, the early-DMA variant and the per-workgroup clock stamps
+// left this file in round 4: their results are in profiles/r03_pass1_*.json and DESIGN.md section 5.1, the code in git history
+// up to commit "Feature-router gate as a tiled GEMM".)
 
 // ---------------------------------------------------------------------------------------------
 // prep: meta (scale, norm maxima, finiteness), fp16 tile images, rounding-residual norm
@@ -251,22 +244,10 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 //       workgroup-rare event), so no second pass over x is needed.
 // ---------------------------------------------------------------------------------------------
 #ifdef DVQ_TUNING
-// diagnostics of the tuning build only: per-workgroup clock stamps around the code loop (s_memtime / s_memrealtime,
-// MI355X guide "DVFS give-back" item 6) and per-token (best, second, 2W, code) of the production arithmetic for the
-// bound audit.  Written to buffers of their own; no output value is computed from them.
-__device__ unsigned long long *g_dvq_stamps = nullptr;     // [grid][8]: CU slot, realtime at entry / before the lock / loop start, cycles at loop
-                                                           // start, realtime / cycles at loop end, realtime at exit (100 MHz / shader clock)
+// diagnostic of the tuning build only: per-token (best, second, 2W, code) of the production arithmetic for the bound audit
+// (tools/bound_audit.py --production).  Written to a buffer of its own; no output value is computed from it.
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
 #endif
-
-__device__ __forceinline__ int dvq_cu_slot()
-{
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    // HW_ID[15:8] = {se_id, sh_id, cu_id}; XCC_ID[3:0]
-    return (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu));
-}
 
 template <int D, int SEL, bool CONV, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
@@ -274,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, int *__restrict__ cu_lock, const DvqConv cv)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
@@ -296,10 +277,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
     char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;   // this wave's permutation scratch
-#ifdef DVQ_TUNING
-    unsigned long long st_entry = 0, st_pro = 0, st_r0 = 0, st_c0 = 0;
-    if (g_dvq_stamps != nullptr && tid == 0) st_entry = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // DMA of code tile t into its ring slot, in PER_TILE pieces (q < CPW: 1 KiB of the image, q == CPW:
     // this wave's copy of the seeds).  Past the end: harmless repeat, so the counts stay constant.
@@ -354,15 +331,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         const float *xp = zp;
         auto issue_group = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < ((DVQ_ABLATE & 128) ? 0 : 4); ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const int i = 4 * wave + q;                  // piece: row tile i >> 1, hi / lo i & 1
                 glds16(cv.wimg + (size_t)(i >> 1) * QTILE + (i & 1) * QIMG + k * 1024 + lane * 16,
                        lds + (k & 3) * IMG_BYTES + i * 1024);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (DVQ_ABLATE & 64) asm volatile("v_mov_b32 %0, 0" : "=v"(xr[k % 3][j]) :: "memory");
-                else asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
+                asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
                 xp += st;
             }
             xp += 8 * st;                                    // the other lane half's 8 channels
@@ -378,23 +354,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             for (int r = 0; r < 16; ++r) acc[t8][r] = 0.0f;
         int ea = 100;                                        // x is scaled by 2^ea (per token; both lane halves agree)
         float sa = ldexpf(1.0f, 100);
-#ifdef DVQ_TUNING
-        unsigned tc_wait = 0, tc_bar = 0;
-        const unsigned tc_begin = (unsigned)__builtin_readcyclecounter();
-#define DVQ_TC(ACC, STMT) do { const unsigned t0_ = (unsigned)__builtin_readcyclecounter(); STMT; ACC += (unsigned)__builtin_readcyclecounter() - t0_; } while (0)
-#else
-#define DVQ_TC(ACC, STMT) do { STMT; } while (0)
-#endif
         // group g has landed for this wave when at most the (up to two) younger groups are outstanding; its 8 values are scaled
         // and split into the hi / lo B fragments.  The scale follows the running maximum: a value that would reach 2^15 after
         // scaling moves it (exact rescale of the accumulators by a power of two; wave-uniform branch, rare after the first
         // k-steps).
         f16x8 xh, xl;
         auto take_group = [&](int g) __attribute__((always_inline)) {
-            DVQ_TC(tc_wait, {
             if (g <= S16 - 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else if (g == S16 - 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); });
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(xr[g % 3][j])); xv[j] = xr[g % 3][j]; }
@@ -420,10 +388,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 sa = ldexpf(1.0f, ea);
             }
             u32x4 ph, pl;
-            if (DVQ_ABLATE & 1024) {
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) { ph[j2] = __float_as_uint(xv[2 * j2]); pl[j2] = __float_as_uint(xv[2 * j2 + 1]); }
-            } else {
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
                 const float v0 = xv[2 * j2] * sa, v1 = xv[2 * j2 + 1] * sa;
@@ -434,27 +398,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                 ph[j2] = __builtin_bit_cast(unsigned, hh);
                 pl[j2] = __builtin_bit_cast(unsigned, ll);
             }
-            }
             xh = __builtin_bit_cast(f16x8, ph);
             xl = __builtin_bit_cast(f16x8, pl);
         };
         take_group(0);
 #pragma unroll
         for (int s = 0; s < S16; ++s) {
-            if (!(DVQ_ABLATE & 512)) DVQ_TC(tc_bar, { __builtin_amdgcn_s_barrier(); });   // k-step s of the weights landed (everybody's pieces); s - 1 consumed
+            __builtin_amdgcn_s_barrier();                    // k-step s of the weights landed (everybody's pieces); s - 1 consumed
             asm volatile("" ::: "memory");
             if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers already converted
             const char *buf = lds + (s & 3) * IMG_BYTES;
             const f16x8 bh = xh, bl = xl;
 #pragma unroll
             for (int t8 = 0; t8 < 8; ++t8) {
-                f16x8 ah, al;
-                if (DVQ_ABLATE & 256) { ah = bh; al = bl; }
-                else {
-                    ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
-                    al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
-                }
-                if (DVQ_ABLATE & 2048) { asm volatile("" : "+v"(acc[t8]) : "v"(ah), "v"(al), "v"(bh), "v"(bl)); continue; }
+                const f16x8 ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
+                const f16x8 al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t8], 0, 0, 0);
                 acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t8], 0, 0, 0);
@@ -462,13 +420,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             __builtin_amdgcn_sched_barrier(0);               // the MFMAs are issued; the next k-step's conversion runs under them
             if (s + 1 < S16) take_group(s + 1);
         }
-#ifdef DVQ_TUNING
-        if (g_dvq_tokdbg != nullptr && tid == 0) {           // cycles of this wave in the conv loop: total, in its counted waits, in its barriers
-            f32x4 dbg = {(float)((unsigned)__builtin_readcyclecounter() - tc_begin), (float)tc_wait, (float)tc_bar, 0.0f};
-            *(f32x4 *)(g_dvq_tokdbg + 4 * (size_t)blockIdx.x) = dbg;
-        }
-#endif
-#undef DVQ_TC
         const float unscale = ldexpf(cv.meta->inv_scale_w, -ea);
 #pragma unroll
         for (int s = 0; s < S16; ++s) {
@@ -669,27 +620,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         asm volatile("" ::: "memory");
     }
     for (int t = pre; t < 3; ++t) issue(t);                  // (SEL == 2) the code tiles that waited for those slots
-#ifdef DVQ_TUNING
-    if (g_dvq_stamps != nullptr && tid == 0) st_pro = __builtin_amdgcn_s_memrealtime();
-    // anti-phase experiment (tuning build only, measured and NOT adopted: profiles/r03_pass1_antiphase_ab.json): the two
-    // workgroups a CU holds take turns in the code loop through a lock word per CU.  A lone workgroup's loop takes as long
-    // as two sharing the matrix cores (the loop is bound by each wave's own instruction stream, not by the pipe), so
-    // serialising the loops only adds the lock wait.  (Lane 0 of wave 0 spins, bounded; the other waves wait at the
-    // loop's first barrier.)
-    int lock_slot = 0;
-    if (cu_lock != nullptr) {
-        lock_slot = dvq_cu_slot();
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_exchange(&cu_lock[lock_slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-                   spins < DVQ_LOCK_MAX_SPINS) {
-                __builtin_amdgcn_s_sleep(24);
-                ++spins;
-            }
-        }
-    }
-    if (g_dvq_stamps != nullptr && tid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
 
     // ---- 16x16x32 code loop: fragment F = c2 * S32 + s' of the tile feeds two MFMAs (token halves t2 = 0, 1);
     // accumulator acc16[c2][t2][i] = code 16 c2 + 4 (lane >> 4) + i against token 16 t2 + (lane & 15)
@@ -727,56 +657,36 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         };
     for (int t = 0; t < T; ++t) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // all but the youngest tile's DMA: tiles <= t + 1 landed
-            if (!(DVQ_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // tile t (everybody's DMA) landed; t-1 consumed
+            __builtin_amdgcn_s_barrier();                    // tile t (everybody's DMA) landed; t-1 consumed
             asm volatile("" ::: "memory");
-            if (S16 != 16 && !(DVQ_ABLATE & 2)) issue(t + 3);      // D = 256: pieces ride between the MFMAs below
+            if (S16 != 16) issue(t + 3);                     // D = 256: pieces ride between the MFMAs below
             // A fragments: hand-placed LDS reads, four k-steps ahead of the MFMA that consumes them
             // (ds_read returns in order: lgkmcnt(3) = "the oldest of my four reads has landed")
             const unsigned tile_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
                                         lds + (t & (NBUF - 1)) * IMG_BYTES + lane * 16);
             f16x8 a0, a1, a2, a3;
-#if DVQ_ABLATE & 16
-#define DVQ_RD(dst, S) asm volatile("" : "=v"(dst) : "v"(tile_a))
-#else
 #define DVQ_RD(dst, S) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(tile_a), "i"((S) * 1024))
-#endif
             DVQ_RD(a0, 0); DVQ_RD(a1, 1); DVQ_RD(a2, 2); DVQ_RD(a3, 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (t > 0 && !(DVQ_ABLATE & 1)) top2(t - 1);
+            if (t > 0) top2(t - 1);
             __builtin_amdgcn_sched_barrier(0);
             {
                 // accumulator seeds of tile t: this wave's own DMA copy (landed by the wait above), read behind the fragments
                 const unsigned seed_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(
                                             enraw + ((t & (NBUF - 1)) * NW + wave) * 64 + 4 * q16);
                 f32x4 e0, e1;
-#if DVQ_ABLATE & 32
-                asm volatile("" : "=v"(e0), "=v"(e1) : "v"(seed_a));
-#else
                 asm volatile("ds_read_b128 %0, %1" : "=v"(e0) : "v"(seed_a));
                 asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(e1) : "v"(seed_a));
-#endif
-#if DVQ_DMA_EARLY
-                if (S16 == 16 && !(DVQ_ABLATE & 2)) {
-#pragma unroll
-                    for (int q = 0; q < PER_TILE; ++q) issue_piece(t + 3, q);
-                }
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
                 acc16[0][0] = e0; acc16[0][1] = e0; acc16[1][0] = e1; acc16[1][1] = e1;
             }
             __builtin_amdgcn_sched_barrier(0);
-#if DVQ_DMA_EARLY || (DVQ_ABLATE & 2)
-#define DVQ_PIECE(Q)
-#else
 #define DVQ_PIECE(Q) issue_piece(t + 3, Q);
-#endif
 #define DVQ_MM(src, F, WAIT, NEXT)                                                                             \
             asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (!(DVQ_ABLATE & 8)) {                                                                              \
             acc16[(F) / S32][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[0][(F) % S32], acc16[(F) / S32][0], 0, 0, 0); \
             acc16[(F) / S32][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(src, zb[1][(F) % S32], acc16[(F) / S32][1], 0, 0, 0); \
-            } else { asm volatile("" : "+v"(acc16[(F) / S32][0]), "+v"(acc16[(F) / S32][1]) : "v"(src), "v"(zb[0][(F) % S32]), "v"(zb[1][(F) % S32])); } \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             if ((F) + 4 < S16) { DVQ_RD(src, ((F) + 4 < S16 ? (F) + 4 : 0)); }                                  \
             NEXT
@@ -799,21 +709,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #undef DVQ_PIECE
             __builtin_amdgcn_s_setprio(0);
         }
-        if (!(DVQ_ABLATE & 1)) top2(T - 1);
-#ifdef DVQ_TUNING
-        if (g_dvq_stamps != nullptr && tid == 0) {
-            unsigned long long *sp = g_dvq_stamps + 8 * (size_t)blockIdx.x;
-            sp[0] = (unsigned long long)dvq_cu_slot(); sp[1] = st_entry; sp[2] = st_pro; sp[3] = st_r0; sp[4] = st_c0;
-            sp[5] = __builtin_amdgcn_s_memrealtime(); sp[6] = __builtin_amdgcn_s_memtime();
-        }
-#endif
+        top2(T - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // surplus ring DMA
-#ifdef DVQ_TUNING
-        if (cu_lock != nullptr) {
-            __builtin_amdgcn_s_barrier();                    // every wave is out of the loop: hand the matrix cores over
-            if (tid == 0) __hip_atomic_store(&cu_lock[lock_slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#endif
         // merge the four lane groups of a token column (lower lane wins ties), then hand the results to the lanes
         // that own the token in the (c, h) layout of the prologue / epilogue
         float rb[2], rs[2];
@@ -958,12 +855,6 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         __syncthreads();
         if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-#ifdef DVQ_TUNING
-    if (g_dvq_stamps != nullptr && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's stores have left
-        g_dvq_stamps[8 * (size_t)blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 
@@ -1857,8 +1748,7 @@ int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep,
 }
 
 // counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
-// [1] exact-list count, [4] finalize ticket, [5] prepass ticket, [DVQ_QCOUNT0 ..] per-shard queue counts,
-// [DVQ_LOCK0 ..] one anti-phase lock word per (XCC, CU)
+// [1] exact-list count, [4] finalize ticket, [5] prepass ticket, [DVQ_QCOUNT0 ..] per-shard queue counts
 __global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict__ chunk_sync, int nsync)
 {
     for (int i = threadIdx.x; i < DVQ_COUNTER_BYTES / 4; i += blockDim.x) counters[i] = 0;
@@ -1876,14 +1766,10 @@ int dvq_launch_exact_list(const float *z, const float *prep, const float *E, con
 // Launch-time choices of the filter path.  They are compile-time constants of the production library; only the
 // tuning build (-DDVQ_TUNING: libdvq_tuning.so, tools/) can change them, through dvq_tuning_set().
 struct DvqTune {
-    int antiphase;       // pass 1, tuning build only: the two workgroups of a CU take turns in the code loop (per-CU lock)
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
     int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
 };
-#ifndef DVQ_ANTIPHASE_DEFAULT
-#define DVQ_ANTIPHASE_DEFAULT 0
-#endif
 #ifndef DVQ_PIPE_DEFAULT
 #define DVQ_PIPE_DEFAULT 0
 #endif
@@ -1892,26 +1778,24 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0, DVQ_PIPE_DEFAULT};
+static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
-    if (!strcmp(key, "antiphase")) g_tune.antiphase = value;
-    else if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
+    if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
     else if (!strcmp(key, "pipe")) g_tune.pipe = value;
     else return -1;
     return 0;
 }
-// device buffers the tuning build's pass 1 writes its diagnostics to (null = off): stamps [grid][8] u64 (see
-// g_dvq_stamps); tokdbg [N][4] f32 = best, second, 2W, code
+// device buffer the tuning build's pass 1 writes its per-token diagnostics to (null = off): tokdbg [N][4] f32 = best, second,
+// 2W, code.  (The first argument was round 3's clock-stamp buffer; it is ignored.)
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *stamps, void *tokdbg)
 {
-    hipError_t rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_stamps), &stamps, sizeof(void *));
-    if (rc == hipSuccess) rc = hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
-    return (int)rc;
+    (void)stamps;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {DVQ_ANTIPHASE_DEFAULT, 1, 0, DVQ_PIPE_DEFAULT};
+static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
 #endif
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
@@ -2023,11 +1907,9 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
     int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, CONV, FOLD>, (int)shmem1, &done);
     if (rc) return rc;
     const unsigned grid = (unsigned)((N + 127) / 128);
-    // anti-phase pays when every CU holds two workgroups for more than one generation
-    int *lock = (g_tune.antiphase && grid >= 1024) ? w.counters + DVQ_LOCK0 : nullptr;
     hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV, FOLD>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, rv, lock, cv);
+                       w.cap / DVQ_QSHARDS, rv, cv);
     return (int)hipGetLastError();
 }
 
