@@ -809,44 +809,57 @@ def run_rank(a):
     model_order = None
     if (world == 1 and a.scaling == "weak" and a.path == "routed" and a.mode == "filter" and not a.no_model_order and not force_xch):
         import copy
-        a2 = copy.copy(a)
-        a2.path = "model"
-        wl2 = WeakDual(a2, rank, world, dev)
-        wl2.prep_dom = wl.prep_dom
-        n2 = [0]
 
-        def step2():
-            k = n2[0]
-            n2[0] += 1
-            with torch.cuda.stream(streams[k % S]):
-                wl2.step(wl2.slots[k % S])
-        step2()
-        torch.cuda.synchronize()
-        for _ in range(50):
+        def side_leg(path, note):
+            """a short second measurement of another path on the same streams, its own inputs and its own parity check"""
+            a2 = copy.copy(a)
+            a2.path = path
+            wl2 = WeakDual(a2, rank, world, dev)
+            wl2.prep_dom = wl.prep_dom
+            n2 = [0]
+
+            def step2():
+                k = n2[0]
+                n2[0] += 1
+                with torch.cuda.stream(streams[k % S]):
+                    wl2.step(wl2.slots[k % S])
             step2()
-        torch.cuda.synchronize()
-        k2 = min(a.steps, 200)
-        dts2 = []
-        for _ in range(R):
             torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(k2):
+            for _ in range(50):
                 step2()
             torch.cuda.synchronize()
-            dts2.append(time.perf_counter() - t2)
-        dt2 = float(np.median(dts2))
-        model_order = {"path": "model", "workload": wl2.describe(), "steps": k2, "repeats": R, "ms_per_step": dt2 / k2 * 1e3,
-                       "ms_per_step_min_max": [min(dts2) / k2 * 1e3, max(dts2) / k2 * 1e3],
-                       "value": wl2.Bglobal * k2 / dt2, "unit": "images/s",
-                       "note": "bench.py --path model is the full measurement of this path (own roofline, serial step, all slots checked)"}
-        if not a.no_parity:
-            p2 = wl2.parity(wl2.slots[(n2[0] - 1) % S])
-            bad2 = sum(v for k_, v in p2.items() if k_.endswith("_mismatches"))
-            model_order["parity_checked"] = bool(bad2 == 0 and p2["loss_rel_err"] <= 1e-5)
-            model_order["parity"] = {k_: p2[k_] for k_ in ("images_checked", "code_mismatches", "zq_mismatches", "h_max_err_over_bound",
-                                                          "codes_match_rate_vs_fp64_conv", "rerun_with_h_buf_mismatches", "loss_rel_err")}
-        del wl2
-        torch.cuda.empty_cache()
+            k2 = min(a.steps, 200)
+            dts2 = []
+            for _ in range(R):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(k2):
+                    step2()
+                torch.cuda.synchronize()
+                dts2.append(time.perf_counter() - t2)
+            dt2 = float(np.median(dts2))
+            leg = {"path": path, "workload": wl2.describe(), "steps": k2, "repeats": R, "ms_per_step": dt2 / k2 * 1e3,
+                   "ms_per_step_min_max": [min(dts2) / k2 * 1e3, max(dts2) / k2 * 1e3],
+                   "value": wl2.Bglobal * k2 / dt2, "unit": "images/s", "note": note}
+            if not a.no_parity:
+                p2 = wl2.parity(wl2.slots[(n2[0] - 1) % S])
+                bad2 = sum(v for k_, v in p2.items() if k_.endswith("_mismatches"))
+                leg["parity_checked"] = bool(bad2 == 0 and p2["loss_rel_err"] <= 1e-5)
+                leg["parity"] = {k_: p2[k_] for k_ in ("images_checked", "code_mismatches", "zq_mismatches", "h_max_err_over_bound",
+                                                        "codes_match_rate_vs_fp64_conv", "rerun_with_h_buf_mismatches", "loss_rel_err",
+                                                        "tokens_resolved_with_a_conv", "token_stream_mismatches") if k_ in p2}
+            del wl2
+            torch.cuda.empty_cache()
+            return leg
+
+        # the model order beside the headline: the same step behind the models' 1x1 quant_conv -- as ONE op with the conv computed in
+        # pass 1 (codes, z_q AND loss: what training-time callers of `encode` get), and in the opt-in loss-free form with the conv
+        # FOLDED into the codebook (inference / stage-2 tokenisation: no conv is computed for tokens the filter decides)
+        model_order = side_leg("model", "bench.py --path model is the full measurement of this path (own roofline, serial step, all slots checked)")
+        model_order["fold"] = side_leg("model_fold", "bench.py --path model_fold: the model order for loss-free inference, quant_conv folded "
+                                                     "into the codebook (codes + z_q = codebook[code]; same codes as the conv-then-assign order)")
+        model_order["tokens_fold"] = side_leg("tokens_fold", "bench.py --path tokens_fold: stage 2's tokenisation of a stage-1 checkpoint (codes only "
+                                                             "+ permuter) with the quant_conv folded into the codebook")
 
     # the same K steps strictly serial (one stream, one slot's buffers): what a caller without stream slots gets
     serial_ms, serial_blocks = None, None

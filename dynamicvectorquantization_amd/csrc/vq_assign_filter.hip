@@ -329,19 +329,20 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         // lane's 8 x values of it.  All of it asm / DMA with counted waits: 12 vector-memory operations per group and wave.
         float xr[3][8];
         const float *xp = zp;
+        auto issue_w = [&](int k, int q) __attribute__((always_inline)) {       // weight piece q < 4 of group k
+            const int i = 4 * wave + q;                      // piece: row tile i >> 1, hi / lo i & 1
+            glds16(cv.wimg + (size_t)(i >> 1) * QTILE + (i & 1) * QIMG + k * 1024 + lane * 16,
+                   lds + (k & 3) * IMG_BYTES + i * 1024);
+        };
+        auto issue_x = [&](int k, int j) __attribute__((always_inline)) {       // x value j < 8 of group k (in order j = 0 .. 7)
+            asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
+            xp += (j == 7) ? 9 * st : st;                    // after the last one: skip the other lane half's 8 channels
+        };
         auto issue_group = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 4 * wave + q;                  // piece: row tile i >> 1, hi / lo i & 1
-                glds16(cv.wimg + (size_t)(i >> 1) * QTILE + (i & 1) * QIMG + k * 1024 + lane * 16,
-                       lds + (k & 3) * IMG_BYTES + i * 1024);
-            }
+            for (int q = 0; q < 4; ++q) issue_w(k, q);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                asm volatile("global_load_dword %0, %1, off nt" : "=v"(xr[k % 3][j]) : "v"(xp) : "memory");
-                xp += st;
-            }
-            xp += 8 * st;                                    // the other lane half's 8 channels
+            for (int j = 0; j < 8; ++j) issue_x(k, j);
         };
         glds4(cv.bias + wave * 64 + lane, bias_l + wave * 64);
         issue_group(0);
@@ -406,17 +407,42 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         for (int s = 0; s < S16; ++s) {
             __builtin_amdgcn_s_barrier();                    // k-step s of the weights landed (everybody's pieces); s - 1 consumed
             asm volatile("" ::: "memory");
-            if (s + 3 < S16) issue_group(s + 3);             // into the slot of k-step s - 1 and the x registers already converted
-            const char *buf = lds + (s & 3) * IMG_BYTES;
+            // group s + 3 (into the slot of k-step s - 1 and the x registers already converted) is issued piece by piece BETWEEN
+            // the row tiles below: each of its 12 vector-memory instructions then issues in the shadow of MFMAs already in the pipe
             const f16x8 bh = xh, bl = xl;
-#pragma unroll
-            for (int t8 = 0; t8 < 8; ++t8) {
-                const f16x8 ah = *(const f16x8 *)(buf + (2 * t8) * 1024 + lane * 16);
-                const f16x8 al = *(const f16x8 *)(buf + (2 * t8 + 1) * 1024 + lane * 16);
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t8], 0, 0, 0);     // small terms first (qconv.hip)
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t8], 0, 0, 0);
-                acc[t8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t8], 0, 0, 0);
-            }
+            // the 16 weight fragments of the k-step (per row tile: lo, then hi) through three rotating registers, each read
+            // CONV_AHEAD fragments before its MFMAs behind a counted lgkmcnt: left to hipcc every ds_read_b128 was followed by
+            // a full LDS round trip (lgkmcnt(0)) in front of its MFMA -- 16 exposed round trips per 24 MFMAs
+            const unsigned wa = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(lds + (s & 3) * IMG_BYTES) + lane * 16;
+            f16x8 wf[3];
+#define CV_OFF(Q) ((((Q) & 1) ? ((Q) - 1) : ((Q) + 1)) * 1024)      /* fragment Q: even = lo of tile Q / 2 (stored second), odd = hi */
+#define CV_RD(Q) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(wf[(Q) % 3]) : "v"(wa), "i"(CV_OFF(Q)))
+#define CV_WAIT(N, Q) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(wf[(Q) % 3]) :: "memory")
+            CV_RD(0); CV_RD(1); CV_RD(2);
+            __builtin_amdgcn_sched_barrier(0);
+#define CV_TILE(T8, W0, W1)                                                                                              \
+            CV_WAIT(W0, 2 * (T8));                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            acc[T8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(2 * (T8)) % 3], bh, acc[T8], 0, 0, 0);   /* small terms first (qconv.hip) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            if (2 * (T8) + 3 < 16) { CV_RD(2 * (T8) + 3 < 16 ? 2 * (T8) + 3 : 0); }                                       \
+            CV_WAIT(W1, 2 * (T8) + 1);                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            acc[T8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(2 * (T8) + 1) % 3], bl, acc[T8], 0, 0, 0);               \
+            acc[T8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(2 * (T8) + 1) % 3], bh, acc[T8], 0, 0, 0);               \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            if (2 * (T8) + 4 < 16) { CV_RD(2 * (T8) + 4 < 16 ? 2 * (T8) + 4 : 0); }
+            // outstanding reads at each wait: fragments Q .. min(Q + 2, 15); "all but the youngest N" = Q has landed
+#define CV_W(Q) if (s + 3 < S16) { issue_w(s + 3, Q); __builtin_amdgcn_sched_barrier(0); }
+#define CV_X(J) if (s + 3 < S16) { issue_x(s + 3, J); issue_x(s + 3, (J) + 1); __builtin_amdgcn_sched_barrier(0); }
+            CV_TILE(0, 2, 2) CV_W(0) CV_TILE(1, 2, 2) CV_W(1) CV_TILE(2, 2, 2) CV_W(2) CV_TILE(3, 2, 2) CV_W(3)
+            CV_TILE(4, 2, 2) CV_X(0) CV_TILE(5, 2, 2) CV_X(2) CV_TILE(6, 2, 2) CV_X(4) CV_TILE(7, 1, 0) CV_X(6)
+#undef CV_W
+#undef CV_X
+#undef CV_TILE
+#undef CV_WAIT
+#undef CV_RD
+#undef CV_OFF
             __builtin_amdgcn_sched_barrier(0);               // the MFMAs are issued; the next k-step's conversion runs under them
             if (s + 1 < S16) take_group(s + 1);
         }

@@ -45,4 +45,8 @@ def test_default_bench_reports_the_model_order_too():
     assert d["config"]["path"] == "routed" and d["parity_checked"] is True
     m = d["model_order"]
     assert m["path"] == "model" and m["ms_per_step"] > 0 and m["parity_checked"] is True and m["parity"]["code_mismatches"] == 0
+    for k, path in (("fold", "model_fold"), ("tokens_fold", "tokens_fold")):      # the loss-free forms with the conv folded into the codebook
+        f = m[k]
+        assert f["path"] == path and f["ms_per_step"] > 0 and f["parity_checked"] is True and f["parity"]["code_mismatches"] == 0
+        assert f["parity"]["tokens_resolved_with_a_conv"] > 0
     assert "model_order" not in _run("--no-model-order", "--no-parity")
