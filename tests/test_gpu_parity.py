@@ -586,6 +586,50 @@ def test_stream_slots_pipelined_encode_matches_serial(dev, oracle_mod):
             assert abs(float(loss) - serial[i][1]) <= 1e-6 * abs(serial[i][1])
 
 
+@pytest.mark.parametrize("which,Cc,norm,gate_type,B,hc,wc", [
+    ("dual", 256, "group-32", "2layer-fc-SiLu", 3, 5, 6),      # 90 cells: the last 32-cell block is partly empty (zero-filled image)
+    ("triple", 256, "group-32", "2layer-fc-ReLu", 2, 8, 8),    # 48 k-steps: 384 resident fragment registers
+    ("dual", 128, "group-16", "2layer-fc-SiLu", 5, 4, 4),      # 16 k-steps, hidden 256 = two hidden groups
+    ("triple", 64, "group-8", "2layer-fc-SiLu", 4, 3, 5),      # 12 k-steps (ring chunks of 4), hidden 192: the last group has empty row tiles
+    ("dual", 256, "group-8", "2layer-fc-SiLu", 40, 16, 16),    # 320 cell blocks: several per workgroup, 32 channels per group
+    ("triple", 256, "group-32", "2layer-fc-SiLu", 20, 8, 8),
+])
+def test_router_gate_gemm_form_matches_torch_ops(dev, which, Cc, norm, gate_type, B, hc, wc):
+    """the GEMM form of the gate (gate_pool_kernel<true> -> gate_gemm_kernel -> gate_finalize_kernel: hidden-layer weights resident
+    in registers, feature images streamed through an LDS ring) on shapes that take it -- GroupNorm with whole octets of channels
+    per group, a hidden layer -- against the module's own differentiable torch ops; deterministic across calls"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.router import DualGrainFeatureRouter, TripleGrainFeatureRouter
+    torch.manual_seed(23)
+    nbr = 2 if which == "dual" else 3
+    r = (DualGrainFeatureRouter if nbr == 2 else TripleGrainFeatureRouter)(Cc, norm, gate_type).to(dev)
+    with torch.no_grad():
+        for n_, p_ in r.named_parameters():
+            if "feature_norm" in n_:
+                p_.copy_(torch.randn_like(p_) * 0.5 + (1.0 if n_.endswith("weight") else 0.0))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    feats = [t(synth.features(7700 + i, B, Cc, hc << i, wc << i) * np.float32(1.5) + np.float32(0.3)) for i in range(nbr)]
+    kw = dict(h_coarse=feats[0], h_fine=feats[-1])
+    if nbr == 3:
+        kw["h_median"] = feats[1]
+    with torch.no_grad():
+        fused = r(**kw)
+        again = r(**kw)
+    ref = r(**kw).detach()
+    assert torch.equal(fused, again)
+    err = float((fused - ref).abs().max())
+    assert err < 1e-4 * max(1.0, float(ref.abs().max())), err
+    # GroupNorm parameters large enough that the normalised features leave the fp16 range: the a-priori power-of-two scale
+    with torch.no_grad():
+        for n_, p_ in r.named_parameters():
+            if "feature_norm" in n_ and n_.endswith("weight"):
+                p_.mul_(3000.0)
+        big = r(**kw)
+    ref_big = r(**kw).detach()
+    assert torch.isfinite(big).all()
+    assert float((big - ref_big).abs().max()) < 1e-4 * max(1.0, float(ref_big.abs().max()))
+
+
 @pytest.mark.gpu
 def test_fused_router_gate_fuzz(dev):
     """40 random router configurations (branches, channels, grid, batch, normalisation, gate type): the fused gate
