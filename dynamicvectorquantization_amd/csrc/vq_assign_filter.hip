@@ -37,6 +37,9 @@
 // image and the fp32 codebook rows keep their lines
 #define DVQ_LOAD_Z(p) __builtin_nontemporal_load(p)
 #define DVQ_STORE_ZQ(p, v) __builtin_nontemporal_store((v), (p))
+// the same through buffer instructions (resource = wave-uniform base, vector byte offset, scalar byte offset; aux 2 = nt)
+#define DVQ_BUF_LOAD(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 2))
+#define DVQ_BUF_STORE(v, rsrc, voff, soff) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), (rsrc), (voff), (soff), 2)
 // the per-lane select prologue (SEL = 1) reads lines of the coarser branches that neighbouring waves read again:
 // plain loads keep them in L2
 #define DVQ_LOAD_SEL(p) (*(p))
@@ -315,6 +318,22 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         const int hw = (int)(nn - bimg * HW);
         return ((size_t)bimg * D + 8 * h) * HW + hw;
     };
+    // The 128 loads and 128 stores of a lane go through BUFFER instructions: a wave-uniform base (the resource: lane 0's token, the
+    // smallest of the wave, or the image's base) + a 32-bit lane offset in ONE vector register + the channel's stride in a scalar
+    // register -- no vector instruction per access (global_load / global_store took one 64-bit vector add each: 270 of a block's
+    // ~8000 instructions).  D * HW < 2^29 (checked by the launcher) keeps every byte offset below 2^31.
+    auto wave_base = [&](const float *p0) -> __amdgpu_buffer_rsrc_t {     // resource at p0 + (lane 0's token_base())
+        const size_t tb = token_base();
+        const size_t tb0 = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) |
+                           (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(tb & 0xFFFFFFFFu));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p0 + tb0), 0, -1, 0x00020000);
+    };
+    auto lane_off = [&]() -> unsigned {                      // byte offset of this lane's token_base() from lane 0's
+        const size_t tb = token_base();
+        const size_t tb0 = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) |
+                           (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(tb & 0xFFFFFFFFu));
+        return (unsigned)(tb - tb0) * 4u;
+    };
     float zf[S16][8];
     float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell
     int sel_g = 0;                                           // SEL == 2: grain of this lane's cell
@@ -538,12 +557,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                     (unsigned)((8 * h) * 128 + (((wave >> 1) * 16 + (c >> 1)) << 2));
             stg_b = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)img_b +
                     (unsigned)((8 * h) * 32 + ((c >> 2) << 2));
-            const float *zp = rv.src[rv.G - 1] + ((size_t)b * D + 8 * h) * HW + pos;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void *)(rv.src[rv.G - 1] + (size_t)bw * D * HW), 0,
+                                                                                -1, 0x00020000);      // the image's plane stack
+            const unsigned zo = (unsigned)(8 * h * HW + pos) * 4u;
             __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int s = 0; s < S16; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
+                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the branch images (and its loads) landed;
             __builtin_amdgcn_s_barrier();                      // the barrier makes that true for the other waves' pieces
@@ -555,12 +576,13 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
         conv_prologue(z + token_base(), (size_t)HW);
     } else {
         for (int t = 0; t < pre; ++t) issue(t);
-        const float *zp = z + token_base();
+        const __amdgpu_buffer_rsrc_t zr = wave_base(z);
+        const unsigned zo = lane_off();
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int s = 0; s < S16; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_LOAD_Z(zp + (size_t)(16 * s + j) * HW);
+            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4);
         __builtin_amdgcn_s_setprio(0);
     }
     f16x8 zb[2][S32];                                        // B operands of the 16x16x32 loop, [token half][k-step of 32]
@@ -811,7 +833,10 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             // exec-masked branch to an out-of-line block.
             auto finish = [&](auto store_tag) {
                 constexpr bool STORE = decltype(store_tag)::value;
-                float *zqp = STORE ? zq + token_base() : nullptr;
+                const __amdgpu_buffer_rsrc_t qr = wave_base(STORE ? zq : (float *)E);
+                const unsigned qo = lane_off();
+                int hw4 = HW * 4;                            // opaque: the 128 scalar offsets are recomputed here (two scalar
+                asm volatile("" : "+s"(hw4));                // instructions each) instead of living in spilled SGPRs since the prologue
 #pragma unroll
                 for (int s0 = 0; s0 < S16; s0 += SB) {
                     f32x4 eg[SB][2];
@@ -827,11 +852,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
                         for (int j = 0; j < 8; ++j) {
                             float e = eg[q][j >> 2][j & 3];
                             if constexpr (FOLD) {           // the registers hold the conv's INPUT: z_q := e[code] (within 1e-6 of
-                                if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, e);   // fl(h + fl(e - h))), no loss term
+                                if (STORE) DVQ_BUF_STORE(e, qr, qo, (16 * s + j) * hw4);   // fl(h + fl(e - h))), no loss term
                             } else {
                             float diff = __fsub_rn(e, zf[s][j]);
-                            if (STORE) DVQ_STORE_ZQ(zqp + (size_t)(16 * s + j) * HW, __fadd_rn(zf[s][j], diff));
-                            lsum = __fadd_rn(lsum, __fmul_rn(__fmul_rn(diff, diff), m));
+                            if (STORE) DVQ_BUF_STORE(__fadd_rn(zf[s][j], diff), qr, qo, (16 * s + j) * hw4);
+                            lsum = __builtin_fmaf(diff, diff, lsum);   // the token's loss weight is applied once, below
                             }
                         }
                     }
@@ -839,6 +864,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
             };
             if (zq != nullptr) finish(std::true_type{});
             else finish(std::false_type{});
+            lsum *= m;
         }
     }
     if (umask != 0ull) {                                    // wave-uniform
@@ -1838,8 +1864,8 @@ static int rec_capacity(long N) { return DVQ_QSHARDS * shard_capacity(N); }
 
 bool dvq_filter_supported(int D, int HW, int K, long N)
 {
-    (void)HW;
-    return (D == 64 || D == 128 || D == 256) && N < (1L << 31) && K < (1 << 20);
+    // D * HW < 2^29: pass 1 addresses a wave's loads / stores as a 32-bit byte offset from the wave's first token (buffer instructions)
+    return (D == 64 || D == 128 || D == 256) && N < (1L << 31) && K < (1 << 20) && (long)D * HW < (1L << 29);
 }
 
 // resolver slices over the code tiles: 1 up to 64 tiles (K <= 2048), then one per 64 tiles, at most 8
