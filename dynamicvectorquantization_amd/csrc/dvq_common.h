@@ -109,6 +109,13 @@ struct DvqLossTail {
 #define DVQ_QSHARDS 64        // the pass-1 -> resolver queue is sharded this many ways (power of two)
 #define DVQ_QCOUNT0 8         // counters[DVQ_QCOUNT0 + shard] = tokens queued in that shard
 #define DVQ_COUNTER_BYTES 512
+// Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
+// branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
+// gate just read (profiles/r04_cache_policy.json: -6 % on the configs[3] per-GPU step, -7 % on the gate) -- above it with the non-temporal
+// hint (B = 256: plain loads cost 3 - 6 %).
+#ifndef DVQ_CACHED_MAX_BYTES
+#define DVQ_CACHED_MAX_BYTES ((size_t)160 << 20)
+#endif
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
 // Kernels with more than 64 KiB of dynamic LDS need the per-device opt-in once; `done` is the caller's

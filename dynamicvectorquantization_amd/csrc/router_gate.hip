@@ -54,10 +54,11 @@ struct DvqGateArgs {
 // workgroup rebuilds a tile.  fp16 range: every workgroup derives the SAME power-of-two scale from the GroupNorm parameters
 // alone -- |normalised value| <= |w| sqrt(n) + |b| for every element of a group of n values, and an average of such values
 // obeys the same bound -- so no workgroup needs another's data; xs[0] = that scale's inverse for the matrix kernel.
+#define GATE_LD(p) (NT ? __builtin_nontemporal_load(p) : *(p))    // NT: see DVQ_CACHED_MAX_BYTES (dvq_common.h)
 #ifndef DVQ_POOL_WPE
 #define DVQ_POOL_WPE 8           // workgroups per CU the pooling pass is compiled for (a streaming pass lives on occupancy)
 #endif
-template <bool IMG>
+template <bool IMG, bool NT>
 __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArgs a, float2 *__restrict__ ab,
                                                         float *__restrict__ pool, char *__restrict__ ximg,
                                                         float *__restrict__ xs)
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
                     for (int j = 0; j < 4; ++j) { s += r[j]; ss += (double)r[j] * r[j]; }
                 };
                 if (sc == 1) {
-                    const f32x4 r0 = __builtin_nontemporal_load((const f32x4 *)p);
+                    const f32x4 r0 = GATE_LD((const f32x4 *)p);
                     acc4(r0);
                     *(f32x4 *)o = r0;
                 } else if (sc == 2) {
-                    const f32x4 r0 = __builtin_nontemporal_load((const f32x4 *)p);
-                    const f32x4 r1 = __builtin_nontemporal_load((const f32x4 *)(p + Wb));
+                    const f32x4 r0 = GATE_LD((const f32x4 *)p);
+                    const f32x4 r1 = GATE_LD((const f32x4 *)(p + Wb));
                     acc4(r0); acc4(r1);
                     f32x2 v;
                     v[0] = ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
                 } else {
                     f32x4 rw[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rw[i] = __builtin_nontemporal_load((const f32x4 *)(p + (size_t)i * Wb));
+                    for (int i = 0; i < 4; ++i) rw[i] = GATE_LD((const f32x4 *)(p + (size_t)i * Wb));
                     float s4 = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -149,19 +150,19 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
             const float *p = p0 + (size_t)ch * plane + (size_t)sc * y * Wb + sc * x;
             float v;
             if (sc == 1) {
-                const float r = __builtin_nontemporal_load(p);
+                const float r = GATE_LD(p);
                 s += r; ss += (double)r * r;
                 v = r;
             } else if (sc == 2) {
-                const f32x2 r0 = __builtin_nontemporal_load((const f32x2 *)p);
-                const f32x2 r1 = __builtin_nontemporal_load((const f32x2 *)(p + Wb));
+                const f32x2 r0 = GATE_LD((const f32x2 *)p);
+                const f32x2 r1 = GATE_LD((const f32x2 *)(p + Wb));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { s += r0[j]; ss += (double)r0[j] * r0[j]; s += r1[j]; ss += (double)r1[j] * r1[j]; }
                 v = ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
             } else {
                 f32x4 r[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = __builtin_nontemporal_load((const f32x4 *)(p + (size_t)i * Wb));
+                for (int i = 0; i < 4; ++i) r[i] = GATE_LD((const f32x4 *)(p + (size_t)i * Wb));
                 float s4 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -907,6 +908,9 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     }
 #endif
     const int F = nb * C, Fp = (F + 15) & ~15;
+    // features that fit the memory-side cache are read with plain loads (pass 1 reads them again right after)
+    const int fs = 1 << (nb - 1);
+    const bool cached = (size_t)B * C * hc * fs * wc * fs * sizeof(float) <= DVQ_CACHED_MAX_BYTES;
     float2 *stats = (float2 *)ws;                            // (scale, shift) per (image, feature)
     float *pool = (float *)((char *)ws + align256r((size_t)B * F * sizeof(float2)));
     // ws: [folded GroupNorm affine][pooled averages (direct form) OR feature images (GEMM form)][W1 images, when the caller
@@ -936,8 +940,12 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         const int nblocks = (int)((ncell + 31) / 32);
         if ((ncell & 31) != 0)                               // the last block's unused cell columns must hold finite values
             (void)hipMemsetAsync(ximg + (size_t)(nblocks - 1) * S16 * 2048, 0, (size_t)S16 * 2048, st);
-        hipLaunchKernelGGL(gate_pool_kernel<true>, dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
-                           stats, pool, ximg, xs);
+        if (cached)
+            hipLaunchKernelGGL((gate_pool_kernel<true, false>), dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
+                               stats, pool, ximg, xs);
+        else
+            hipLaunchKernelGGL((gate_pool_kernel<true, true>), dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
+                               stats, pool, ximg, xs);
         int ncu = 256;
         {
             int dev = 0, n = 256;
@@ -979,8 +987,12 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, part, HG * 4, nout, nb, b2, gate);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(gate_pool_kernel<false>, dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
-                       nullptr, nullptr);
+    if (cached)
+        hipLaunchKernelGGL((gate_pool_kernel<false, false>), dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
+                           nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((gate_pool_kernel<false, true>), dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
+                           nullptr, nullptr);
     // two blocks of 32 cells per workgroup when the split tile of 64 cells fits the LDS and there are enough cells to keep
     // every CU busy that way
     const size_t shmem2 = ((size_t)2 * 32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);

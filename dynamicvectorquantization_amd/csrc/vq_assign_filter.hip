@@ -38,7 +38,7 @@
 #define DVQ_LOAD_Z(p) __builtin_nontemporal_load(p)
 #define DVQ_STORE_ZQ(p, v) __builtin_nontemporal_store((v), (p))
 // the same through buffer instructions (resource = wave-uniform base, vector byte offset, scalar byte offset; aux 2 = nt)
-#define DVQ_BUF_LOAD(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 2))
+#define DVQ_BUF_LOAD(rsrc, voff, soff, AUX) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), (AUX)))
 #define DVQ_BUF_STORE(v, rsrc, voff, soff) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(v)), (rsrc), (voff), (soff), 2)
 // the per-lane select prologue (SEL = 1) reads lines of the coarser branches that neighbouring waves read again:
 // plain loads keep them in L2
@@ -252,13 +252,17 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
 #endif
 
-template <int D, int SEL, bool CONV, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
+// NT: the latents are read with the non-temporal hint (a launch streams more than the 256-MB memory-side cache holds: keep L2 for
+// the code image and the codebook rows) or with plain loads (vq_assign_filter_cached_kernel: a batch whose features FIT that cache
+// was just written by the encoder / read by the router gate, and plain loads are served from it: -6 % on the configs[3] per-GPU
+// step, profiles/r04_cache_policy.json)
+template <int D, int SEL, bool CONV, bool FOLD, bool NT>
+__device__ __forceinline__ void pass1_body(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
+    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv)
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
             for (int s = 0; s < S16; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4);
+                for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4, NT ? 2 : 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the branch images (and its loads) landed;
             __builtin_amdgcn_s_barrier();                      // the barrier makes that true for the other waves' pieces
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 #pragma unroll
         for (int s = 0; s < S16; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4);
+            for (int j = 0; j < 8; ++j) zf[s][j] = DVQ_BUF_LOAD(zr, zo, (16 * s + j) * HW * 4, NT ? 2 : 0);
         __builtin_amdgcn_s_setprio(0);
     }
     f16x8 zb[2][S32];                                        // B operands of the 16x16x32 loop, [token half][k-step of 32]
@@ -910,6 +914,29 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
 }
 
 
+
+template <int D, int SEL, bool CONV, bool FOLD = false>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
+{
+    pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
+}
+
+// the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
+template <int D, int SEL, bool FOLD>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
+{
+    pass1_body<D, SEL, false, FOLD, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
+}
 
 // ---------------------------------------------------------------------------------------------
 // pass 1, large codebooks ("wide" form, D = 256): a wave scores TWO blocks of 32 tokens against every
@@ -1956,9 +1983,21 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
+    const unsigned grid = (unsigned)((N + 127) / 128);
+    if constexpr (D == 256 && !CONV && SEL != 1) {
+        // a batch whose features fit the memory-side cache (with room for what else is live): plain loads instead of non-temporal ones
+        if ((size_t)N * D * sizeof(float) <= DVQ_CACHED_MAX_BYTES) {
+            static unsigned long long done_c = 0;
+            int rcc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_cached_kernel<D, SEL, FOLD>, (int)shmem1, &done_c);
+            if (rcc) return rcc;
+            hipLaunchKernelGGL((vq_assign_filter_cached_kernel<D, SEL, FOLD>), dim3(grid), dim3(256), shmem1, st,
+                               z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                               w.cap / DVQ_QSHARDS, rv, cv);
+            return (int)hipGetLastError();
+        }
+    }
     int rc = dvq_allow_dynamic_lds((const void *)vq_assign_filter_kernel<D, SEL, CONV, FOLD>, (int)shmem1, &done);
     if (rc) return rc;
-    const unsigned grid = (unsigned)((N + 127) / 128);
     hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV, FOLD>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
                        w.cap / DVQ_QSHARDS, rv, cv);

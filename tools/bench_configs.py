@@ -11,7 +11,7 @@ from dynamicvectorquantization_amd.encode import encode_dual, encode_triple
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(a).to(dev)
 
-def timeit(fn, n=20, warm=5):
+def timeit(fn, n=int(os.environ.get("DVQ_BC_ITERS", "20")), warm=5):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
