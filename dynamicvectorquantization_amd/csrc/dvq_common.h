@@ -112,9 +112,9 @@ struct DvqLossTail {
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
 // gate just read (profiles/r04_cache_policy.json: -6 % on the configs[3] per-GPU step, -7 % on the gate) -- above it with the non-temporal
-// hint (B = 256: plain loads cost 3 - 6 %).
+// hint (B = 256: plain loads cost 3 - 6 %; break-even measured at ~150 MB, tools/cache_policy_sweep.py).
 #ifndef DVQ_CACHED_MAX_BYTES
-#define DVQ_CACHED_MAX_BYTES ((size_t)160 << 20)
+#define DVQ_CACHED_MAX_BYTES ((size_t)136 << 20)
 #endif
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
