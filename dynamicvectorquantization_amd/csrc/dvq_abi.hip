@@ -506,7 +506,6 @@ int dvq_route_select_dual_f32(const void *gate, int gate_dtype, const float *h_c
 {
     int rc = route_args_ok("dvq_route_select_dual_f32", gate, gate_dtype, h_coarse, h_fine, B, C, hc, wc, h_out, indices, cmask);
     if (rc) return rc;
-    if (wc % 2 != 0) { dvq_set_error("dvq_route_select_dual_f32: wc=%d must be even (rows move as 16-byte pieces)", wc); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_route_select(2, gate_dtype == DVQ_GATE_I64, gate, h_coarse, nullptr, h_fine, B, C, hc, wc,
                                           h_out, (long long *)indices, cmask, 0.0f, nullptr, (hipStream_t)stream), "route_select_dual");
 }
@@ -518,7 +517,6 @@ int dvq_route_select_dual_entropy_f32(const float *entropy, float threshold, con
 {
     int rc = route_args_ok("dvq_route_select_dual_entropy_f32", entropy, DVQ_GATE_F32, h_coarse, h_fine, B, C, hc, wc, h_out, indices, cmask);
     if (rc) return rc;
-    if (wc % 2 != 0) { dvq_set_error("dvq_route_select_dual_entropy_f32: wc=%d must be even (rows move as 16-byte pieces)", wc); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_route_select(2, 2, entropy, h_coarse, nullptr, h_fine, B, C, hc, wc,
                                           h_out, (long long *)indices, cmask, threshold, (long long *)gate_out,
                                           (hipStream_t)stream), "route_select_dual_entropy");

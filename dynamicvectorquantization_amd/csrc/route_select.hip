@@ -49,7 +49,12 @@ __device__ __forceinline__ int gate_argmax(const void *gate, size_t cell, float 
 constexpr int PLANES_PER_BLOCK = 8;
 constexpr int MAX_CELLS = 4096;                 // grain map bytes kept in LDS (64 x 64 coarse cells)
 
-template <int G, int MODE>
+// V = floats per thread and access: 4 (rows are whole float4s), or 2 for the dual select on an odd coarse width (rows of 2 wc floats
+// are then only 8-byte pieces; both floats of a piece lie in one coarse cell)
+template <int V> struct VecOf;
+template <> struct VecOf<4> { typedef f32x4 type; };
+template <> struct VecOf<2> { typedef f32x2 type; };
+template <int G, int MODE, int V = 4>
 __global__ __launch_bounds__(256) void route_select_kernel(
     const void *__restrict__ gate, const float *__restrict__ h_coarse,
     const float *__restrict__ h_median, const float *__restrict__ h_fine,
@@ -59,7 +64,8 @@ __global__ __launch_bounds__(256) void route_select_kernel(
 {
     constexpr int SC = (G == 2) ? 2 : 4;          // fine pixels per coarse cell edge
     __shared__ unsigned char grain[MAX_CELLS];
-    const int H = SC * hc, W = SC * wc, W4 = W / 4;
+    typedef typename VecOf<V>::type vec_t;
+    const int H = SC * hc, W = SC * wc, W4 = W / V;
     const int per_plane = H * W4;
     const int ncell = hc * wc;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
@@ -77,21 +83,21 @@ __global__ __launch_bounds__(256) void route_select_kernel(
     for (int p = p0; p < p1; ++p) {
         const size_t plane = (size_t)b * C + p;
         for (int i = threadIdx.x; i < per_plane; i += 256) {
-            const int y = i / W4, x = (i - y * W4) * 4;
+            const int y = i / W4, x = (i - y * W4) * V;
             const int cy = y / SC;
-            const int cx0 = x / SC, cx1 = (x + 3) / SC;       // the (up to two) coarse cells of this float4
+            const int cx0 = x / SC, cx1 = (x + V - 1) / SC;   // the (up to two) coarse cells of this piece
             const int cell0 = cy * wc + cx0;
             const int g0 = grain_of(cell0);
             const int g1 = (cx1 != cx0) ? grain_of(cell0 + 1) : g0;
             if (p == C) {
-                f32x4 m;
+                vec_t m;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < V; ++j) {
                     int g = ((x + j) / SC == cx0) ? g0 : g1;
                     m[j] = (G == 2) ? (g == 0 ? 0.25f : 1.0f)
                                     : (g == 0 ? 0.0625f : (g == 1 ? 0.25f : 1.0f));
                 }
-                *(f32x4 *)(cmask + ((size_t)b * H + y) * W + x) = m;
+                *(vec_t *)(cmask + ((size_t)b * H + y) * W + x) = m;
                 if (y % SC == 0) {
                     if (x % SC == 0) indices[(size_t)b * ncell + cell0] = g0;
                     if (cx1 != cx0) indices[(size_t)b * ncell + cell0 + 1] = g1;
@@ -112,14 +118,14 @@ __global__ __launch_bounds__(256) void route_select_kernel(
                 continue;
             }
             const size_t o = (plane * H + y) * W + x;
-            f32x4 v;
+            vec_t v;
             if (g0 == G - 1 && g1 == G - 1) {
-                v = *(const f32x4 *)(h_fine + o);
+                v = *(const vec_t *)(h_fine + o);
             } else {
-                f32x4 f = {0.f, 0.f, 0.f, 0.f};
-                if (g0 == G - 1 || g1 == G - 1) f = *(const f32x4 *)(h_fine + o);
+                vec_t f = {};
+                if (g0 == G - 1 || g1 == G - 1) f = *(const vec_t *)(h_fine + o);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < V; ++j) {
                     const int xx = x + j;
                     const int g = (xx / SC == cx0) ? g0 : g1;
                     float sv;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void route_select_kernel(
                     v[j] = sv;
                 }
             }
-            *(f32x4 *)(h_out + o) = v;
+            *(vec_t *)(h_out + o) = v;
         }
     }
     if (in_lds) __syncthreads();                  // the next image overwrites the grain map
@@ -190,12 +196,19 @@ int dvq_launch_route_select(int G, int gate_mode, const void *gate, const float 
 {
     dim3 grid((C + 1 + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK, B < 65535 ? B : 65535), block(256);
 #define DVQ_SEL(GG, MM) hipLaunchKernelGGL((route_select_kernel<GG, MM>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask, thr, gate_out)
+#define DVQ_SEL2(MM) hipLaunchKernelGGL((route_select_kernel<2, MM, 2>), grid, block, 0, st, gate, h_coarse, h_median, h_fine, B, C, hc, wc, h_out, indices, cmask, thr, gate_out)
+    if (G == 2 && (wc & 1)) {                                // odd coarse width: 8-byte pieces
+        if (gate_mode == 2) DVQ_SEL2(2);
+        else if (gate_mode == 1) DVQ_SEL2(1);
+        else DVQ_SEL2(0);
+    } else
     if (G == 2 && gate_mode == 2) DVQ_SEL(2, 2);
     else if (G == 2 && gate_mode == 1) DVQ_SEL(2, 1);
     else if (G == 2) DVQ_SEL(2, 0);
     else if (gate_mode == 1) DVQ_SEL(3, 1);
     else DVQ_SEL(3, 0);
 #undef DVQ_SEL
+#undef DVQ_SEL2
     return (int)hipGetLastError();
 }
 

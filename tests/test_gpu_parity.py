@@ -226,10 +226,11 @@ def test_route_select_triple_golden(dev):
     assert tuple(out["gate"].shape) == (2, 3, 8, 8)
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 1, 2), (3, 5, 3, 6), (2, 256, 16, 16)])
+@pytest.mark.parametrize("shape", [(1, 4, 1, 2), (3, 5, 3, 6), (2, 256, 16, 16), (2, 7, 1, 1), (3, 6, 5, 7), (2, 32, 15, 15)])
 def test_route_select_shapes_vs_oracle(dev, oracle_mod, shape):
+    """incl. odd coarse widths (rows of the dual select then move as 8-byte pieces: 240-px images, 15 x 15 cells)"""
     from dynamicvectorquantization_amd import synth
-    from dynamicvectorquantization_amd.router import route_select_dual, route_select_triple
+    from dynamicvectorquantization_amd.router import route_select_dual, route_select_dual_entropy, route_select_triple
     B, Cc, hc_, wc_ = shape
     t = lambda a: torch.from_numpy(a).to(dev)
     hf, hc = synth.features(1, B, Cc, 2 * hc_, 2 * wc_), synth.features(2, B, Cc, hc_, wc_)
@@ -238,6 +239,14 @@ def test_route_select_shapes_vs_oracle(dev, oracle_mod, shape):
     o = oracle_mod.route_select_dual(gate, hc, hf)
     for k in ("h_dual", "indices", "codebook_mask"):
         assert np.array_equal(out[k].cpu().numpy(), o[k]), k
+    ent = synth.entropy_map(7, B, hc_, wc_)
+    thr = 1.6777750253677368
+    out = route_select_dual_entropy(t(ent), thr, t(hc), t(hf))
+    og = oracle_mod.entropy_gate(ent, thr)
+    o = oracle_mod.route_select_dual(og, hc, hf)
+    for k in ("h_dual", "indices", "codebook_mask"):
+        assert np.array_equal(out[k].cpu().numpy(), o[k]), k
+    assert np.array_equal(out["gate"].cpu().numpy(), og.transpose(0, 3, 1, 2))      # the encoders hand the gate on as [B, 2, hc, wc]
     hf, hm = synth.features(4, B, Cc, 4 * hc_, 4 * wc_), synth.features(5, B, Cc, 2 * hc_, 2 * wc_)
     lg = synth.grain_logits_triple(6, B, hc_, wc_)
     out = route_select_triple(t(lg), t(hc), t(hm), t(hf))
