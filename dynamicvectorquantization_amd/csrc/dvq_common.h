@@ -111,10 +111,12 @@ struct DvqLossTail {
 #define DVQ_COUNTER_BYTES 512
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
-// gate just read (profiles/r04_cache_policy.json: -6 % on the configs[3] per-GPU step, -7 % on the gate) -- above it with the non-temporal
-// hint (B = 256: plain loads cost 3 - 6 %; break-even measured at ~150 MB, tools/cache_policy_sweep.py).
+// gate just read -- above it with the non-temporal hint.  profiles/r04_cache_policy.json: one batch at a time, plain loads pay up to
+// ~150 MB (configs[1] -2.4 %, the gate op -5 %); with three batches in flight on three streams (how bench.py and a serving loop drive
+// the op) they pay only while all three working sets fit the cache together, hence 64 MiB (B = 64 at 32 x 32 x 256); B = 128 under
+// three streams loses 3 % with plain loads, B = 256 3 - 6 % even alone.
 #ifndef DVQ_CACHED_MAX_BYTES
-#define DVQ_CACHED_MAX_BYTES ((size_t)136 << 20)
+#define DVQ_CACHED_MAX_BYTES ((size_t)64 << 20)
 #endif
 #define DVQ_EXACT_LIST_BLOCKS 512   // grid of the list-mode exact kernel (2 per CU; it walks the list in chunks)
 
