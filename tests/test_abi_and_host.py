@@ -57,7 +57,6 @@ def test_size_queries_and_validation_without_gpu():
     assert L.dvq_vq_assign_nchw_f32(1, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, 0, 0, 7, 0) == -1   # mode
     assert L.dvq_codebook_prepare_f32(1, 1024, 256, 256, 16, 0) == -3                          # too small
     assert L.dvq_route_select_dual_f32(0, 0, 0, 0, 1, 1, 1, 2, 0, 0, 0, 0) == -1
-    assert L.dvq_route_select_dual_f32(1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 0) == -2               # odd wc
     assert L.dvq_embed_gather_f32(1, 4, 6, 1, 1, 1, 0) == -2                                    # D % 4
     # newer entry points: same discipline
     assert L.dvq_route_select_dual_entropy_f32(0, 1.0, 0, 0, 1, 1, 1, 2, 0, 0, 0, 0, 0) == -1
