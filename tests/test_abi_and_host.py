@@ -60,7 +60,6 @@ def test_size_queries_and_validation_without_gpu():
     assert L.dvq_embed_gather_f32(1, 4, 6, 1, 1, 1, 0) == -2                                    # D % 4
     # newer entry points: same discipline
     assert L.dvq_route_select_dual_entropy_f32(0, 1.0, 0, 0, 1, 1, 1, 2, 0, 0, 0, 0, 0) == -1
-    assert L.dvq_route_select_dual_entropy_f32(1, 1.0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 0, 0) == -2    # odd wc
     assert L.dvq_ema_accumulate_nchw_f32(0, 0, 1, 64, 1, 8, 0, 0, 0) == -1
     assert L.dvq_entropy_map_f32(1, 1, 250, 256, 16, 1, 0) == -2                               # H % 16
     assert L.dvq_router_gate_workspace_bytes(2, 64, 256, 16, 16, 32, 512) >= 512 * 512 * 4 + 64 * 512 * 256 * 4
