@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 400   // 0.4.0: the conv folded into the codebook (dvq_fold_*, dvq_vq_assign_*fold*)
+#define DVQ_VERSION 401   // 0.4.1: the conv folded into the codebook (dvq_fold_*, dvq_vq_assign_*fold*); the dual select takes odd coarse widths
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -219,7 +219,7 @@ int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float 
     if (rc) return rc;
     const long N = (long)B * HW;
     if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
-    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: shape unsupported by the filter path (D=%d HW=%d K=%d: K < 2^20, D * HW < 2^29)", fn, D, HW, K); return DVQ_EUNSUPPORTED; }
     if (!ws || ws_bytes < dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER)) {
         dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER));
         return DVQ_EWORKSPACE;
@@ -275,7 +275,7 @@ int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *f
     if (rc) return rc;
     const long N = (long)B * HW;
     if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
-    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, HW, K, N)) { dvq_set_error("%s: shape unsupported by the filter path (D=%d HW=%d K=%d: K < 2^20, D * HW < 2^29)", fn, D, HW, K); return DVQ_EUNSUPPORTED; }
     if (!ws || ws_bytes < dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER)) {
         dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_workspace_bytes(B, D, HW, K, DVQ_MODE_FILTER));
         return DVQ_EWORKSPACE;
@@ -349,7 +349,7 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     }
     const long N = (long)B * SC * hc * SC * wc;
     if (N >= (1L << 31) || (size_t)N * D >= ((size_t)1 << 40) || B > 32768) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }
-    if (!dvq_filter_supported(D, SC * hc * SC * wc, K, N)) { dvq_set_error("%s: K=%d unsupported", fn, K); return DVQ_EUNSUPPORTED; }
+    if (!dvq_filter_supported(D, SC * hc * SC * wc, K, N)) { dvq_set_error("%s: shape unsupported by the filter path (D=%d HW=%d K=%d: K < 2^20, D * HW < 2^29)", fn, D, SC * hc * SC * wc, K); return DVQ_EUNSUPPORTED; }
     if (!ws || ws_bytes < dvq_vq_assign_routed_workspace_bytes(nb, B, D, hc, wc, K, mode)) {
         dvq_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, dvq_vq_assign_routed_workspace_bytes(nb, B, D, hc, wc, K, mode));
         return DVQ_EWORKSPACE;
