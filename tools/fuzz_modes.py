@@ -68,5 +68,5 @@ def run(ncases=150, seed=12345, verbose=True):
 
 
 if __name__ == "__main__":
-    bad, n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 150)
+    bad, n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     sys.exit(1 if bad else 0)

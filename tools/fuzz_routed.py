@@ -115,4 +115,4 @@ def run(ncases=200, seed=2468):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 200) else 0)
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 2468) else 0)
