@@ -87,6 +87,10 @@ def parse():
 # launcher: N fresh rank processes, started before this process has made any GPU call
 # ------------------------------------------------------------------------------------------------
 def launch_ranks(a):
+    """Start one rank process per GPU and FAIL FAST: every process is polled; the first non-zero exit (a rank that dies in
+    set-up would otherwise leave the others in the rendezvous until torch's 10-30 min timeout) kills the rest and the
+    launcher returns non-zero within seconds.  The whole job is bounded by DVQ_BENCH_LAUNCH_TIMEOUT seconds (default 900)."""
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -97,27 +101,45 @@ def launch_ranks(a):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 600
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()                                   # rank 0's pipe is drained while everybody is polled
+    deadline = time.time() + float(os.environ.get("DVQ_BENCH_LAUNCH_TIMEOUT", "900"))
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why = "rank %d exited with code %d" % bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() > deadline:
+            why = "wall-time bound exceeded (DVQ_BENCH_LAUNCH_TIMEOUT)"
+            break
+        time.sleep(0.1)
+    if why is not None:
+        for p in procs:                              # the exact processes started above, nothing by pattern
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 3.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5.0)
     line = None
-    for ln in (out0 or "").splitlines():
+    for ln in out0:
+        ln = ln.rstrip("\n")
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-        else:
+        elif ln:
             print(ln, file=sys.stderr)
-    if any(rcs) or line is None:
-        print("bench.py launcher: rank exit codes %s%s" % (rcs, "" if line else ", no JSON line from rank 0"),
+    if why is not None or line is None:
+        print("bench.py launcher: %s; rank exit codes %s" % (why or "no JSON line from rank 0", [p.returncode for p in procs]),
               file=sys.stderr)
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         return 1
     print(line, flush=True)
     return 0
@@ -683,6 +705,14 @@ def run_rank(a):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("DVQ_BENCH_TEST_FAIL_RANK") == str(rank):    # launcher test: this rank dies in set-up, before the rendezvous
+        raise RuntimeError("bench.py: rank %d told to fail in set-up (DVQ_BENCH_TEST_FAIL_RANK)" % rank)
+    if os.environ.get("DVQ_BENCH_TEST_SLEEP_RANK") == str(rank):   # launcher test: this rank never joins (wall-time bound)
+        time.sleep(3600)
+    backend = os.environ.get("DVQ_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for tests
+    if world > 1 and backend != "nccl":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)   # needs no GPU: the rendezvous comes first
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local = local % torch.cuda.device_count()      # (a 1-GPU box can still exercise the N > 1 code path)
@@ -693,13 +723,9 @@ def run_rank(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    if world > 1:
+    if world > 1 and backend == "nccl":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DVQ_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for tests
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dynamicvectorquantization_amd.encode import CodeExchange, StreamSlots
     from dynamicvectorquantization_amd.quantize import _CodebookPrep

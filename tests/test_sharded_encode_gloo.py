@@ -130,6 +130,36 @@ def test_ema_update_world2_single_collective():
     assert all(tuple(np.round(r, 5)) in rows0 for r in ee0[~used])          # ... with rank 0's vectors everywhere
 
 
+def test_bench_launcher_fails_fast_when_a_rank_dies_in_setup():
+    """a rank that dies in set-up must not leave the others (and the launcher) in the rendezvous until torch's
+    timeout.  Rank 1 raises before it joins (DVQ_BENCH_TEST_FAIL_RANK), rank 0 and 2 sit in the gloo rendezvous (which needs no
+    GPU): the launcher sees the non-zero exit, ends the other ranks it started and returns non-zero within seconds.  Also the
+    wall-time bound: nobody fails, nobody can finish (3 ranks announced, rank 2 never joins -- it is told to sleep)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DVQ_BENCH_BACKEND="gloo", DVQ_BENCH_TEST_FAIL_RANK="1")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert p.returncode != 0
+    assert dt < 30.0, "launcher took %.1f s to notice a dead rank" % dt
+    assert "rank 1 exited with code" in p.stderr, p.stderr[-2000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # the wall-time bound
+    env = dict(os.environ, DVQ_BENCH_BACKEND="gloo", DVQ_BENCH_TEST_SLEEP_RANK="2", DVQ_BENCH_LAUNCH_TIMEOUT="4")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert p.returncode != 0 and dt < 30.0, (p.returncode, dt)
+    assert "wall-time bound" in p.stderr, p.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_bench_launcher_spawns_ranks_and_exchanges_on_device():
     """`python bench.py --gpus 2` is a launcher -- it starts 2 rank processes itself (here both
