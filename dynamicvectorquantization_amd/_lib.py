@@ -23,6 +23,7 @@ MODE_FILTER = 1
 MODE_FILTER_PASS1 = 2   # profiling aid: only the dominant filter kernel
 MODE_FILTER_WIDE = 3    # testing aid: force the two-blocks-per-wave pass-1 kernel (D = 256)
 FILTER_MODES = (MODE_FILTER, MODE_FILTER_PASS1, MODE_FILTER_WIDE)
+MODE_WS_CLEAN = 0x100   # flag OR-ed into a filter mode: the workspace is clean (include/dvq.h), no zeroing kernel is launched
 GATE_F32 = 0
 GATE_I64 = 1
 GATE_ENTROPY = 2        # routed assign only: entropy map + threshold
@@ -172,6 +173,8 @@ def _load():
 
 
 lib = _load()
+# DVQ_MODE_WS_CLEAN exists since ABI 0.5.0 (an older build loaded through DVQ_LIBRARY for an A/B rejects the flag)
+HAS_WS_CLEAN = lib.dvq_version() >= 500
 
 
 def check(rc, what):

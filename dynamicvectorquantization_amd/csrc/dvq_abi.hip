@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 401   // 0.4.1: the conv folded into the codebook (dvq_fold_*, dvq_vq_assign_*fold*); the dual select takes odd coarse widths
+#define DVQ_VERSION 500   // 0.5.0: fused form of the filter path (resolver inside pass 1's launch), DVQ_MODE_WS_CLEAN
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";
@@ -28,13 +28,13 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd = nullptr);
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd, bool ws_clean);
 int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const float *h_coarse,
                       const float *h_median, const float *h_fine, const void *prep, const float *E,
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
                       double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv,
-                      const DvqFold *fd = nullptr);
+                      const DvqFold *fd, bool ws_clean);
 size_t dvq_fold_prep_bytes_impl(int K, int D);
 int dvq_launch_fold_prep(const float *E, int K, int D, const void *cbprep, const float *Wt, const float *bias, void *fprep,
                          hipStream_t st);
@@ -134,6 +134,7 @@ int dvq_codebook_prepare_f32(const float *codebook, int K, int D, void *prep, si
 size_t dvq_vq_assign_workspace_bytes(int B, int D, int HW, int K, int mode)
 {
     if (B <= 0 || HW <= 0 || K <= 0 || D <= 0) return 0;
+    mode &= ~DVQ_MODE_WS_CLEAN;
     long N = (long)B * HW;
     size_t partials = partials_bytes_for(N);
     size_t extra = (mode == DVQ_MODE_FILTER || mode == DVQ_MODE_FILTER_PASS1 || mode == DVQ_MODE_FILTER_WIDE) ? dvq_filter_ws_extra_bytes(D, HW, K, N) : 0;
@@ -156,6 +157,8 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     if (!z || !codebook || !prep || !codes) { dvq_set_error("dvq_vq_assign_nchw_f32: null pointer"); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_vq_assign_nchw_f32: B=%d HW=%d K=%d must be positive", B, HW, K); return DVQ_EINVAL; }
     if (!dim_ok(D)) { dvq_set_error("dvq_vq_assign_nchw_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
+    mode &= ~DVQ_MODE_WS_CLEAN;
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
     const bool force_wide = (mode == DVQ_MODE_FILTER_WIDE);
     if (pass1_only || force_wide) mode = DVQ_MODE_FILTER;
@@ -175,7 +178,7 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     int rc;
     if (mode == DVQ_MODE_FILTER && dvq_filter_supported(D, HW, K, N)) {
         rc = dvq_launch_filter(z, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, nullptr, st, nullptr);
+                               (char *)ws + partials_bytes, pass1_only, force_wide, loss, beta, nullptr, st, nullptr, nullptr, ws_clean);
         return hip_rc(rc, "vq_assign_filter");     // the loss finalize is fused into its last kernel
     } else {
         rc = dvq_launch_exact(z, (const float *)prep, codebook, mask, D, HW, K, N, zq,
@@ -212,6 +215,8 @@ int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float 
     const char *fn = "dvq_vq_assign_qconv_f32";
     if (!x || !codebook || !prep || !codes) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("%s: B=%d HW=%d K=%d must be positive", fn, B, HW, K); return DVQ_EINVAL; }
+    const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
+    mode &= ~DVQ_MODE_WS_CLEAN;
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
     if (mode != DVQ_MODE_FILTER && !pass1_only) { dvq_set_error("%s: mode %d (the conv is fused into the filter path only)", fn, mode); return DVQ_EINVAL; }
     DvqConv cv;
@@ -227,7 +232,7 @@ int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float 
     if (((uintptr_t)ws & 255) != 0) { dvq_set_error("%s: workspace must be 256-byte aligned", fn); return DVQ_EINVAL; }
     double *partials = loss ? (double *)ws : nullptr;
     rc = dvq_launch_filter(x, prep, codebook, mask, D, HW, K, N, zq, (long long *)codes, partials,
-                           (char *)ws + partials_bytes_for(N), pass1_only, false, loss, beta, nullptr, (hipStream_t)stream, &cv);
+                           (char *)ws + partials_bytes_for(N), pass1_only, false, loss, beta, nullptr, (hipStream_t)stream, &cv, nullptr, ws_clean);
     return hip_rc(rc, fn);
 }
 
@@ -267,6 +272,8 @@ int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *f
                            void *ws, size_t ws_bytes, int mode, void *stream)
 {
     const char *fn = "dvq_vq_assign_fold_f32";
+    const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
+    mode &= ~DVQ_MODE_WS_CLEAN;
     if (!x || !codebook || !prep || !codes) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("%s: B=%d HW=%d K=%d must be positive", fn, B, HW, K); return DVQ_EINVAL; }
     if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
@@ -284,7 +291,7 @@ int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *f
     if (mode != DVQ_MODE_FILTER && mode != DVQ_MODE_FILTER_PASS1) { dvq_set_error("%s: mode %d (the fold is a form of the filter path)", fn, mode); return DVQ_EINVAL; }
     rc = dvq_launch_filter(x, prep, codebook, nullptr, D, HW, K, N, zq, (long long *)codes, nullptr,
                            (char *)ws + partials_bytes_for(N), mode == DVQ_MODE_FILTER_PASS1, false, nullptr, 0.0f, nullptr,
-                           (hipStream_t)stream, nullptr, &fd);
+                           (hipStream_t)stream, nullptr, &fd, ws_clean);
     return hip_rc(rc, fn);
 }
 
@@ -332,6 +339,8 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
     int SC;
     if (!routed_dims(nb, hc, wc, &SC)) { dvq_set_error("%s: hc*wc=%ld exceeds %d coarse cells", fn, (long)hc * wc, DVQ_ROUTE_MAX_CELLS_ABI); return DVQ_EUNSUPPORTED; }
+    const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
+    mode &= ~DVQ_MODE_WS_CLEAN;
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
     if (pass1_only) mode = DVQ_MODE_FILTER;
     if (mode != DVQ_MODE_EXACT && mode != DVQ_MODE_FILTER) { dvq_set_error("%s: unknown mode %d", fn, mode); return DVQ_EINVAL; }
@@ -362,7 +371,7 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     int rc = dvq_launch_routed(nb, gmode, gate, threshold, h_coarse, h_median, h_fine, prep, codebook, B, D, hc, wc, K,
                                beta, zq, (long long *)codes, loss, (long long *)indices, cmask, (long long *)gate_out,
                                partials, (char *)ws + pbytes, mode == DVQ_MODE_EXACT, pass1_only, st, conv ? &cv : nullptr,
-                               fold_prep != nullptr ? &fd : nullptr);
+                               fold_prep != nullptr ? &fd : nullptr, ws_clean);
     return hip_rc(rc, fn);                                   // the loss finalize is part of the op in both modes
 }
 

@@ -25,11 +25,11 @@ static constexpr int RES_CAND = 512;              // resolver: candidate pairs p
 // record of one queued token (written by pass 1, read by the resolver)
 //   [zf: D*4 B in channel order][meta 32 B]   (the resolver re-derives the fp16 fragments: same RNE conversion)
 __host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; }
-//   n:    output position of the token (b*HW + hw); rep = 1 (a token that covered rep x rep positions, rows Wout apart,
-//         belonged to the de-duplicated forms of round 2; the resolver still honours the field)
+//   n:    output position of the token (b*HW + hw), also what the exact list carries for it
+//   m:    the token's loss weight (codebook_mask value; the resolver must not read the mask tensor: in the routed op pass 1
+//         writes it in the same launch)
 //   best: merged (distance, code) key of the sliced resolver (large K), ~0 = none yet; written ~0 by pass 1
-//   tokid: what the exact list carries for the token (= n)
-struct RecMeta { int n; float xn; float thr; int tokid; unsigned long long best; int prov; int rep; };   // 32 B
+struct RecMeta { int n; float xn; float thr; float m; unsigned long long best; int prov; int pad; };   // 32 B
 
 // The bound W on |G - truth| (derivation: header of vq_assign_filter.hip);
 // returns 2 W (1 + margin), NaN for a token the fp16 path cannot score.

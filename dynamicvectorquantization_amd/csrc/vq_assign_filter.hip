@@ -250,7 +250,66 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // diagnostic of the tuning build only: per-token (best, second, 2W, code) of the production arithmetic for the bound audit
 // (tools/bound_audit.py --production).  Written to a buffer of its own; no output value is computed from it.
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
+// ... and a timeline of the fused form: [block][16] s_memrealtime stamps (100 MHz), thread 0 of every workgroup.  Token blocks:
+// [0] entry, [1] exit.  Consumers: [0] entry, [1] exit, then per chunk c < 2 at [2 + 7c ..]: chunk ready (poll + stamps), records
+// in LDS, enumerated, exact chains done, chunk done, nlive, -; tools/fused_timeline.py reads it.
+__device__ unsigned long long *g_dvq_clk = nullptr;
+#define DVQ_CLK(slot) do { if (g_dvq_clk != nullptr && threadIdx.x == 0 && (slot) < 16) g_dvq_clk[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DVQ_CLKV(slot, v) do { if (g_dvq_clk != nullptr && threadIdx.x == 0 && (slot) < 16) g_dvq_clk[(size_t)blockIdx.x * 16 + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define DVQ_CLK(slot) do { } while (0)
+#define DVQ_CLKV(slot, v) do { } while (0)
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// The fused form: the resolver runs INSIDE pass 1's launch, as `ncons` consumer workgroups appended to the grid (block
+// indices >= nb1; they are dispatched when the last generation of token blocks retires and take the slots it frees).
+// Hand-off of the queued tokens' records, producer -> consumer, inside one launch (MI355X_MICROARCH.md, "inter-workgroup
+// visibility"; per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
+//   producer   record payload + meta as 16-byte WRITE-THROUGH stores (sc1) -> every storing wave `s_waitcnt vmcnt(0)` ->
+//              workgroup barrier -> one sc1 "stamp" store per record (stamps[record index] = 1) and ONE agent-scope add to
+//              counters[DVQ_C_DONE] per workgroup.  The reservation of a record's slot (an agent-scope atomic on the shard's
+//              counter) happened long before.
+//   consumer   one wave polls with sc1 loads: DONE first, then the shard's reservation count (DONE == nb1 makes that count
+//              final), then the stamps of the 32 slots of its chunk; after a workgroup barrier every wave loads the records
+//              with sc1 16-byte loads.  No fence anywhere: nothing but sc1 traffic crosses workgroups.
+// Consumers never wait for other consumers and producers wait for nobody, so the launch cannot deadlock however its blocks are
+// dispatched as long as ncons workgroups cannot occupy every slot of the chip (ncons <= 256 at two workgroups per CU); the
+// hardware dispatches a grid in block order anyway, which is what makes the consumers arrive when they are needed.
+// What a consumer decides goes to LISTS the op's last kernel (the exact-list kernel) applies after the kernel boundary: a
+// (record, winning code) pair for every token whose exact winner differs from pass 1's provisional choice -- a consumer must not
+// store to z_q / codes itself: the provisional values may still sit dirty in another XCD's L2, whose write-back would land on top
+// of the correction -- and the tokens it cannot resolve (exact list).  The last consumer to leave (ticket) copies the list
+// counts to a mailbox and puts every live counter back to zero: the workspace is clean for the next op, no zero kernel needed.
+// ---------------------------------------------------------------------------------------------
+struct DvqFuse {
+    int ncons;                // consumer workgroups behind the nb1 token workgroups (0: unfused -- no stamps, no DONE)
+    int nb1;
+    int *stamps;              // [DVQ_QSHARDS * rec_cap], zero between ops
+    int *rewrites;            // [rec_capacity][2]
+    const float *en_all;
+    const char *img32;        // the 32x32x16-order code image the resolver enumerates on (pass 1 streams the 16x16x32 one)
+    float *h_spill;           // CONV: where the exact-list kernel reads its tokens' conv output from
+    double *cons_partials;    // [ncons] loss corrections of the consumers
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dvq_rsrc(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000);
+}
+// 16-byte / 4-byte accesses that carry sc1 (aux bit 4): write-through stores, L1-bypassing coherent loads
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16);
+}
+__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16));
+}
+__device__ __forceinline__ int ld_sc1(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // NT: the latents are read with the non-temporal hint (a launch streams more than the 256-MB memory-side cache holds: keep L2 for
 // the code image and the codebook rows) or with plain loads (vq_assign_filter_cached_kernel: a batch whose features FIT that cache
@@ -262,7 +321,7 @@ __device__ __forceinline__ void pass1_body(
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv)
+    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv, const DvqFuse &fz)
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
@@ -284,6 +343,7 @@ __device__ __forceinline__ void pass1_body(
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
     char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;   // this wave's permutation scratch
+    DVQ_CLK(0);
 
     // DMA of code tile t into its ring slot, in PER_TILE pieces (q < CPW: 1 KiB of the image, q == CPW:
     // this wave's copy of the seeds).  Past the end: harmless repeat, so the counts stay constant.
@@ -309,7 +369,7 @@ __device__ __forceinline__ void pass1_body(
 #pragma unroll
         for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
-    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_id = xcd_swizzle(blockIdx.x, fz.nb1);    // (the grid may carry consumer workgroups behind the nb1 token blocks)
     // SEL == 2 parks the coarser branches in the ring slots from `pre` on: 2 slots = D x 128 B for the 2x-coarser
     // branch (dual: slots 2, 3; triple: slots 1, 2), slot 3 for the triple's 4x-coarser branch (D x 32 B)
     const int pre = (SEL == 2) ? ((rv.G == 2) ? 2 : 1) : 3;  // code tiles in flight before the prologue
@@ -814,7 +874,7 @@ __device__ __forceinline__ void pass1_body(
     int slot_raw = 0;
     if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
     if (valid && hopeless && h == 0) {
-        int pos = atomicAdd(&counters[1], 1);
+        int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);
         exact_list[pos] = n;
     }
     auto spill_h = [&]() {                                  // CONV: the exact-list kernel reads this token's h from cv.h_buf
@@ -826,11 +886,12 @@ __device__ __forceinline__ void pass1_body(
     };
     if (CONV && valid && hopeless && !cv.h_all) spill_h();
     float lsum = 0.0f;
+    float m_tok = 1.0f;
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
+        m_tok = (SEL != 0) ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
-            const float m = (SEL != 0) ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
             constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
             // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
             // inside the loop on the per-lane pointer every one of the 128 stores became its own
@@ -868,16 +929,17 @@ __device__ __forceinline__ void pass1_body(
             };
             if (zq != nullptr) finish(std::true_type{});
             else finish(std::false_type{});
-            lsum *= m;
+            lsum *= m_tok;
         }
     }
+    int rec_index = -1;                                     // this lane's record (both lane halves of a queued token)
     if (umask != 0ull) {                                    // wave-uniform
         const int base = __shfl(slot_raw, 0);
         int slot = base + (int)__popcll(umask & ((1ull << c) - 1ull));   // rank among the wave's undecided tokens
         slot = undecided ? slot : -1;
         if (undecided && slot >= rec_cap) {                 // shard full: full exact evaluation instead; the
             if (h == 0) {                                   // provisional code / z_q written above are overwritten
-                int pos = atomicAdd(&counters[1], 1);       // by the exact-list kernel, the loss term is dropped here
+                int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);   // by the exact-list kernel, the loss term is dropped here
                 exact_list[pos] = n;
             }
             if (CONV && !cv.h_all) spill_h();
@@ -885,57 +947,46 @@ __device__ __forceinline__ void pass1_body(
             slot = -1;
         }
         if (slot >= 0) {
-            char *rec = records + ((size_t)shard * rec_cap + slot) * rec_bytes(D);
+            // write-through (sc1) stores: the record may be read inside this launch by a consumer workgroup on another XCD
+            rec_index = shard * rec_cap + slot;
+            const __amdgpu_buffer_rsrc_t rr = dvq_rsrc(records);
+            const unsigned ro = (unsigned)rec_index * (unsigned)rec_bytes(D);
 #pragma unroll
             for (int s = 0; s < S16; ++s) {
                 f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
                 f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
-                *(f32x4 *)(rec + (16 * s + 8 * h) * 4) = lo;
-                *(f32x4 *)(rec + (16 * s + 8 * h + 4) * 4) = hi;
+                st16_sc1(rr, ro + (16 * s + 8 * h) * 4, lo);
+                st16_sc1(rr, ro + (16 * s + 8 * h + 4) * 4, hi);
             }
             if (h == 0) {
                 RecMeta rm;
-                rm.n = n; rm.xn = xn; rm.thr = thr; rm.tokid = n; rm.prov = code;
-                rm.best = ~0ull; rm.rep = 1;
-                *(RecMeta *)(rec + (size_t)D * 4) = rm;
+                rm.n = n; rm.xn = xn; rm.thr = thr; rm.m = m_tok; rm.prov = code;
+                rm.best = ~0ull; rm.pad = 0;
+                const f32x4 *rq = (const f32x4 *)&rm;
+                st16_sc1(rr, ro + D * 4, rq[0]);
+                st16_sc1(rr, ro + D * 4 + 16, rq[1]);
             }
         }
     }
-    if (partials != nullptr) {
+    const bool fused = fz.ncons > 0;                        // kernel argument: uniform
+    if (fused) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's records have been written through
+    if (partials != nullptr || fused) {
         double dsum = (double)lsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
-        __syncthreads();
-        double *red = (double *)lds;
-        if (lane == 0) red[wave] = dsum;
-        __syncthreads();
-        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();                                    // ... and every other wave's
+        if (fused) {
+            if (rec_index >= 0 && h == 0) __hip_atomic_store(fz.stamps + rec_index, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) (void)__hip_atomic_fetch_add(&counters[DVQ_C_DONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (partials != nullptr) {
+            double *red = (double *)lds;
+            if (lane == 0) red[wave] = dsum;
+            __syncthreads();
+            if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
     }
-}
-
-
-
-template <int D, int SEL, bool CONV, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
-    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
-    const float *__restrict__ E, const float *__restrict__ mask,
-    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
-    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
-{
-    pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
-}
-
-// the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
-template <int D, int SEL, bool FOLD>
-__global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
-    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
-    const float *__restrict__ E, const float *__restrict__ mask,
-    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
-    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
-{
-    pass1_body<D, SEL, false, FOLD, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
+    DVQ_CLK(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1209,7 +1260,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
 #pragma unroll
     for (int u = 0; u < 2; ++u)
         if (valid[u] && hopeless[u] && h == 0) {
-            int pos = atomicAdd(&counters[1], 1);
+            int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);
             exact_list[pos] = nn[u];
         }
 
@@ -1264,8 +1315,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
         else finish(std::false_type{});
         if (rec != nullptr && h == 0) {
             RecMeta rm;
-            rm.n = n; rm.xn = xnu; rm.thr = thru; rm.tokid = n; rm.prov = cd;
-            rm.best = ~0ull; rm.rep = 1;
+            rm.n = n; rm.xn = xnu; rm.thr = thru; rm.m = m; rm.prov = cd;
+            rm.best = ~0ull; rm.pad = 0;
             *(RecMeta *)(rec + (size_t)D * 4) = rm;
         }
     };
@@ -1293,6 +1344,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
 // (a few % of the tokens), so the work is spread for LATENCY: the four waves of a workgroup share
 // the same 32 tokens and each takes every fourth code tile, reading its A fragments straight from
 // the L2-resident prep image (no LDS ring, no barrier in the loop).
+// Two callers: vq_resolve_kernel (a launch of its own behind pass 1: large codebooks with sliced code
+// tiles, the wide / pipe forms of pass 1) and resolve_consumer (the fused form: consumer workgroups at
+// the end of pass 1's own grid, see DvqFuse).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long order_key(float d, int code)
 {
@@ -1323,66 +1377,98 @@ __device__ __forceinline__ float aten_sumsq(const float *v, int D)
     return s;
 }
 
+// LDS of one resolver workgroup (statics of vq_resolve_kernel, a carve of pass 1's dynamic region for the consumers)
+template <int D>
+struct ResLds {
+    static constexpr int RB = D * 4 + 32;                    // bytes per record (rec_bytes(D))
+    static constexpr int SREC = 0;                           // [RES_SLOTS][RB] this workgroup's records
+    static constexpr int CAND = SREC + RES_SLOTS * RB;       // [RES_CAND] unsigned
+    static constexpr int BEST = CAND + RES_CAND * 4;         // [RES_SLOTS] u64
+    static constexpr int REWR = BEST + RES_SLOTS * 8;        // [RES_SLOTS] int
+    static constexpr int MISC = REWR + RES_SLOTS * 4;        // [8] int: 0 candidate count, 1 rewrite count, 2 last slice, 3 overflow flag,
+                                                             //          4 live slots of the chunk, 5 chunk is the shard's last
+    static constexpr int RED = MISC + 32;                    // [4] double
+    static constexpr int BYTES = RED + 32;
+    static_assert(CAND % 16 == 0 && BEST % 8 == 0 && RED % 8 == 0, "carve alignment");
+};
+
+#ifndef DVQ_FOLD_ABL
+#define DVQ_FOLD_ABL 0           // timing experiments of the tuning build only (results WRONG): 1 no conv loop, 2 no xn, 4 no h write-back
+#endif
+
+// One chunk: the records [base, base + nlive) (record indices; nlive <= RES_SLOTS), code tiles [t_begin, t_end).
 // FOLD (vq_fold.hip): the records hold the conv's INPUT x and `img` / `meta` are the folded codebook: the enumeration below
 // runs on x exactly as pass 1 scored it (its candidate set contains the reference's winner for every h inside the conv's
 // tolerance); the workgroup then computes h = W x + bias for its 32 tokens -- qconv.hip's split-fp16 arithmetic, bit-identical
 // to dvq_qconv_f32 -- in place over x, and the exact chains / the rewrite run on that h against the codebook itself.
-template <int D, bool FOLD>
-__global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
-    const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
-    const float *__restrict__ E, const float *__restrict__ mask, int HW, int K,
-    float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
-    int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    int nslice, int *__restrict__ chunk_sync, int Wout, float *__restrict__ h_spill, const DvqConv cv)
+// INGRID (consumer workgroup of the fused form): the records are loaded with sc1 loads (their producers are workgroups of this
+// very launch); winners that differ from pass 1's provisional code go to the rewrite list instead of z_q / codes.
+// nslice > 1 (stand-alone kernel, large codebooks): each slice resolves its candidates locally, merges its per-token best
+// into the record with a 64-bit atomicMin, and the slice that arrives last at the chunk's ticket carries on.
+// Returns (thread 0) the chunk's loss correction; *not_last is set for a slice that is not the chunk's last.
+// HW = positions per image of the OUTPUT grid.
+template <int D, bool FOLD, bool INGRID>
+__device__ __forceinline__ double resolve_chunk(
+    char *__restrict__ L, const int base, const int nlive, const int t_begin, const int t_end,
+    const char *__restrict__ img, const float *__restrict__ en_all, const float *__restrict__ E, int HW,
+    float *__restrict__ zq, long long *__restrict__ codes, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int nslice, int *__restrict__ ticket, float *__restrict__ h_spill, const DvqConv &cv,
+    int *__restrict__ rewrites_out, const bool want_loss, bool *not_last, const int clk_base = 16)
 {
+    (void)clk_base;
     // h_spill (conv fused into pass 1; null otherwise): [B, D, HW] buffer the exact-list kernel reads its tokens' latents from.
     // Pass 1 spills the rows of ITS hand-offs; the tokens the resolver itself sends to that list (candidate overflow, no
     // candidate) get their row written here, from the record (which holds the conv's output).
-    // HW = positions per image of the OUTPUT grid; a routed token (RecMeta.rep > 1) covers rep x rep
-    // positions, rows Wout apart, all rewritten with the same values.
-    // Large codebooks: the code tiles are cut into `nslice` slices (blockIdx.y); each slice resolves its
-    // candidates locally, merges its per-token best into the record with a 64-bit atomicMin, and the
-    // slice that arrives last at the chunk's ticket does the rewrite.  nslice == 1: all of it in LDS.
+    using LL = ResLds<D>;
     constexpr int S16 = D / 16;
     constexpr int IMG_BYTES = S16 * 1024;
     constexpr int TILE_STRIDE = IMG_BYTES + 256;
-    __shared__ unsigned cand[RES_CAND];
-    __shared__ unsigned long long best[RES_SLOTS];
-    __shared__ int misc[4];                           // [0] candidate count, [1] rewrite count
-    __shared__ int rewrite[RES_SLOTS];
     constexpr int RW = DVQ_RES_WAVES;
-    __shared__ double red[RW];
-    constexpr int RB = D * 4 + 32;                           // bytes per record (rec_bytes(D))
-    __shared__ __attribute__((aligned(16))) char srec[RES_SLOTS * RB];   // this workgroup's records, read from HBM / L2 once
+    constexpr int RB = LL::RB;
+    char *srec = L + LL::SREC;
+    unsigned *cand = (unsigned *)(L + LL::CAND);
+    unsigned long long *best = (unsigned long long *)(L + LL::BEST);
+    int *rewrite = (int *)(L + LL::REWR);
+    int *misc = (int *)(L + LL::MISC);
+    double *red = (double *)(L + LL::RED);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    // block -> (shard, chunk): the first DVQ_QSHARDS blocks take chunk 0 of every shard, and so on
-    const int shard = blockIdx.x & (DVQ_QSHARDS - 1), chunk = blockIdx.x / DVQ_QSHARDS;
-    int total = counters[DVQ_QCOUNT0 + shard];
-    total = total < rec_cap ? total : rec_cap;
-    total += shard * rec_cap;                                   // end of this shard's filled run
-    const int base = shard * rec_cap + chunk * RES_SLOTS;
-    const int slice = blockIdx.y;
-    if (base >= total) {
-        if (partials != nullptr && tid == 0 && slice == 0) partials[blockIdx.x] = 0.0;
-        return;
-    }
-    const int T = dvq_num_tiles(K);
-    int tps = (T + nslice - 1) / nslice;                        // tiles per slice, a multiple of 4
-    tps = (tps + RW - 1) / RW * RW;
-    const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
+    *not_last = false;
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
-
     {
-        const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
-        const f32x4 *src = (const f32x4 *)(records + (size_t)base * RB);
-        for (int i = tid; i < nlive * (RB / 16); i += RW * 64) ((f32x4 *)srec)[i] = src[i];
+        // all of a thread's pieces are in flight before the first is stored (the rolled loop paid one memory latency per piece:
+        // 4.3 of a chunk's 13 us)
+        constexpr int NP = (RES_SLOTS * (RB / 16) + RW * 64 - 1) / (RW * 64);
+        const int npieces = nlive * (RB / 16);
+        f32x4 tmp[NP];
+        if constexpr (INGRID) {
+            const __amdgpu_buffer_rsrc_t rr = dvq_rsrc(records);
+            const unsigned b0 = (unsigned)base * (unsigned)RB;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * RW * 64;
+                tmp[k] = ld16_sc1(rr, b0 + 16u * (unsigned)(i < npieces ? i : 0));
+            }
+        } else {
+            const f32x4 *src = (const f32x4 *)(records + (size_t)base * RB);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * RW * 64;
+                tmp[k] = src[i < npieces ? i : 0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * RW * 64;
+            if (i < npieces) ((f32x4 *)srec)[i] = tmp[k];
+        }
     }
     __syncthreads();
-    const bool live = base + c < total;
+    DVQ_CLK(clk_base + 1);
+    const bool live = c < nlive;
     const char *rec = srec + (live ? c : 0) * RB;
     f16x8 zh[S16];
 #pragma unroll
@@ -1436,22 +1522,34 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
                 if (pos < RES_CAND) cand[pos] = ((unsigned)c << 20) | (unsigned)code;
             }
         };
+        // Two tiles in flight per wave.  Every fetch is UNCONDITIONAL (past the wave's last tile it re-reads that tile and the
+        // result is not scored): with `if (t + RW < t_end) fetch(..)` the wait in front of a tile's first MFMA was computed over
+        // both paths -- vmcnt(5): the just-issued prefetch had to land too, so no tile was ever fetched under another's MFMAs
+        // (0.85 us per tile on an idle chip instead of the MFMA chain's 0.25).
         f16x8 a0[S16], a1[S16];
         f32x4 e0[4], e1[4];
         const int tw = t_begin + wave;
         if (tw < t_end) {
+            const int tl = tw + (t_end - 1 - tw) / RW * RW;      // this wave's last tile
+            auto clampt = [&](int t) { return t < tl ? t : tl; };
+            // (sched_barrier: left alone the scheduler interleaves the two fetches, and the register the first MFMA needs is
+            // then among the last loads issued)
             fetch(tw, a0, e0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(clampt(tw + RW), a1, e1);
+            __builtin_amdgcn_sched_barrier(0);
             for (int t = tw; t < t_end; t += 2 * RW) {
-                if (t + RW < t_end) fetch(t + RW, a1, e1);
                 score(t, a0, e0);
-                if (t + 2 * RW < t_end) fetch(t + 2 * RW, a0, e0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(clampt(t + 2 * RW), a0, e0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (t + RW < t_end) score(t + RW, a1, e1);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(clampt(t + 3 * RW), a1, e1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-#ifndef DVQ_FOLD_ABL
-#define DVQ_FOLD_ABL 0           // timing experiments of the tuning build only (results WRONG): 1 no conv loop, 2 no xn, 4 no h write-back
-#endif
     if constexpr (FOLD) {
         constexpr int T8 = D / 32, NT = (T8 + RW - 1) / RW;      // row tiles of the weight; this wave takes wave, wave + RW, ..
         constexpr int QIMG = S16 * 1024, QTILE = 2 * QIMG + 256;
@@ -1546,11 +1644,12 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
             float sn = __shfl(tl, lane & ~7);
 #pragma unroll
             for (int i = 1; i < 8; ++i) sn = __fadd_rn(sn, __shfl(tl, (lane & ~7) + i));
-            if (l8 == 0 && base + tk < total) ((RecMeta *)(srec + tk * RB + (size_t)D * 4))->xn = sn;
+            if (l8 == 0 && tk < nlive) ((RecMeta *)(srec + tk * RB + (size_t)D * 4))->xn = sn;
         }
         __syncthreads();
     }
     __syncthreads();
+    DVQ_CLK(clk_base + 2);
     const int ncand_raw = misc[0];
     bool overflow = ncand_raw > RES_CAND;             // hand the whole group to the exact list
     const int ncand = overflow ? 0 : ncand_raw;
@@ -1564,53 +1663,68 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         const f32x4 *ev = (const f32x4 *)(E + (size_t)code * D);
         const float xn = ((const RecMeta *)(r2 + (size_t)D * 4))->xn;
         float acc = 0.0f;
-#pragma unroll 16
-        for (int q = 0; q < D / 4; ++q) {
-            f32x4 a = zv[q], b = ev[q];
-            acc = __builtin_fmaf(a[0], b[0], acc);
-            acc = __builtin_fmaf(a[1], b[1], acc);
-            acc = __builtin_fmaf(a[2], b[2], acc);
-            acc = __builtin_fmaf(a[3], b[3], acc);
+        // the codebook row in batches of 16 x 16 B, the next batch in flight while this one feeds the (sequential) chain
+        constexpr int CB = 16, NB = D / 4 / CB;
+        f32x4 eb[2][CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) eb[0][q] = ev[q];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) {
+#pragma unroll
+                for (int q = 0; q < CB; ++q) eb[(b + 1) & 1][q] = ev[(b + 1) * CB + q];
+            }
+#pragma unroll
+            for (int q = 0; q < CB; ++q) {
+                const f32x4 a = zv[b * CB + q], bb = eb[b & 1][q];
+                acc = __builtin_fmaf(a[0], bb[0], acc);
+                acc = __builtin_fmaf(a[1], bb[1], acc);
+                acc = __builtin_fmaf(a[2], bb[2], acc);
+                acc = __builtin_fmaf(a[3], bb[3], acc);
+            }
         }
         float bias = __fadd_rn(xn, en_all[code]);
         float d = __builtin_fmaf(-2.0f, acc, bias);
         atomicMin(&best[sl], order_key(d, code));
     }
     __syncthreads();
+    DVQ_CLK(clk_base + 3);
 
-    if (nslice > 1) {
-        // merge across slices through the records; the last slice of this chunk carries on
-        int *ticket = chunk_sync + 2 * blockIdx.x, *oflag = ticket + 1;
-        if (tid < RES_SLOTS && base + tid < total && best[tid] != ~0ull) {
-            RecMeta *gm = (RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
-            atomicMin(&gm->best, best[tid]);
-        }
-        if (overflow && tid == 0) atomicOr(oflag, 1);
-        __syncthreads();
-        if (tid == 0) {
+    if constexpr (!INGRID) {
+        if (nslice > 1) {
+            // merge across slices through the records; the last slice of this chunk carries on
+            int *oflag = ticket + 1;
+            if (tid < nlive && best[tid] != ~0ull) {
+                RecMeta *gm = (RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
+                atomicMin(&gm->best, best[tid]);
+            }
+            if (overflow && tid == 0) atomicOr(oflag, 1);
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                misc[2] = (atomicAdd(ticket, 1) == nslice - 1);
+            }
+            __syncthreads();
+            if (!misc[2]) { *not_last = true; return 0.0; }   // not the last slice (its partial is written by the last)
             __threadfence();
-            misc[2] = (atomicAdd(ticket, 1) == nslice - 1);
+            if (tid < nlive) {
+                const RecMeta *gm = (const RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
+                best[tid] = __hip_atomic_load(&gm->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            overflow = misc[3] != 0;
         }
-        __syncthreads();
-        if (!misc[2]) return;                          // not the last slice (its partial is written by the last)
-        __threadfence();
-        if (tid < RES_SLOTS && base + tid < total) {
-            const RecMeta *gm = (const RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
-            best[tid] = __hip_atomic_load(&gm->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 0) misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        overflow = misc[3] != 0;
     }
 
     // ---- winners; slots whose winner differs from pass 1 are rewritten
-    if (tid < RES_SLOTS && base + tid < total) {
+    if (tid < nlive) {
         const char *r2 = srec + tid * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
             {
-                int pos = atomicAdd(&counters[1], 1);     // cannot resolve here: full exact evaluation;
-                exact_list[pos] = m2.tokid;               // pass 1's loss term for it is taken back below
+                int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);   // cannot resolve here: full exact evaluation;
+                exact_list[pos] = m2.n;                           // pass 1's loss term for it is taken back below
             }
             int pos = atomicAdd(&misc[1], 1);
             rewrite[pos] = (tid << 20) | 0xFFFFF;
@@ -1631,11 +1745,17 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
         const char *r2 = srec + sl * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         const long n = m2.n;
-        const int rep = m2.rep;
         const long bimg = n / HW;
         const int hw = (int)(n - bimg * HW);
-        const float m = (mask != nullptr) ? mask[n] : 1.0f;
+        const float m = m2.m;
         float delta = 0.0f;
+        if (INGRID && !take_back_only && lane == 0) {
+            // the list kernel applies it behind the kernel boundary (see DvqFuse)
+            const int pos = atomicAdd(&counters[DVQ_C_NREW], 1);
+            rewrites_out[2 * pos] = base + sl;
+            rewrites_out[2 * pos + 1] = win;
+        }
+        if (INGRID && !want_loss && !(take_back_only && h_spill != nullptr)) continue;   // nothing else to do for this token
         for (int k0 = lane * 4; k0 < D; k0 += 256) {
             f32x4 zv = *(const f32x4 *)(r2 + k0 * 4);
             if (take_back_only && h_spill != nullptr) {
@@ -1647,34 +1767,181 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float dn = __fsub_rn(en_[j], zv[j]), dold = __fsub_rn(eo[j], zv[j]);
-                if (zq != nullptr && !take_back_only) {
-                    float *zp = zq + ((size_t)bimg * D + k0 + j) * HW + hw;
-                    const float v = __fadd_rn(zv[j], dn);
-                    for (int ry = 0; ry < rep; ++ry)
-                        for (int rx = 0; rx < rep; ++rx) zp[(size_t)ry * Wout + rx] = v;
+                if (!INGRID && zq != nullptr && !take_back_only) {
+                    // FOLD: the record (now h) gives fl(h + fl(e - h)) here, e[code] in pass 1: both within 1e-6 of each other
+                    zq[((size_t)bimg * D + k0 + j) * HW + hw] = FOLD ? en_[j] : __fadd_rn(zv[j], dn);
                 }
                 float tn = take_back_only ? 0.0f : __fmul_rn(__fmul_rn(dn, dn), m);
                 delta += tn - __fmul_rn(__fmul_rn(dold, dold), m);
             }
         }
-        if (lane == 0 && !take_back_only)
-            for (int ry = 0; ry < rep; ++ry)
-                for (int rx = 0; rx < rep; ++rx) codes[n + (long)ry * Wout + rx] = (long long)win;
-        delta *= (float)(rep * rep);
+        if (!INGRID && lane == 0 && !take_back_only) codes[n] = (long long)win;
         dsum += (double)delta;
     }
-    if (partials != nullptr) {
+    double tot = 0.0;
+    if (want_loss) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
         if (tid == 0) {
-            double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < RW; ++w) tot += red[w];
-            partials[blockIdx.x] = tot;
         }
     }
+    return tot;
+}
+
+template <int D, bool FOLD>
+__global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
+    const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
+    const float *__restrict__ E, int HW, int K,
+    float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
+    int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
+    int nslice, int *__restrict__ chunk_sync, float *__restrict__ h_spill, const DvqConv cv)
+{
+    __shared__ __attribute__((aligned(16))) char L[ResLds<D>::BYTES];
+    (void)meta;
+    // block -> (shard, chunk): the first DVQ_QSHARDS blocks take chunk 0 of every shard, and so on
+    const int shard = blockIdx.x & (DVQ_QSHARDS - 1), chunk = blockIdx.x / DVQ_QSHARDS;
+    int total = counters[DVQ_QCOUNT0 + shard];
+    total = total < rec_cap ? total : rec_cap;
+    total += shard * rec_cap;                                   // end of this shard's filled run
+    const int base = shard * rec_cap + chunk * RES_SLOTS;
+    const int slice = blockIdx.y;
+    if (base >= total) {
+        if (partials != nullptr && threadIdx.x == 0 && slice == 0) partials[blockIdx.x] = 0.0;
+        return;
+    }
+    const int T = dvq_num_tiles(K);
+    int tps = (T + nslice - 1) / nslice;                        // tiles per slice, a multiple of 4
+    tps = (tps + DVQ_RES_WAVES - 1) / DVQ_RES_WAVES * DVQ_RES_WAVES;
+    const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
+    const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
+    bool not_last;
+    const double tot = resolve_chunk<D, FOLD, false>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, zq, codes, counters,
+                                                     exact_list, records, nslice, chunk_sync + 2 * blockIdx.x, h_spill, cv, nullptr,
+                                                     partials != nullptr, &not_last);
+    if (!not_last && partials != nullptr && threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The consumer role of the fused form (see DvqFuse): workgroup j of the `ncons` behind the token blocks serves queue shard
+// j % 64, chunks j / 64, j / 64 + ncons / 64, ... of it.  One wave polls (sc1 loads, s_sleep between polls); a chunk is taken
+// when its 32 slots are reserved and stamped, or -- once every token block has signalled DONE, which makes the reservation
+// count final -- with whatever it holds.  A consumer leaves after the shard's last (partial or empty) chunk.  The consumer that
+// leaves last fills the mailbox for the list kernel and zeroes the live counters.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool FOLD>
+__device__ __forceinline__ void resolve_consumer(
+    char *__restrict__ L, const int j, const char *__restrict__ img32, const float *__restrict__ E, int HW, int K,
+    int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
+    const DvqConv &cv, const DvqFuse &fz, const bool want_loss)
+{
+    using LL = ResLds<D>;
+    int *misc = (int *)(L + LL::MISC);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int shard = j & (DVQ_QSHARDS - 1), cps = fz.ncons / DVQ_QSHARDS;
+    const int T = dvq_num_tiles(K);
+    double mysum = 0.0;                                         // thread 0: this consumer's loss correction
+    DVQ_CLK(0);
+    int nchunk = 0;
+    for (int q = j / DVQ_QSHARDS;; q += cps, ++nchunk) {
+        if (wave == 0) {
+            int nlive, done;
+            for (;;) {
+                done = ld_sc1(&counters[DVQ_C_DONE]);           // DONE first: if it reads nb1, the count read after it is final
+                int r = ld_sc1(&counters[DVQ_QCOUNT0 + shard]);
+                r = r < rec_cap ? r : rec_cap;
+                nlive = r - q * RES_SLOTS;
+                nlive = nlive < 0 ? 0 : (nlive > RES_SLOTS ? RES_SLOTS : nlive);
+                if (nlive == RES_SLOTS || done == fz.nb1) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            // the stamps of the chunk's live slots (a reserved record is stamped once it has been written through)
+            const int *st = fz.stamps + shard * rec_cap + q * RES_SLOTS;
+            while (nlive > 0) {
+                const bool ok = (lane >= nlive) || ld_sc1(st + (lane < nlive ? lane : 0)) != 0;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (lane == 0) { misc[4] = nlive; misc[5] = (nlive < RES_SLOTS); }
+        }
+        __syncthreads();                                        // (also the barrier between the poll and every wave's record loads)
+        const int nlive = misc[4];
+        const bool last = misc[5] != 0;
+        DVQ_CLK(2 + 7 * nchunk);
+        DVQ_CLKV(2 + 7 * nchunk + 5, nlive);
+        if (nlive > 0) {
+            bool not_last;
+            const int base = shard * rec_cap + q * RES_SLOTS;
+            const double t = resolve_chunk<D, FOLD, true>(L, base, nlive, 0, T, img32, fz.en_all, E, HW, nullptr, nullptr, counters,
+                                                          exact_list, records, 1, nullptr, fz.h_spill, cv, fz.rewrites, want_loss,
+                                                          &not_last, 2 + 7 * nchunk);
+            DVQ_CLK(2 + 7 * nchunk + 4);
+            if (tid == 0) mysum += t;
+            if (tid < nlive) fz.stamps[base + tid] = 0;         // (read again only by the next op's consumers, behind a kernel boundary)
+        }
+        __syncthreads();                                        // misc / the record area are free for the next chunk
+        if (last) break;
+    }
+    DVQ_CLK(1);
+    if (tid == 0) {
+        if (fz.cons_partials != nullptr) fz.cons_partials[j] = mysum;
+        // exit ticket: every append of this workgroup to the exact / rewrite lists has returned (its index was used)
+        const int t = __hip_atomic_fetch_add(&counters[DVQ_C_CONS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == fz.ncons - 1) {
+            int queued = 0;
+            for (int i = 0; i < DVQ_QSHARDS; ++i) {
+                const int v = ld_sc1(&counters[DVQ_QCOUNT0 + i]);
+                queued += v < rec_cap ? v : rec_cap;
+            }
+            counters[DVQ_C_MAIL + 0] = ld_sc1(&counters[DVQ_C_EXACT]);
+            counters[DVQ_C_MAIL + 1] = ld_sc1(&counters[DVQ_C_NREW]);
+            counters[DVQ_C_MAIL + 2] = queued;
+            for (int i = 0; i < DVQ_QSHARDS; ++i) counters[DVQ_QCOUNT0 + i] = 0;
+            counters[DVQ_C_EXACT] = 0;
+            counters[DVQ_C_DONE] = 0;
+            counters[DVQ_C_CONS] = 0;
+            counters[DVQ_C_NREW] = 0;
+        }
+    }
+}
+
+template <int D, int SEL, bool CONV, bool FOLD = false>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv, const DvqFuse fz)
+{
+    if ((int)blockIdx.x >= fz.nb1) {                         // consumer workgroup of the fused form
+        extern __shared__ __attribute__((aligned(16))) char lds_c[];
+        resolve_consumer<D, FOLD>(lds_c, (int)blockIdx.x - fz.nb1, fz.img32, E, HW, K, counters, exact_list, records, rec_cap, cv, fz,
+                                  partials != nullptr);
+        return;
+    }
+    pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv, fz);
+}
+
+// the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
+template <int D, int SEL, bool FOLD>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv, const DvqFuse fz)
+{
+    if ((int)blockIdx.x >= fz.nb1) {
+        extern __shared__ __attribute__((aligned(16))) char lds_c[];
+        resolve_consumer<D, FOLD>(lds_c, (int)blockIdx.x - fz.nb1, fz.img32, E, HW, K, counters, exact_list, records, rec_cap, cv, fz,
+                                  partials != nullptr);
+        return;
+    }
+    pass1_body<D, SEL, false, FOLD, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv, fz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1826,12 +2093,14 @@ int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep,
     return (int)hipGetLastError();
 }
 
-// counters (ints): [0] queued total (written by the last kernel, for dvq_vq_assign_fallback_count_offset),
-// [1] exact-list count, [4] finalize ticket, [5] prepass ticket, [DVQ_QCOUNT0 ..] per-shard queue counts
-__global__ void zero_counters_kernel(int *__restrict__ counters, int *__restrict__ chunk_sync, int nsync)
+// The op's counter block (dvq_common.h: DVQ_C_*), the sliced resolver's chunk tickets and -- fused form on a workspace the caller
+// did not declare clean -- the record stamps.  In the steady state of the fused form nobody launches this: the op's last consumer
+// workgroup leaves every live word zero (DVQ_MODE_WS_CLEAN, dvq.h).
+__global__ void zero_counters_kernel(int *__restrict__ counters, int nwords, int *__restrict__ stamps, int nstamps)
 {
-    for (int i = threadIdx.x; i < DVQ_COUNTER_BYTES / 4; i += blockDim.x) counters[i] = 0;
-    for (int i = threadIdx.x; i < nsync; i += blockDim.x) chunk_sync[i] = 0;      // sliced resolver only
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (int i = i0; i < nwords; i += step) counters[i] = 0;      // counter block + (sliced resolver) chunk_sync, contiguous
+    for (int i = i0; i < nstamps; i += step) stamps[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1848,6 +2117,7 @@ struct DvqTune {
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
     int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
+    int cps;             // fused form: consumer workgroups per queue shard, 0 = by token count
 };
 #ifndef DVQ_PIPE_DEFAULT
 #define DVQ_PIPE_DEFAULT 0
@@ -1857,12 +2127,13 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
+static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 0};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
     else if (!strcmp(key, "pipe")) g_tune.pipe = value;
+    else if (!strcmp(key, "cps")) g_tune.cps = value;
     else return -1;
     return 0;
 }
@@ -1870,11 +2141,12 @@ extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char 
 // 2W, code.  (The first argument was round 3's clock-stamp buffer; it is ignored.)
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *stamps, void *tokdbg)
 {
-    (void)stamps;
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_clk), &stamps, sizeof(void *));
+    if (rc) return rc;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
+static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 0};
 #endif
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
@@ -1904,13 +2176,14 @@ static int resolver_slices(int K)
     return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
 }
 
-// ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk]
-//           [exact list N ints][records cap * rec_bytes]
+// ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk][stamps: 1 int per record]
+//           [exact list N ints][rewrite list: 2 ints per record][records cap * rec_bytes]
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
-    return DVQ_COUNTER_BYTES + align256((size_t)rec_capacity(N) / RES_SLOTS * 2 * sizeof(int)) +
-           align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
+    const size_t cap = (size_t)rec_capacity(N);
+    return DVQ_COUNTER_BYTES + align256(cap / RES_SLOTS * 2 * sizeof(int)) + align256(cap * sizeof(int)) +
+           align256((size_t)N * sizeof(int)) + align256(cap * 2 * sizeof(int)) + align256(cap * rec_bytes(D));
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -1947,7 +2220,7 @@ int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr,
                               long long *indices, float *cmask, long long *gate_out, hipStream_t st);
 
 struct FilterWs {
-    int *counters, *chunk_sync, *exact_list;
+    int *counters, *chunk_sync, *stamps, *exact_list, *rewrites;
     char *records;
     int cap;
 };
@@ -1955,12 +2228,14 @@ struct FilterWs {
 static FilterWs carve_ws(void *ws_extra, long N, int D)
 {
     FilterWs w;
-    w.counters = (int *)ws_extra;
+    char *p = (char *)ws_extra;
     w.cap = rec_capacity(N);
-    w.chunk_sync = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
-    const size_t sync_bytes = align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
-    w.exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
-    w.records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
+    w.counters = (int *)p;                       p += DVQ_COUNTER_BYTES;
+    w.chunk_sync = (int *)p;                     p += align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
+    w.stamps = (int *)p;                         p += align256((size_t)w.cap * sizeof(int));
+    w.exact_list = (int *)p;                     p += align256((size_t)N * sizeof(int));
+    w.rewrites = (int *)p;                       p += align256((size_t)w.cap * 2 * sizeof(int));
+    w.records = p;
     (void)D;
     return w;
 }
@@ -1975,15 +2250,37 @@ static bool staged_select_ok(const DvqRouted &rv)
     return true;
 }
 
+// consumer workgroups of the fused form: a multiple of the 64 queue shards -- 1 / 2 / 4 / 8 per shard by the number of tokens, so
+// that every chunk of a shard has a workgroup of its own (a shard collects ~N / 1800 records at the usual 3 - 4 % undecided
+// tokens, 32 to a chunk, plus the partial last one: the tail of the op is ONE chunk's latency, not two in a row) -- and never more
+// than the chip has slots for this kernel (two per CU)
+static int fused_consumers(long N)
+{
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    int cps = N >= 131072 ? 8 : (N >= 32768 ? 4 : (N >= 8192 ? 2 : 1));
+    if (g_tune.cps >= 1 && g_tune.cps <= 16) cps = g_tune.cps;
+    while (cps > 1 && cps * DVQ_QSHARDS > 2 * n) cps >>= 1;
+    return cps * DVQ_QSHARDS;
+}
+
 template <int D, int SEL, bool CONV = false, bool FOLD = false>
 static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta *meta, const float *E,
                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
                              double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st,
-                             const DvqConv &cv = DvqConv{})
+                             const DvqConv &cv, DvqFuse fz)
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
-    const unsigned grid = (unsigned)((N + 127) / 128);
+    static_assert(ResLds<D>::BYTES <= 4 * (D / 16) * 1024 + 4 * 4 * 64 * 4 + 4 * 2048, "the consumer role's LDS is a carve of pass 1's");
+    fz.nb1 = (int)((N + 127) / 128);
+    const unsigned grid = (unsigned)(fz.nb1 + fz.ncons);     // consumer workgroups (fused form) behind the token blocks
     if constexpr (D == 256 && !CONV && SEL != 1) {
         // a batch whose features fit the memory-side cache (with room for what else is live): plain loads instead of non-temporal ones
         if ((size_t)N * D * sizeof(float) <= DVQ_CACHED_MAX_BYTES) {
@@ -1992,7 +2289,7 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
             if (rcc) return rcc;
             hipLaunchKernelGGL((vq_assign_filter_cached_kernel<D, SEL, FOLD>), dim3(grid), dim3(256), shmem1, st,
                                z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                               w.cap / DVQ_QSHARDS, rv, cv);
+                               w.cap / DVQ_QSHARDS, rv, cv, fz);
             return (int)hipGetLastError();
         }
     }
@@ -2000,32 +2297,43 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
     if (rc) return rc;
     hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV, FOLD>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, rv, cv);
+                       w.cap / DVQ_QSHARDS, rv, cv, fz);
     return (int)hipGetLastError();
+}
+
+// does pass 1 of this op go through vq_assign_filter_kernel (whose grid can carry the resolver as consumer workgroups)?
+static bool pass1_is_fusable(int D, int K, long N, bool force_wide, const DvqRouted *rv, const DvqConv *cv, bool fold)
+{
+    if (resolver_slices(K) > 1) return false;                // sliced resolver (large codebooks): a launch of its own
+#ifdef DVQ_TUNING
+    if (g_tune.pipe && !fold && cv == nullptr) return false; // the persistent pass-1 form (tuning build) has no consumer role
+#endif
+    if (fold || cv != nullptr || rv != nullptr) return true;
+    return !(D == 256 && (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)));
 }
 
 template <int D>
 static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                         const float *mask, int HW, int K, long N, float *zq, long long *codes,
                         double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
-                        hipStream_t st, const DvqConv *cv = nullptr, bool fold = false)
+                        hipStream_t st, const DvqConv *cv, const DvqConv *fold_cv, const DvqFuse &fz)
 {
     const int nb1 = (int)((N + 127) / 128);
     const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
-    if (fold) {                                              // img / meta: the folded codebook; z (or the branches): the conv's input
-        const DvqRouted none = {};
+    const DvqRouted none = {};
+    const DvqConv nocv = {};
+    if (fold_cv != nullptr) {                                // img / meta: the folded codebook; z (or the branches): the conv's input
         if (rv == nullptr)
-            return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
+            return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *fold_cv, fz);
         if (staged_select_ok(*rv))
-            return launch_pass1_form<D, 2, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
-        return launch_pass1_form<D, 1, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+            return launch_pass1_form<D, 2, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv, fz);
+        return launch_pass1_form<D, 1, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv, fz);
     }
     if (cv != nullptr) {                                     // the 1x1 conv as the prologue (D = 256; the ABI layer checked)
         if constexpr (D == 256) {
-            const DvqRouted none = {};
             if (rv != nullptr)
-                return launch_pass1_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *cv);
-            return launch_pass1_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *cv);
+                return launch_pass1_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *cv, fz);
+            return launch_pass1_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *cv, fz);
         } else {
             return -1000;
         }
@@ -2038,8 +2346,8 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
 #endif
     if (rv != nullptr) {                                     // select fused in
         if (staged_select_ok(*rv))
-            return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
-        return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st);
+            return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv, fz);
+        return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv, fz);
     }
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
@@ -2055,45 +2363,48 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
             return (int)hipGetLastError();
         }
     }
-    const DvqRouted none = {};
-    return launch_pass1_form<D, 0>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st);
+    return launch_pass1_form<D, 0>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, nocv, fz);
 }
 
 template <int D>
 static int launch_resolver(const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
-                           const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                           const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st)
+                           int HWout, int K, float *zq, long long *codes, double *partials,
+                           const FilterWs &w, float *h_spill, const DvqFold *fd, hipStream_t st)
 {
     const int nslice = resolver_slices(K);
     if (fd != nullptr)
         hipLaunchKernelGGL((vq_resolve_kernel<D, true>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
-                           meta, en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, fd->cv);
+                           meta, en_all, E, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, h_spill, fd->cv);
     else
         hipLaunchKernelGGL((vq_resolve_kernel<D, false>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
-                           meta, en_all, E, mask, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, DvqConv{});
+                           meta, en_all, E, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, h_spill, DvqConv{});
     return (int)hipGetLastError();
 }
 
 static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
-                             const float *mask, int HWout, int K, float *zq, long long *codes, double *partials,
-                             const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st)
+                             int HWout, int K, float *zq, long long *codes, double *partials,
+                             const FilterWs &w, float *h_spill, const DvqFold *fd, hipStream_t st)
 {
     switch (D) {
-    case 64:  return launch_resolver<64>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
-    case 128: return launch_resolver<128>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
-    case 256: return launch_resolver<256>(img, meta, en_all, E, mask, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st);
+    case 64:  return launch_resolver<64>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
+    case 128: return launch_resolver<128>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
+    case 256: return launch_resolver<256>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
     default:  return -1000;
     }
 }
 
 // Dense op: z [B, D, HW].  Routed op (rv != nullptr): one token per output position of rv (the select fused into
 // pass 1); N = B * HWout, mask = the codebook_mask pass 1 writes.
+// Kernels of one op.  Fused form (codebooks up to 2048 codes through vq_assign_filter_kernel, i.e. every reference config):
+//   [zero kernel unless ws_clean] -> pass 1 + resolver (consumer workgroups of the same grid) -> list kernel (rewrites the
+//   consumers decided, exact list, loss finalize);
+// otherwise: zero kernel -> pass 1 -> resolver -> list kernel.
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
-                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd)
+                      const DvqRouted *rv, hipStream_t st, const DvqConv *cv, const DvqFold *fd, bool ws_clean)
 {
     char *base = (char *)prep + dvq_prep_f16_offset(K, D);
     base = (char *)(((uintptr_t)base + 255) / 256 * 256);
@@ -2104,40 +2415,70 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     const FilterWs w = carve_ws(ws_extra, N, D);
     const bool routed = rv != nullptr;
-    // A kernel rather than hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of
-    // kernel nodes under hipGraph capture.
-    hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(256), 0, st, w.counters, w.chunk_sync,
-                       resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
+    const int HWout = routed ? rv->HWout : HW;
+    float *h_spill = (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr;   // (h_all: pass 1 already wrote every token's row)
     const int np1 = (int)((N + 127) / 128);
+    const bool fused = !pass1_only && pass1_is_fusable(D, K, N, force_wide, rv, cv, fd != nullptr);
+    DvqFuse fz = {};
+    if (fused) {
+        fz.ncons = fused_consumers(N);
+        fz.stamps = w.stamps;
+        fz.rewrites = w.rewrites;
+        fz.en_all = en_all;
+        fz.img32 = img;
+        fz.h_spill = h_spill;
+        fz.cons_partials = partials ? partials + np1 : nullptr;
+    }
+    if (!(fused && ws_clean)) {
+        // A kernel rather than hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of
+        // kernel nodes under hipGraph capture.
+        const int nwords = DVQ_COUNTER_BYTES / 4 + (resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
+        const int nstamps = fused ? w.cap : 0;
+        hipLaunchKernelGGL(zero_counters_kernel, dim3(nstamps ? 32 : 1), dim3(256), 0, st, w.counters, nwords, w.stamps, nstamps);
+        int rc0 = (int)hipGetLastError();
+        if (rc0) return rc0;
+    }
+    int rc;
+    const DvqConv *fold_cv = fd ? &fd->cv : nullptr;
     switch (D) {
-    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
-    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
-    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fd != nullptr); break;
+    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
+    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
+    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;
-    const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
-    // (h_all: pass 1 already wrote every token's row)
-    rc = launch_resolver_d(D, img, meta, en_all, E, mask, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
-                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, fd, st);
-    if (rc) return rc;
-    double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
+    // partials layout: [pass 1: np1][fused: ncons consumers | unfused: one per resolver chunk][list kernel blocks]
+    const int nres = fused ? fz.ncons : w.cap / RES_SLOTS;
+    if (!fused) {
+        rc = launch_resolver_d(D, img, meta, en_all, E, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
+                               w, h_spill, fd, st);
+        if (rc) return rc;
+    }
+    double *partials3 = partials ? partials + np1 + nres : nullptr;
     // the list kernel is the last of the op: it also sums all partials into loss[0..1]
-    const DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + 4,
-                              np1 + w.cap / RES_SLOTS + list_blocks(N),
-                              1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS};
+    DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + DVQ_C_TICKET,
+                        np1 + nres + list_blocks(N),
+                        1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS,
+                        nullptr, nullptr, nullptr, 0, 0};
+    const int *list_count = w.counters + DVQ_C_EXACT;
+    if (fused) {
+        tail.mail = w.counters + DVQ_C_MAIL;
+        tail.rewrites = w.rewrites;
+        tail.records = w.records;
+        tail.rec_bytes = (int)rec_bytes(D);
+        tail.fold = fd != nullptr;
+        list_count = tail.mail;                              // (the live counter is zero again by then)
+    }
     // conv folded in: the list kernel computes its tokens' h itself, from the conv's input (dense z or the branches)
     if (fd != nullptr)
         return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
-                                     w.exact_list, w.counters + 1, tail, rv, st, &fd->cv);
+                                     w.exact_list, list_count, tail, rv, st, &fd->cv);
     // conv fused in: the tokens on the list have their conv output in cv->h_buf (dense layout), written by pass 1
     if (cv != nullptr)
         return dvq_launch_exact_list(cv->h_buf, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
-                                     w.exact_list, w.counters + 1, tail, nullptr, st);
+                                     w.exact_list, list_count, tail, nullptr, st);
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
-                                 w.exact_list, w.counters + 1, tail, rv, st);
+                                 w.exact_list, list_count, tail, rv, st);
 }
 
 // ---- routed op ---------------------------------------------------------------------------------
@@ -2155,7 +2496,7 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
                       int B, int D, int hc, int wc, int K, float beta, float *zq, long long *codes,
                       float *loss, long long *indices, float *cmask, long long *gate_out,
                       double *partials, void *ws_extra, bool exact, bool pass1_only, hipStream_t st, const DvqConv *cv,
-                      const DvqFold *fd)
+                      const DvqFold *fd, bool ws_clean)
 {
     const int SC = (G == 2) ? 2 : 4;
     const int Wout = SC * wc, HWout = SC * hc * Wout;
@@ -2184,5 +2525,5 @@ int dvq_launch_routed(int G, int gate_mode, const void *gate, float thr, const f
         return dvq_launch_loss_finalize(partials, (int)((N + 127) / 128), 1.0 / ((double)N * D), beta, loss, st);
     }
     return dvq_launch_filter(nullptr, prep, E, cmask, D, HWout, K, N, zq, codes, partials, ws_extra, pass1_only, false,
-                             loss, beta, &rv, st, cv, fd);
+                             loss, beta, &rv, st, cv, fd, ws_clean);
 }

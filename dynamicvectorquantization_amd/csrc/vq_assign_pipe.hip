@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 if (slot >= a.rec_cap) { hopeless = true; slot = -1; }          // shard full -> exact list
             }
             if (hopeless && h == 0) {
-                int pos = atomicAdd(&a.counters[1], 1);
+                int pos = atomicAdd(&a.counters[DVQ_C_EXACT], 1);
                 a.exact_list[pos] = tok_n;
             }
             if (slot >= 0) {
@@ -342,8 +342,9 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                 }
                 if (h == 0) {
                     RecMeta rm;
-                    rm.n = tok_n; rm.xn = xn; rm.thr = thr; rm.tokid = tok_n; rm.prov = code;
-                    rm.best = ~0ull; rm.rep = 1;
+                    rm.n = tok_n; rm.xn = xn; rm.thr = thr; rm.prov = code;
+                    rm.m = (SEL != 0) ? sel_mask : ((a.mask != nullptr) ? a.mask[tok_n] : 1.0f);
+                    rm.best = ~0ull; rm.pad = 0;
                     *(RecMeta *)(rec + (size_t)D * 4) = rm;
                 }
             }

@@ -24,6 +24,35 @@ from . import _lib
 _lib_handle = _lib.lib
 
 
+class _Workspace:
+    """One workspace of the filter-path ops (loss partials, queue counters, record stamps, lists, records) and whether it is
+    CLEAN: zero-filled at allocation, and every filter-path op leaves it clean again (its last consumer workgroup puts the live
+    counters back to zero), so the steady state passes `DVQ_MODE_WS_CLEAN` and no zeroing kernel is launched (include/dvq.h).
+    `begin` marks it dirty until `end` has seen the call return DVQ_OK; the profiling mode MODE_FILTER_PASS1 leaves it dirty."""
+    __slots__ = ("t", "clean")
+
+    def __init__(self, nbytes, device):
+        self.t = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=device)
+        self.clean = True
+
+    def begin(self, mode):
+        """-> (pointer, bytes, mode [| MODE_WS_CLEAN]) for the ABI call"""
+        flag = _lib.MODE_WS_CLEAN if (self.clean and _lib.HAS_WS_CLEAN and mode in _lib.FILTER_MODES) else 0
+        self.clean = False
+        return self.t.data_ptr(), self.t.numel(), mode | flag
+
+    def end(self, mode):
+        self.clean = mode in (_lib.MODE_FILTER, _lib.MODE_FILTER_WIDE)
+
+    def check(self, mode, rc, what):
+        """ws.check(mode, lib.fn(..., *ws.begin(mode), ...), "fn"): raises on failure (the workspace then stays dirty)"""
+        _lib.check(rc, what)
+        self.end(mode)
+
+    def __getitem__(self, sl):                      # (fallback_count reads two counters)
+        return self.t[sl]
+
+
 class _CodebookPrep:
     """Per-codebook device buffers of the assign kernels (tile images, exact norms), rebuilt
     whenever the codebook tensor changes: the key is (storage, autograd version, shape, device),
@@ -144,7 +173,7 @@ class _CodebookPrep:
                 nbytes = _lib_handle.dvq_vq_assign_workspace_bytes(B, D, HW, K, mode)
             if len(self._ws) >= 8:                   # shapes rarely change: keep the table small
                 self._ws.clear()
-            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            ws = _Workspace(nbytes, device)
             self._ws[key] = ws
         self._last_ws = (key, ws)
         return ws
@@ -248,24 +277,24 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
     if fold:
         with torch.cuda.device(z.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
-            _lib.check(_lib_handle.dvq_vq_assign_fold_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_fold_f32(
                 z.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), B, D, HW, K,
-                _lib.ptr(zq), codes.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(z.device)), "dvq_vq_assign_fold_f32")
+                _lib.ptr(zq), codes.data_ptr(), *ws.begin(mode), _lib.stream_ptr(z.device)), "dvq_vq_assign_fold_f32")
         return zq, codes, loss
     if conv is not None:
         with torch.cuda.device(z.device):
             qbuf, hb, h_all = _conv_args(conv, prep, z.shape, z.device, h_buf)
             pbuf = prep.get(codebook)
-            _lib.check(_lib_handle.dvq_vq_assign_qconv_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_qconv_f32(
                 z.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
-                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(), mode,
+                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), hb.data_ptr(), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(z.device)), "dvq_vq_assign_qconv_f32")
         return zq, codes, loss
     with torch.cuda.device(z.device):
         pbuf = prep.get(codebook)
-        _lib.check(_lib_handle.dvq_vq_assign_nchw_f32(
+        ws.check(mode, _lib_handle.dvq_vq_assign_nchw_f32(
             z.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
-            _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), ws.data_ptr(), ws.numel(), mode,
+            _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), *ws.begin(mode),
             _lib.stream_ptr(z.device)), "dvq_vq_assign_nchw_f32")
     return zq, codes, loss
 
@@ -341,28 +370,28 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
     if fold:                                     # the conv folded into the codebook (see vq_assign): codes [+ z_q], no loss
         with torch.cuda.device(h_fine.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
-            _lib.check(_lib_handle.dvq_vq_assign_routed_fold_dual_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_routed_fold_dual_f32(
                 g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(),
                 codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, _lib.ptr(zq), codes.data_ptr(), indices.data_ptr(),
-                cmask.data_ptr(), _lib.ptr(gate_out), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+                cmask.data_ptr(), _lib.ptr(gate_out), *ws.begin(mode), _lib.stream_ptr(h_fine.device)),
                 "dvq_vq_assign_routed_fold_dual_f32")
         return res
     if conv is not None:
         with torch.cuda.device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
             pbuf = prep.get(codebook)
-            _lib.check(_lib_handle.dvq_vq_assign_routed_qconv_dual_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_dual_f32(
                 g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(),
                 pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss),
-                indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(),
-                mode, _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_dual_f32")
+                indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), hb.data_ptr(), int(h_all), *ws.begin(mode),
+                _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_dual_f32")
         return res
     with torch.cuda.device(h_fine.device):
         pbuf = prep.get(codebook)
-        _lib.check(_lib_handle.dvq_vq_assign_routed_dual_f32(
+        ws.check(mode, _lib_handle.dvq_vq_assign_routed_dual_f32(
             g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(),
             B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), indices.data_ptr(),
-            cmask.data_ptr(), _lib.ptr(gate_out), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+            cmask.data_ptr(), _lib.ptr(gate_out), *ws.begin(mode), _lib.stream_ptr(h_fine.device)),
             "dvq_vq_assign_routed_dual_f32")
     return res
 
@@ -402,28 +431,28 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
     if fold:
         with torch.cuda.device(h_fine.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
-            _lib.check(_lib_handle.dvq_vq_assign_routed_fold_triple_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_routed_fold_triple_f32(
                 g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
                 fbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, _lib.ptr(zq), codes.data_ptr(),
-                indices.data_ptr(), cmask.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+                indices.data_ptr(), cmask.data_ptr(), *ws.begin(mode), _lib.stream_ptr(h_fine.device)),
                 "dvq_vq_assign_routed_fold_triple_f32")
         return res
     if conv is not None:
         with torch.cuda.device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
             pbuf = prep.get(codebook)
-            _lib.check(_lib_handle.dvq_vq_assign_routed_qconv_triple_f32(
+            ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_triple_f32(
                 g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
                 codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(),
-                _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), hb.data_ptr(), int(h_all), ws.data_ptr(), ws.numel(),
-                mode, _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_triple_f32")
+                _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), hb.data_ptr(), int(h_all), *ws.begin(mode),
+                _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_triple_f32")
         return res
     with torch.cuda.device(h_fine.device):
         pbuf = prep.get(codebook)
-        _lib.check(_lib_handle.dvq_vq_assign_routed_triple_f32(
+        ws.check(mode, _lib_handle.dvq_vq_assign_routed_triple_f32(
             g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(),
             pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss),
-            indices.data_ptr(), cmask.data_ptr(), ws.data_ptr(), ws.numel(), mode, _lib.stream_ptr(h_fine.device)),
+            indices.data_ptr(), cmask.data_ptr(), *ws.begin(mode), _lib.stream_ptr(h_fine.device)),
             "dvq_vq_assign_routed_triple_f32")
     return res
 

@@ -51,6 +51,14 @@ extern "C" {
                                  /* forced (D = 256); normally chosen automatically for K >= 2048 and       */
                                  /* >= 131072 tokens.  Same output.                                         */
 
+/* Flag, OR-ed into `mode` of the filter-path ops (every dvq_vq_assign_* entry point; ignored in DVQ_MODE_EXACT): the caller
+ * guarantees that this workspace is CLEAN -- it was zero-filled when it was allocated (hipMemsetAsync / torch.zeros over
+ * its whole size), or the last call that used it was a filter-path op WITHOUT DVQ_MODE_FILTER_PASS1 that returned DVQ_OK --
+ * and that no other stream is using it.  A filter-path op leaves its workspace clean (its last consumer workgroup puts every
+ * live counter back to zero), so with the flag no zeroing kernel is launched: one kernel boundary (~5 us) less per op.
+ * Without the flag the op zeroes what it needs first and any bytes are fine (the behaviour of earlier versions). */
+#define DVQ_MODE_WS_CLEAN 0x100
+
 /* gate kinds for the router select / routed assign */
 #define DVQ_GATE_F32 0      /* float32 gate logits [.., G]                                      */
 #define DVQ_GATE_I64 1      /* int64 gate [.., G] (what DualGrainFixedEntropyRouter returns)    */
