@@ -105,31 +105,19 @@ struct DvqLossTail {
     float beta;
     int *counters;            // nullptr = no queue bookkeeping; else counters[0] = total queued tokens
     int shard_cap;
-    // fused form (vq_assign_filter.hip: the resolver runs as consumer workgroups of pass 1's grid): the list kernel first applies
-    // the (token, winner) rewrites those consumers decided -- they must not overwrite z_q / codes lines that another XCD's L2
-    // still holds dirty from pass 1 in the same launch -- and reads its counts from the mailbox instead of the live counters
-    const int *mail;          // nullptr = unfused
-    const int *rewrites;      // [count][2]: record index, winning code
-    const char *records;
-    int rec_bytes;
-    int fold;                 // z_q := codebook[code] (conv-folded forms)
 };
 #define DVQ_QSHARDS 64        // the pass-1 -> resolver queue is sharded this many ways (power of two)
 #define DVQ_QCOUNT0 8         // counters[DVQ_QCOUNT0 + shard] = tokens queued in that shard
 #define DVQ_COUNTER_BYTES 512
 // The counter block (ints) at the start of the filter path's workspace.  "report" words are only ever overwritten (what
-// dvq_vq_assign_fallback_count_offset points at); "live" words are zero between ops: the op's last consumer workgroup (fused
-// form) or the zero kernel in front of the op (every other form) puts them back.
+// dvq_vq_assign_fallback_count_offset points at); "live" words are zero between ops: the list kernel's finishing workgroup puts
+// them back (so does each chunk's last resolver slice with its ticket pair), and the zero kernel in front of the op is only
+// launched for a caller that does not declare the workspace clean (DVQ_MODE_WS_CLEAN).
 #define DVQ_C_QUEUED   0      // report: tokens queued for the resolver
 #define DVQ_C_NEXACT   1      // report: tokens handed to the exact list
 #define DVQ_C_EXACT    2      // live: exact-list append counter
-#define DVQ_C_DONE     3      // live: pass-1 workgroups that have published all their records (fused form)
-#define DVQ_C_TICKET   4      // live: finalize ticket of the list kernel (reset by its last workgroup)
+#define DVQ_C_TICKET   4      // live: finalize ticket of the list kernel
 #define DVQ_C_PREPASS  5
-#define DVQ_C_CONS     6      // live: exit ticket of the consumer workgroups (fused form)
-#define DVQ_C_NREW     7      // live: rewrite-list append counter (fused form)
-#define DVQ_C_MAIL     80     // mailbox the fused kernel's last consumer leaves for the list kernel, which only reads it:
-                              //   [+0] exact-list count, [+1] rewrite count, [+2] queued total
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
 // gate just read -- above it with the non-temporal hint.  profiles/r04_cache_policy.json: one batch at a time, plain loads pay up to

@@ -29,7 +29,9 @@ __host__ __device__ inline size_t rec_bytes(int D) { return (size_t)D * 4 + 32; 
 //   m:    the token's loss weight (codebook_mask value; the resolver must not read the mask tensor: in the routed op pass 1
 //         writes it in the same launch)
 //   best: merged (distance, code) key of the sliced resolver (large K), ~0 = none yet; written ~0 by pass 1
-struct RecMeta { int n; float xn; float thr; float m; unsigned long long best; int prov; int pad; };   // 32 B
+//   rep:  the token stands for rep x rep output positions (n = the first; rows Wout apart): the copies of one coarse-cell vector
+//         in the routed op, which all get the resolver's correction
+struct RecMeta { int n; float xn; float thr; float m; unsigned long long best; int prov; int rep; };   // 32 B
 
 // The bound W on |G - truth| (derivation: header of vq_assign_filter.hip);
 // returns 2 W (1 + margin), NaN for a token the fp16 path cannot score.

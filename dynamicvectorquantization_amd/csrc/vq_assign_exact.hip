@@ -48,30 +48,6 @@ __global__ __launch_bounds__(256, FOLDCONV ? 1 : 2) void vq_assign_exact_kernel(
     // tokens: the dense range [0, N) (one 128-token chunk per block), or (pass 2 of the filter path)
     // the entries of a work list, which a small grid walks in 128-entry chunks
     const int cnt = LIST ? *list_count : 0;
-    if constexpr (LIST) {
-        // fused form (DvqFuse, vq_assign_filter.hip): the resolver's consumer workgroups ran inside pass 1's launch and left
-        // the winners that differ from pass 1's provisional codes as (record, code) pairs; z_q / codes are corrected HERE,
-        // behind the kernel boundary (every provisional line has left the XCD L2s by now).  One wave per pair.
-        if (tail.mail != nullptr) {
-            const int nrew = tail.mail[1];
-            for (int e = (int)blockIdx.x * 4 + wave; e < nrew; e += (int)gridDim.x * 4) {
-                const int ri = tail.rewrites[2 * e], win = tail.rewrites[2 * e + 1];
-                const char *r2 = tail.records + (size_t)ri * tail.rec_bytes;
-                const long n = ((const RecMeta *)(r2 + (size_t)D * 4))->n;
-                const long bimg = n / HW;
-                const int hw = (int)(n - bimg * HW);
-                if (zq != nullptr)
-                    for (int k0 = lane * 4; k0 < D; k0 += 256) {
-                        const f32x4 zv = *(const f32x4 *)(r2 + k0 * 4);
-                        const f32x4 en_ = *(const f32x4 *)(E + (size_t)win * D + k0);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            zq[((size_t)bimg * D + k0 + j) * HW + hw] = tail.fold ? en_[j] : __fadd_rn(zv[j], __fsub_rn(en_[j], zv[j]));
-                    }
-                if (lane == 0) codes[n] = (long long)win;
-            }
-        }
-    }
     // list mode: only the blocks that have list entries take part (block 0 always does, it may have to
     // finalize on its own) -- an empty list costs one block, not a grid of ticket atomics
     int nwork = 1;
@@ -342,19 +318,22 @@ __global__ __launch_bounds__(256, FOLDCONV ? 1 : 2) void vq_assign_exact_kernel(
             }
         }
         __syncthreads();
-        if (*flag && tid == 0 && tail.counters != nullptr) {   // bookkeeping for dvq_vq_assign_fallback_count_offset
-            int q = 0;
-            if (tail.mail != nullptr) {
-                q = tail.mail[2];                              // (the live shard counters are zero again)
-            } else {
-                for (int i = 0; i < DVQ_QSHARDS; ++i) {
-                    int v = tail.counters[DVQ_QCOUNT0 + i];
-                    q += v < tail.shard_cap ? v : tail.shard_cap;
-                }
+        if (*flag && tid < DVQ_QSHARDS && tail.counters != nullptr) {
+            // bookkeeping for dvq_vq_assign_fallback_count_offset, and the counter block goes back to zero: this is the op's last
+            // workgroup (every workgroup that takes part has drawn its ticket, the others only ever read the list count, and
+            // with either value -- the count or the zero written here -- they leave at once), so the NEXT op on this workspace
+            // needs no zero kernel (DVQ_MODE_WS_CLEAN)
+            int v = tail.counters[DVQ_QCOUNT0 + tid];
+            v = v < tail.shard_cap ? v : tail.shard_cap;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            tail.counters[DVQ_QCOUNT0 + tid] = 0;
+            if (tid == 0) {
+                tail.counters[DVQ_C_QUEUED] = v;
+                tail.counters[DVQ_C_NEXACT] = cnt;
+                tail.counters[DVQ_C_EXACT] = 0;
+                *tail.ticket = 0;
             }
-            tail.counters[DVQ_C_QUEUED] = q;
-            tail.counters[DVQ_C_NEXACT] = cnt;
-            *tail.ticket = 0;                                  // the workspace is left clean (DVQ_MODE_WS_CLEAN)
         }
         if (*flag && tail.loss != nullptr) {
             __threadfence();
@@ -522,7 +501,7 @@ int dvq_launch_exact(const float *z, const float *prep, const float *E, const fl
                      int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                      const DvqRouted *rv, hipStream_t st)
 {
-    const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f, nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
+    const DvqLossTail none = {nullptr, nullptr, nullptr, 0, 0.0, 0.0f, nullptr, 0};
     return dvq_launch_exact_list(z, prep, E, mask, D, HW, K, N, zq, codes, partials, nullptr, nullptr, none, rv, st, nullptr);
 }
 

@@ -250,67 +250,12 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // diagnostic of the tuning build only: per-token (best, second, 2W, code) of the production arithmetic for the bound audit
 // (tools/bound_audit.py --production).  Written to a buffer of its own; no output value is computed from it.
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
-// ... and a timeline of the fused form: [block][16] s_memrealtime stamps (100 MHz), thread 0 of every workgroup.  Token blocks:
-// [0] entry, [1] exit.  Consumers: [0] entry, [1] exit, then per chunk c < 2 at [2 + 7c ..]: chunk ready (poll + stamps), records
-// in LDS, enumerated, exact chains done, chunk done, nlive, -; tools/fused_timeline.py reads it.
-__device__ unsigned long long *g_dvq_clk = nullptr;
-#define DVQ_CLK(slot) do { if (g_dvq_clk != nullptr && threadIdx.x == 0 && (slot) < 16) g_dvq_clk[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define DVQ_CLKV(slot, v) do { if (g_dvq_clk != nullptr && threadIdx.x == 0 && (slot) < 16) g_dvq_clk[(size_t)blockIdx.x * 16 + (slot)] = (unsigned long long)(v); } while (0)
-#else
-#define DVQ_CLK(slot) do { } while (0)
-#define DVQ_CLKV(slot, v) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// The fused form: the resolver runs INSIDE pass 1's launch, as `ncons` consumer workgroups appended to the grid (block
-// indices >= nb1; they are dispatched when the last generation of token blocks retires and take the slots it frees).
-// Hand-off of the queued tokens' records, producer -> consumer, inside one launch (MI355X_MICROARCH.md, "inter-workgroup
-// visibility"; per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
-//   producer   record payload + meta as 16-byte WRITE-THROUGH stores (sc1) -> every storing wave `s_waitcnt vmcnt(0)` ->
-//              workgroup barrier -> one sc1 "stamp" store per record (stamps[record index] = 1) and ONE agent-scope add to
-//              counters[DVQ_C_DONE] per workgroup.  The reservation of a record's slot (an agent-scope atomic on the shard's
-//              counter) happened long before.
-//   consumer   one wave polls with sc1 loads: DONE first, then the shard's reservation count (DONE == nb1 makes that count
-//              final), then the stamps of the 32 slots of its chunk; after a workgroup barrier every wave loads the records
-//              with sc1 16-byte loads.  No fence anywhere: nothing but sc1 traffic crosses workgroups.
-// Consumers never wait for other consumers and producers wait for nobody, so the launch cannot deadlock however its blocks are
-// dispatched as long as ncons workgroups cannot occupy every slot of the chip (ncons <= 256 at two workgroups per CU); the
-// hardware dispatches a grid in block order anyway, which is what makes the consumers arrive when they are needed.
-// What a consumer decides goes to LISTS the op's last kernel (the exact-list kernel) applies after the kernel boundary: a
-// (record, winning code) pair for every token whose exact winner differs from pass 1's provisional choice -- a consumer must not
-// store to z_q / codes itself: the provisional values may still sit dirty in another XCD's L2, whose write-back would land on top
-// of the correction -- and the tokens it cannot resolve (exact list).  The last consumer to leave (ticket) copies the list
-// counts to a mailbox and puts every live counter back to zero: the workspace is clean for the next op, no zero kernel needed.
-// ---------------------------------------------------------------------------------------------
-struct DvqFuse {
-    int ncons;                // consumer workgroups behind the nb1 token workgroups (0: unfused -- no stamps, no DONE)
-    int nb1;
-    int *stamps;              // [DVQ_QSHARDS * rec_cap], zero between ops
-    int *rewrites;            // [rec_capacity][2]
-    const float *en_all;
-    const char *img32;        // the 32x32x16-order code image the resolver enumerates on (pass 1 streams the 16x16x32 one)
-    float *h_spill;           // CONV: where the exact-list kernel reads its tokens' conv output from
-    double *cons_partials;    // [ncons] loss corrections of the consumers
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t dvq_rsrc(const void *p)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000);
-}
-// 16-byte / 4-byte accesses that carry sc1 (aux bit 4): write-through stores, L1-bypassing coherent loads
-__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16);
-}
-__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off)
-{
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16));
-}
-__device__ __forceinline__ int ld_sc1(const int *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
+// (Round 5 built the resolver INTO this launch -- consumer workgroups appended to the grid, records handed over with sc1
+// write-through stores / stamps / sc1 loads, decisions through a rewrite list -- bit-exact and slower: the consumers get slots only
+// when the last generation of token blocks retires, and what they do beside those blocks costs the blocks as much as it would cost
+// afterwards: profiles/r05_fused_consumers_negative.json; the code is in git history, commit "Fused form of the filter path".)
 // NT: the latents are read with the non-temporal hint (a launch streams more than the 256-MB memory-side cache holds: keep L2 for
 // the code image and the codebook rows) or with plain loads (vq_assign_filter_cached_kernel: a batch whose features FIT that cache
 // was just written by the encoder / read by the router gate, and plain loads are served from it: -6 % on the configs[3] per-GPU
@@ -321,7 +266,7 @@ __device__ __forceinline__ void pass1_body(
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv, const DvqFuse &fz)
+    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv)
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
@@ -343,7 +288,6 @@ __device__ __forceinline__ void pass1_body(
     const int T = dvq_num_tiles(K);
     const float sB = meta->scale_b;
     char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;   // this wave's permutation scratch
-    DVQ_CLK(0);
 
     // DMA of code tile t into its ring slot, in PER_TILE pieces (q < CPW: 1 KiB of the image, q == CPW:
     // this wave's copy of the seeds).  Past the end: harmless repeat, so the counts stay constant.
@@ -369,7 +313,7 @@ __device__ __forceinline__ void pass1_body(
 #pragma unroll
         for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
-    const int tile_id = xcd_swizzle(blockIdx.x, fz.nb1);    // (the grid may carry consumer workgroups behind the nb1 token blocks)
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
     // SEL == 2 parks the coarser branches in the ring slots from `pre` on: 2 slots = D x 128 B for the 2x-coarser
     // branch (dual: slots 2, 3; triple: slots 1, 2), slot 3 for the triple's 4x-coarser branch (D x 32 B)
     const int pre = (SEL == 2) ? ((rv.G == 2) ? 2 : 1) : 3;  // code tiles in flight before the prologue
@@ -399,7 +343,9 @@ __device__ __forceinline__ void pass1_body(
         return (unsigned)(tb - tb0) * 4u;
     };
     float zf[S16][8];
-    float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell
+    float sel_mask = 1.0f;                                   // SEL: the codebook_mask value of this lane's cell (1 / rep^2), NEGATED for
+                                                             // the copies of a coarser cell other than its first position (one register
+                                                             // through the code loop instead of two)
     int sel_g = 0;                                           // SEL == 2: grain of this lane's cell
     unsigned stg_a = 0, stg_b = 0;                           // SEL == 2: LDS byte address of this lane's value of channel 8h in the
                                                              // image of the 2x-coarser / 4x-coarser branch
@@ -576,6 +522,7 @@ __device__ __forceinline__ void pass1_body(
                     }
                 }
             }
+            if (!(y % rep_g == 0 && x % rep_g == 0)) sel_mask = -sel_mask;
         };
         if (SEL == 1) {
             const int g = dvq_gate_reduce(graw, rv.gate_mode, rv.G, rv.thr);
@@ -869,7 +816,12 @@ __device__ __forceinline__ void pass1_body(
     // by the number of undecided tokens), run the z_q / loss phase while it is in flight, and only then
     // read it back and dump the records.
     const bool undecided = valid && !hopeless && !final_ok;
-    const unsigned long long umask = __ballot(undecided && h == 0);
+    // routed op: the rep x rep output positions of a coarser cell are copies of ONE vector -- same scores, same bound, undecided
+    // together -- so only the cell's first position queues a record (RecMeta.rep) and the resolver corrects all of them: 37 %
+    // fewer records at a fine ratio of 0.5 (dual), and the resolver's chunks then fit one per CU
+    const int sel_rep = (SEL == 0 || sel_mask < 0.0f) ? (SEL == 0 ? 1 : 0) : (sel_mask == 1.0f ? 1 : (sel_mask == 0.25f ? 2 : 4));
+    const bool queued = undecided && sel_rep > 0;           // sel_rep: 0 for a copy, else positions per edge of the lane's cell
+    const unsigned long long umask = __ballot(queued && h == 0);
     const int shard = blockIdx.x & (DVQ_QSHARDS - 1);
     int slot_raw = 0;
     if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
@@ -884,12 +836,23 @@ __device__ __forceinline__ void pass1_body(
 #pragma unroll
             for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
     };
+    auto spill_h_cell = [&]() {                             // ... for every position of this lane's cell (rows Wout apart)
+        const int rr = sel_rep > 0 ? sel_rep : 1;
+        for (int ry = 0; ry < rr; ++ry)
+            for (int rx = 0; rx < rr; ++rx) {
+                float *hp = cv.h_buf + token_base() + (size_t)ry * rv.Wout + rx;
+#pragma unroll
+                for (int s = 0; s < S16; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
+            }
+    };
     if (CONV && valid && hopeless && !cv.h_all) spill_h();
     float lsum = 0.0f;
     float m_tok = 1.0f;
     if (valid && !hopeless) {
         if (h == 0) codes[n] = (long long)code;
-        m_tok = (SEL != 0) ? sel_mask : ((mask != nullptr) ? mask[n] : 1.0f);
+        m_tok = (SEL != 0) ? __builtin_fabsf(sel_mask) : ((mask != nullptr) ? mask[n] : 1.0f);
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
             constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
@@ -932,61 +895,50 @@ __device__ __forceinline__ void pass1_body(
             lsum *= m_tok;
         }
     }
-    int rec_index = -1;                                     // this lane's record (both lane halves of a queued token)
     if (umask != 0ull) {                                    // wave-uniform
         const int base = __shfl(slot_raw, 0);
-        int slot = base + (int)__popcll(umask & ((1ull << c) - 1ull));   // rank among the wave's undecided tokens
-        slot = undecided ? slot : -1;
-        if (undecided && slot >= rec_cap) {                 // shard full: full exact evaluation instead; the
+        int slot = base + (int)__popcll(umask & ((1ull << c) - 1ull));   // rank among the wave's queued tokens
+        slot = queued ? slot : -1;
+        if (queued && slot >= rec_cap) {                    // shard full: full exact evaluation instead; the
             if (h == 0) {                                   // provisional code / z_q written above are overwritten
-                int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);   // by the exact-list kernel, the loss term is dropped here
-                exact_list[pos] = n;
+                const int rr = sel_rep > 0 ? sel_rep : 1;   // by the exact-list kernel, the loss term is dropped here
+                for (int ry = 0; ry < rr; ++ry)
+                    for (int rx = 0; rx < rr; ++rx) {
+                        int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);
+                        exact_list[pos] = n + ry * rv.Wout + rx;
+                    }
             }
-            if (CONV && !cv.h_all) spill_h();
-            lsum = 0.0f;
+            if (CONV && !cv.h_all) spill_h_cell();
+            lsum = -(float)(sel_rep * sel_rep - 1) * lsum;  // ... for every copy of the cell (their terms equal this lane's bit for bit)
             slot = -1;
         }
         if (slot >= 0) {
-            // write-through (sc1) stores: the record may be read inside this launch by a consumer workgroup on another XCD
-            rec_index = shard * rec_cap + slot;
-            const __amdgpu_buffer_rsrc_t rr = dvq_rsrc(records);
-            const unsigned ro = (unsigned)rec_index * (unsigned)rec_bytes(D);
+            char *rec = records + ((size_t)shard * rec_cap + slot) * rec_bytes(D);
 #pragma unroll
             for (int s = 0; s < S16; ++s) {
                 f32x4 lo = {zf[s][0], zf[s][1], zf[s][2], zf[s][3]};
                 f32x4 hi = {zf[s][4], zf[s][5], zf[s][6], zf[s][7]};
-                st16_sc1(rr, ro + (16 * s + 8 * h) * 4, lo);
-                st16_sc1(rr, ro + (16 * s + 8 * h + 4) * 4, hi);
+                *(f32x4 *)(rec + (16 * s + 8 * h) * 4) = lo;
+                *(f32x4 *)(rec + (16 * s + 8 * h + 4) * 4) = hi;
             }
             if (h == 0) {
                 RecMeta rm;
                 rm.n = n; rm.xn = xn; rm.thr = thr; rm.m = m_tok; rm.prov = code;
-                rm.best = ~0ull; rm.pad = 0;
-                const f32x4 *rq = (const f32x4 *)&rm;
-                st16_sc1(rr, ro + D * 4, rq[0]);
-                st16_sc1(rr, ro + D * 4 + 16, rq[1]);
+                rm.best = ~0ull; rm.rep = sel_rep > 0 ? sel_rep : 1;
+                *(RecMeta *)(rec + (size_t)D * 4) = rm;
             }
         }
     }
-    const bool fused = fz.ncons > 0;                        // kernel argument: uniform
-    if (fused) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's records have been written through
-    if (partials != nullptr || fused) {
+    if (partials != nullptr) {
         double dsum = (double)lsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
-        __syncthreads();                                    // ... and every other wave's
-        if (fused) {
-            if (rec_index >= 0 && h == 0) __hip_atomic_store(fz.stamps + rec_index, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) (void)__hip_atomic_fetch_add(&counters[DVQ_C_DONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (partials != nullptr) {
-            double *red = (double *)lds;
-            if (lane == 0) red[wave] = dsum;
-            __syncthreads();
-            if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        }
+        __syncthreads();
+        double *red = (double *)lds;
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-    DVQ_CLK(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1316,7 +1268,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
         if (rec != nullptr && h == 0) {
             RecMeta rm;
             rm.n = n; rm.xn = xnu; rm.thr = thru; rm.m = m; rm.prov = cd;
-            rm.best = ~0ull; rm.pad = 0;
+            rm.best = ~0ull; rm.rep = 1;
             *(RecMeta *)(rec + (size_t)D * 4) = rm;
         }
     };
@@ -1344,9 +1296,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_wide_kernel(
 // (a few % of the tokens), so the work is spread for LATENCY: the four waves of a workgroup share
 // the same 32 tokens and each takes every fourth code tile, reading its A fragments straight from
 // the L2-resident prep image (no LDS ring, no barrier in the loop).
-// Two callers: vq_resolve_kernel (a launch of its own behind pass 1: large codebooks with sliced code
-// tiles, the wide / pipe forms of pass 1) and resolve_consumer (the fused form: consumer workgroups at
-// the end of pass 1's own grid, see DvqFuse).
+// One caller, vq_resolve_kernel (a launch of its own behind pass 1; large codebooks: sliced code
+// tiles, the wide / pipe forms of pass 1).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long order_key(float d, int code)
 {
@@ -1401,21 +1352,19 @@ struct ResLds {
 // runs on x exactly as pass 1 scored it (its candidate set contains the reference's winner for every h inside the conv's
 // tolerance); the workgroup then computes h = W x + bias for its 32 tokens -- qconv.hip's split-fp16 arithmetic, bit-identical
 // to dvq_qconv_f32 -- in place over x, and the exact chains / the rewrite run on that h against the codebook itself.
-// INGRID (consumer workgroup of the fused form): the records are loaded with sc1 loads (their producers are workgroups of this
-// very launch); winners that differ from pass 1's provisional code go to the rewrite list instead of z_q / codes.
-// nslice > 1 (stand-alone kernel, large codebooks): each slice resolves its candidates locally, merges its per-token best
-// into the record with a 64-bit atomicMin, and the slice that arrives last at the chunk's ticket carries on.
+// nslice > 1 (large codebooks): each slice resolves its candidates locally, merges its per-token best into the record with a
+// 64-bit atomicMin, and the slice that arrives last at the chunk's ticket carries on (and puts the ticket back to zero).
 // Returns (thread 0) the chunk's loss correction; *not_last is set for a slice that is not the chunk's last.
-// HW = positions per image of the OUTPUT grid.
-template <int D, bool FOLD, bool INGRID>
+// HW = positions per image of the OUTPUT grid; a routed token (RecMeta.rep > 1) covers rep x rep positions, rows Wout apart,
+// all rewritten with the same values.
+template <int D, bool FOLD>
 __device__ __forceinline__ double resolve_chunk(
     char *__restrict__ L, const int base, const int nlive, const int t_begin, const int t_end,
-    const char *__restrict__ img, const float *__restrict__ en_all, const float *__restrict__ E, int HW,
+    const char *__restrict__ img, const float *__restrict__ en_all, const float *__restrict__ E, int HW, int Wout,
     float *__restrict__ zq, long long *__restrict__ codes, int *__restrict__ counters, int *__restrict__ exact_list,
     char *__restrict__ records, int nslice, int *__restrict__ ticket, float *__restrict__ h_spill, const DvqConv &cv,
-    int *__restrict__ rewrites_out, const bool want_loss, bool *not_last, const int clk_base = 16)
+    const bool want_loss, bool *not_last)
 {
-    (void)clk_base;
     // h_spill (conv fused into pass 1; null otherwise): [B, D, HW] buffer the exact-list kernel reads its tokens' latents from.
     // Pass 1 spills the rows of ITS hand-offs; the tokens the resolver itself sends to that list (candidate overflow, no
     // candidate) get their row written here, from the record (which holds the conv's output).
@@ -1444,21 +1393,11 @@ __device__ __forceinline__ double resolve_chunk(
         constexpr int NP = (RES_SLOTS * (RB / 16) + RW * 64 - 1) / (RW * 64);
         const int npieces = nlive * (RB / 16);
         f32x4 tmp[NP];
-        if constexpr (INGRID) {
-            const __amdgpu_buffer_rsrc_t rr = dvq_rsrc(records);
-            const unsigned b0 = (unsigned)base * (unsigned)RB;
+        const f32x4 *src = (const f32x4 *)(records + (size_t)base * RB);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int i = tid + k * RW * 64;
-                tmp[k] = ld16_sc1(rr, b0 + 16u * (unsigned)(i < npieces ? i : 0));
-            }
-        } else {
-            const f32x4 *src = (const f32x4 *)(records + (size_t)base * RB);
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int i = tid + k * RW * 64;
-                tmp[k] = src[i < npieces ? i : 0];
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * RW * 64;
+            tmp[k] = src[i < npieces ? i : 0];
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -1467,7 +1406,6 @@ __device__ __forceinline__ double resolve_chunk(
         }
     }
     __syncthreads();
-    DVQ_CLK(clk_base + 1);
     const bool live = c < nlive;
     const char *rec = srec + (live ? c : 0) * RB;
     f16x8 zh[S16];
@@ -1649,7 +1587,6 @@ __device__ __forceinline__ double resolve_chunk(
         __syncthreads();
     }
     __syncthreads();
-    DVQ_CLK(clk_base + 2);
     const int ncand_raw = misc[0];
     bool overflow = ncand_raw > RES_CAND;             // hand the whole group to the exact list
     const int ncand = overflow ? 0 : ncand_raw;
@@ -1688,9 +1625,8 @@ __device__ __forceinline__ double resolve_chunk(
         atomicMin(&best[sl], order_key(d, code));
     }
     __syncthreads();
-    DVQ_CLK(clk_base + 3);
 
-    if constexpr (!INGRID) {
+    {
         if (nslice > 1) {
             // merge across slices through the records; the last slice of this chunk carries on
             int *oflag = ticket + 1;
@@ -1711,7 +1647,11 @@ __device__ __forceinline__ double resolve_chunk(
                 const RecMeta *gm = (const RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
                 best[tid] = __hip_atomic_load(&gm->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (tid == 0) misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket[0] = 0;                                   // every slice has been here: the pair is clean for the next op
+                ticket[1] = 0;
+            }
             __syncthreads();
             overflow = misc[3] != 0;
         }
@@ -1722,10 +1662,11 @@ __device__ __forceinline__ double resolve_chunk(
         const char *r2 = srec + tid * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         if (overflow || best[tid] == ~0ull) {
-            {
-                int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);   // cannot resolve here: full exact evaluation;
-                exact_list[pos] = m2.n;                           // pass 1's loss term for it is taken back below
-            }
+            for (int ry = 0; ry < m2.rep; ++ry)               // cannot resolve here: full exact evaluation of every position
+                for (int rx = 0; rx < m2.rep; ++rx) {         // the token stands for; pass 1's loss terms are taken back below
+                    int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);
+                    exact_list[pos] = m2.n + ry * Wout + rx;
+                }
             int pos = atomicAdd(&misc[1], 1);
             rewrite[pos] = (tid << 20) | 0xFFFFF;
         } else {
@@ -1745,37 +1686,41 @@ __device__ __forceinline__ double resolve_chunk(
         const char *r2 = srec + sl * RB;
         const RecMeta m2 = *(const RecMeta *)(r2 + (size_t)D * 4);
         const long n = m2.n;
+        const int rep = m2.rep;
         const long bimg = n / HW;
         const int hw = (int)(n - bimg * HW);
         const float m = m2.m;
         float delta = 0.0f;
-        if (INGRID && !take_back_only && lane == 0) {
-            // the list kernel applies it behind the kernel boundary (see DvqFuse)
-            const int pos = atomicAdd(&counters[DVQ_C_NREW], 1);
-            rewrites_out[2 * pos] = base + sl;
-            rewrites_out[2 * pos + 1] = win;
-        }
-        if (INGRID && !want_loss && !(take_back_only && h_spill != nullptr)) continue;   // nothing else to do for this token
         for (int k0 = lane * 4; k0 < D; k0 += 256) {
             f32x4 zv = *(const f32x4 *)(r2 + k0 * 4);
             if (take_back_only && h_spill != nullptr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h_spill[((size_t)bimg * D + k0 + j) * HW + hw] = zv[j];
+                for (int j = 0; j < 4; ++j) {
+                    float *hp = h_spill + ((size_t)bimg * D + k0 + j) * HW + hw;
+                    for (int ry = 0; ry < rep; ++ry)
+                        for (int rx = 0; rx < rep; ++rx) hp[(size_t)ry * Wout + rx] = zv[j];
+                }
             }
             f32x4 eo = *(const f32x4 *)(E + (size_t)m2.prov * D + k0);
             f32x4 en_ = take_back_only ? eo : *(const f32x4 *)(E + (size_t)win * D + k0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float dn = __fsub_rn(en_[j], zv[j]), dold = __fsub_rn(eo[j], zv[j]);
-                if (!INGRID && zq != nullptr && !take_back_only) {
-                    // FOLD: the record (now h) gives fl(h + fl(e - h)) here, e[code] in pass 1: both within 1e-6 of each other
-                    zq[((size_t)bimg * D + k0 + j) * HW + hw] = FOLD ? en_[j] : __fadd_rn(zv[j], dn);
+                if (zq != nullptr && !take_back_only) {
+                    float *zp = zq + ((size_t)bimg * D + k0 + j) * HW + hw;
+                    // FOLD: z_q := e[code] as in pass 1 (the record holds h by now; fl(h + fl(e - h)) is within 1e-6 of it)
+                    const float v = FOLD ? en_[j] : __fadd_rn(zv[j], dn);
+                    for (int ry = 0; ry < rep; ++ry)
+                        for (int rx = 0; rx < rep; ++rx) zp[(size_t)ry * Wout + rx] = v;
                 }
                 float tn = take_back_only ? 0.0f : __fmul_rn(__fmul_rn(dn, dn), m);
                 delta += tn - __fmul_rn(__fmul_rn(dold, dold), m);
             }
         }
-        if (!INGRID && lane == 0 && !take_back_only) codes[n] = (long long)win;
+        if (lane == 0 && !take_back_only)
+            for (int ry = 0; ry < rep; ++ry)
+                for (int rx = 0; rx < rep; ++rx) codes[n + (long)ry * Wout + rx] = (long long)win;
+        delta *= (float)(rep * rep);
         dsum += (double)delta;
     }
     double tot = 0.0;
@@ -1798,10 +1743,20 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const float *__restrict__ E, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
     int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    int nslice, int *__restrict__ chunk_sync, float *__restrict__ h_spill, const DvqConv cv)
+    int nslice, int *__restrict__ chunk_sync, int Wout, float *__restrict__ h_spill, const DvqConv cv,
+    const double *__restrict__ p1_partials, int np1)
 {
     __shared__ __attribute__((aligned(16))) char L[ResLds<D>::BYTES];
     (void)meta;
+    // The workgroup that writes chunk blockIdx.x's partial (also for an empty chunk) folds its share of pass 1's per-block loss
+    // sums into it, in a fixed order: the list kernel's finishing workgroup then adds gridDim.x numbers instead of np1 more.
+    auto p1_share = [&]() -> double {
+        const int per = (np1 + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int i0 = (int)blockIdx.x * per, i1 = (i0 + per < np1) ? i0 + per : np1;
+        double a = 0.0;
+        for (int i = i0; i < i1; ++i) a += p1_partials[i];
+        return a;
+    };
     // block -> (shard, chunk): the first DVQ_QSHARDS blocks take chunk 0 of every shard, and so on
     const int shard = blockIdx.x & (DVQ_QSHARDS - 1), chunk = blockIdx.x / DVQ_QSHARDS;
     int total = counters[DVQ_QCOUNT0 + shard];
@@ -1810,7 +1765,7 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const int base = shard * rec_cap + chunk * RES_SLOTS;
     const int slice = blockIdx.y;
     if (base >= total) {
-        if (partials != nullptr && threadIdx.x == 0 && slice == 0) partials[blockIdx.x] = 0.0;
+        if (partials != nullptr && threadIdx.x == 0 && slice == 0) partials[blockIdx.x] = p1_share();
         return;
     }
     const int T = dvq_num_tiles(K);
@@ -1819,94 +1774,10 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
     const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
     bool not_last;
-    const double tot = resolve_chunk<D, FOLD, false>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, zq, codes, counters,
-                                                     exact_list, records, nslice, chunk_sync + 2 * blockIdx.x, h_spill, cv, nullptr,
-                                                     partials != nullptr, &not_last);
-    if (!not_last && partials != nullptr && threadIdx.x == 0) partials[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The consumer role of the fused form (see DvqFuse): workgroup j of the `ncons` behind the token blocks serves queue shard
-// j % 64, chunks j / 64, j / 64 + ncons / 64, ... of it.  One wave polls (sc1 loads, s_sleep between polls); a chunk is taken
-// when its 32 slots are reserved and stamped, or -- once every token block has signalled DONE, which makes the reservation
-// count final -- with whatever it holds.  A consumer leaves after the shard's last (partial or empty) chunk.  The consumer that
-// leaves last fills the mailbox for the list kernel and zeroes the live counters.
-// ---------------------------------------------------------------------------------------------
-template <int D, bool FOLD>
-__device__ __forceinline__ void resolve_consumer(
-    char *__restrict__ L, const int j, const char *__restrict__ img32, const float *__restrict__ E, int HW, int K,
-    int *__restrict__ counters, int *__restrict__ exact_list, char *__restrict__ records, int rec_cap,
-    const DvqConv &cv, const DvqFuse &fz, const bool want_loss)
-{
-    using LL = ResLds<D>;
-    int *misc = (int *)(L + LL::MISC);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int shard = j & (DVQ_QSHARDS - 1), cps = fz.ncons / DVQ_QSHARDS;
-    const int T = dvq_num_tiles(K);
-    double mysum = 0.0;                                         // thread 0: this consumer's loss correction
-    DVQ_CLK(0);
-    int nchunk = 0;
-    for (int q = j / DVQ_QSHARDS;; q += cps, ++nchunk) {
-        if (wave == 0) {
-            int nlive, done;
-            for (;;) {
-                done = ld_sc1(&counters[DVQ_C_DONE]);           // DONE first: if it reads nb1, the count read after it is final
-                int r = ld_sc1(&counters[DVQ_QCOUNT0 + shard]);
-                r = r < rec_cap ? r : rec_cap;
-                nlive = r - q * RES_SLOTS;
-                nlive = nlive < 0 ? 0 : (nlive > RES_SLOTS ? RES_SLOTS : nlive);
-                if (nlive == RES_SLOTS || done == fz.nb1) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-            // the stamps of the chunk's live slots (a reserved record is stamped once it has been written through)
-            const int *st = fz.stamps + shard * rec_cap + q * RES_SLOTS;
-            while (nlive > 0) {
-                const bool ok = (lane >= nlive) || ld_sc1(st + (lane < nlive ? lane : 0)) != 0;
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (lane == 0) { misc[4] = nlive; misc[5] = (nlive < RES_SLOTS); }
-        }
-        __syncthreads();                                        // (also the barrier between the poll and every wave's record loads)
-        const int nlive = misc[4];
-        const bool last = misc[5] != 0;
-        DVQ_CLK(2 + 7 * nchunk);
-        DVQ_CLKV(2 + 7 * nchunk + 5, nlive);
-        if (nlive > 0) {
-            bool not_last;
-            const int base = shard * rec_cap + q * RES_SLOTS;
-            const double t = resolve_chunk<D, FOLD, true>(L, base, nlive, 0, T, img32, fz.en_all, E, HW, nullptr, nullptr, counters,
-                                                          exact_list, records, 1, nullptr, fz.h_spill, cv, fz.rewrites, want_loss,
-                                                          &not_last, 2 + 7 * nchunk);
-            DVQ_CLK(2 + 7 * nchunk + 4);
-            if (tid == 0) mysum += t;
-            if (tid < nlive) fz.stamps[base + tid] = 0;         // (read again only by the next op's consumers, behind a kernel boundary)
-        }
-        __syncthreads();                                        // misc / the record area are free for the next chunk
-        if (last) break;
-    }
-    DVQ_CLK(1);
-    if (tid == 0) {
-        if (fz.cons_partials != nullptr) fz.cons_partials[j] = mysum;
-        // exit ticket: every append of this workgroup to the exact / rewrite lists has returned (its index was used)
-        const int t = __hip_atomic_fetch_add(&counters[DVQ_C_CONS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == fz.ncons - 1) {
-            int queued = 0;
-            for (int i = 0; i < DVQ_QSHARDS; ++i) {
-                const int v = ld_sc1(&counters[DVQ_QCOUNT0 + i]);
-                queued += v < rec_cap ? v : rec_cap;
-            }
-            counters[DVQ_C_MAIL + 0] = ld_sc1(&counters[DVQ_C_EXACT]);
-            counters[DVQ_C_MAIL + 1] = ld_sc1(&counters[DVQ_C_NREW]);
-            counters[DVQ_C_MAIL + 2] = queued;
-            for (int i = 0; i < DVQ_QSHARDS; ++i) counters[DVQ_QCOUNT0 + i] = 0;
-            counters[DVQ_C_EXACT] = 0;
-            counters[DVQ_C_DONE] = 0;
-            counters[DVQ_C_CONS] = 0;
-            counters[DVQ_C_NREW] = 0;
-        }
-    }
+    const double tot = resolve_chunk<D, FOLD>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, Wout, zq, codes, counters,
+                                              exact_list, records, nslice, chunk_sync + 2 * blockIdx.x, h_spill, cv,
+                                              partials != nullptr, &not_last);
+    if (!not_last && partials != nullptr && threadIdx.x == 0) partials[blockIdx.x] = tot + p1_share();
 }
 
 template <int D, int SEL, bool CONV, bool FOLD = false>
@@ -1915,15 +1786,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv, const DvqFuse fz)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
 {
-    if ((int)blockIdx.x >= fz.nb1) {                         // consumer workgroup of the fused form
-        extern __shared__ __attribute__((aligned(16))) char lds_c[];
-        resolve_consumer<D, FOLD>(lds_c, (int)blockIdx.x - fz.nb1, fz.img32, E, HW, K, counters, exact_list, records, rec_cap, cv, fz,
-                                  partials != nullptr);
-        return;
-    }
-    pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv, fz);
+    pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
 }
 
 // the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
@@ -1933,15 +1798,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv, const DvqFuse fz)
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
 {
-    if ((int)blockIdx.x >= fz.nb1) {
-        extern __shared__ __attribute__((aligned(16))) char lds_c[];
-        resolve_consumer<D, FOLD>(lds_c, (int)blockIdx.x - fz.nb1, fz.img32, E, HW, K, counters, exact_list, records, rec_cap, cv, fz,
-                                  partials != nullptr);
-        return;
-    }
-    pass1_body<D, SEL, false, FOLD, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv, fz);
+    pass1_body<D, SEL, false, FOLD, false>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2093,14 +1952,12 @@ int dvq_launch_filter_scores_debug(const float *tokens, int n, const void *prep,
     return (int)hipGetLastError();
 }
 
-// The op's counter block (dvq_common.h: DVQ_C_*), the sliced resolver's chunk tickets and -- fused form on a workspace the caller
-// did not declare clean -- the record stamps.  In the steady state of the fused form nobody launches this: the op's last consumer
-// workgroup leaves every live word zero (DVQ_MODE_WS_CLEAN, dvq.h).
-__global__ void zero_counters_kernel(int *__restrict__ counters, int nwords, int *__restrict__ stamps, int nstamps)
+// The op's counter block (dvq_common.h: DVQ_C_*) and the sliced resolver's chunk tickets.  In the steady state nobody launches
+// this: every filter-path op puts its live words back to zero itself -- the list kernel's finishing workgroup the counter block,
+// each chunk's last resolver slice its ticket pair -- and a caller that keeps track says so with DVQ_MODE_WS_CLEAN (dvq.h).
+__global__ void zero_counters_kernel(int *__restrict__ counters, int nwords)
 {
-    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
-    for (int i = i0; i < nwords; i += step) counters[i] = 0;      // counter block + (sliced resolver) chunk_sync, contiguous
-    for (int i = i0; i < nstamps; i += step) stamps[i] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) counters[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2117,7 +1974,6 @@ struct DvqTune {
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
     int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
-    int cps;             // fused form: consumer workgroups per queue shard, 0 = by token count
 };
 #ifndef DVQ_PIPE_DEFAULT
 #define DVQ_PIPE_DEFAULT 0
@@ -2127,13 +1983,12 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 0};
+static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
     else if (!strcmp(key, "pipe")) g_tune.pipe = value;
-    else if (!strcmp(key, "cps")) g_tune.cps = value;
     else return -1;
     return 0;
 }
@@ -2141,12 +1996,11 @@ extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char 
 // 2W, code.  (The first argument was round 3's clock-stamp buffer; it is ignored.)
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *stamps, void *tokdbg)
 {
-    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_clk), &stamps, sizeof(void *));
-    if (rc) return rc;
+    (void)stamps;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 0};
+static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
 #endif
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
@@ -2176,14 +2030,13 @@ static int resolver_slices(int K)
     return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
 }
 
-// ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk][stamps: 1 int per record]
-//           [exact list N ints][rewrite list: 2 ints per record][records cap * rec_bytes]
+// ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk]
+//           [exact list N ints][records cap * rec_bytes]
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
-    const size_t cap = (size_t)rec_capacity(N);
-    return DVQ_COUNTER_BYTES + align256(cap / RES_SLOTS * 2 * sizeof(int)) + align256(cap * sizeof(int)) +
-           align256((size_t)N * sizeof(int)) + align256(cap * 2 * sizeof(int)) + align256(cap * rec_bytes(D));
+    return DVQ_COUNTER_BYTES + align256((size_t)rec_capacity(N) / RES_SLOTS * 2 * sizeof(int)) +
+           align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -2220,7 +2073,7 @@ int dvq_launch_routed_prepass(int G, int gate_mode, const void *gate, float thr,
                               long long *indices, float *cmask, long long *gate_out, hipStream_t st);
 
 struct FilterWs {
-    int *counters, *chunk_sync, *stamps, *exact_list, *rewrites;
+    int *counters, *chunk_sync, *exact_list;
     char *records;
     int cap;
 };
@@ -2228,14 +2081,12 @@ struct FilterWs {
 static FilterWs carve_ws(void *ws_extra, long N, int D)
 {
     FilterWs w;
-    char *p = (char *)ws_extra;
+    w.counters = (int *)ws_extra;
     w.cap = rec_capacity(N);
-    w.counters = (int *)p;                       p += DVQ_COUNTER_BYTES;
-    w.chunk_sync = (int *)p;                     p += align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
-    w.stamps = (int *)p;                         p += align256((size_t)w.cap * sizeof(int));
-    w.exact_list = (int *)p;                     p += align256((size_t)N * sizeof(int));
-    w.rewrites = (int *)p;                       p += align256((size_t)w.cap * 2 * sizeof(int));
-    w.records = p;
+    w.chunk_sync = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES);
+    const size_t sync_bytes = align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
+    w.exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
+    w.records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
     (void)D;
     return w;
 }
@@ -2250,37 +2101,15 @@ static bool staged_select_ok(const DvqRouted &rv)
     return true;
 }
 
-// consumer workgroups of the fused form: a multiple of the 64 queue shards -- 1 / 2 / 4 / 8 per shard by the number of tokens, so
-// that every chunk of a shard has a workgroup of its own (a shard collects ~N / 1800 records at the usual 3 - 4 % undecided
-// tokens, 32 to a chunk, plus the partial last one: the tail of the op is ONE chunk's latency, not two in a row) -- and never more
-// than the chip has slots for this kernel (two per CU)
-static int fused_consumers(long N)
-{
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
-    if (n == 0) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
-        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
-    }
-    int cps = N >= 131072 ? 8 : (N >= 32768 ? 4 : (N >= 8192 ? 2 : 1));
-    if (g_tune.cps >= 1 && g_tune.cps <= 16) cps = g_tune.cps;
-    while (cps > 1 && cps * DVQ_QSHARDS > 2 * n) cps >>= 1;
-    return cps * DVQ_QSHARDS;
-}
-
 template <int D, int SEL, bool CONV = false, bool FOLD = false>
 static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta *meta, const float *E,
                              const float *mask, int HW, int K, long N, float *zq, long long *codes,
                              double *partials, const FilterWs &w, const DvqRouted &rv, hipStream_t st,
-                             const DvqConv &cv, DvqFuse fz)
+                             const DvqConv &cv = DvqConv{})
 {
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
-    static_assert(ResLds<D>::BYTES <= 4 * (D / 16) * 1024 + 4 * 4 * 64 * 4 + 4 * 2048, "the consumer role's LDS is a carve of pass 1's");
-    fz.nb1 = (int)((N + 127) / 128);
-    const unsigned grid = (unsigned)(fz.nb1 + fz.ncons);     // consumer workgroups (fused form) behind the token blocks
+    const unsigned grid = (unsigned)((N + 127) / 128);
     if constexpr (D == 256 && !CONV && SEL != 1) {
         // a batch whose features fit the memory-side cache (with room for what else is live): plain loads instead of non-temporal ones
         if ((size_t)N * D * sizeof(float) <= DVQ_CACHED_MAX_BYTES) {
@@ -2289,7 +2118,7 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
             if (rcc) return rcc;
             hipLaunchKernelGGL((vq_assign_filter_cached_kernel<D, SEL, FOLD>), dim3(grid), dim3(256), shmem1, st,
                                z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                               w.cap / DVQ_QSHARDS, rv, cv, fz);
+                               w.cap / DVQ_QSHARDS, rv, cv);
             return (int)hipGetLastError();
         }
     }
@@ -2297,26 +2126,15 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
     if (rc) return rc;
     hipLaunchKernelGGL((vq_assign_filter_kernel<D, SEL, CONV, FOLD>), dim3(grid), dim3(256), shmem1, st,
                        z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
-                       w.cap / DVQ_QSHARDS, rv, cv, fz);
+                       w.cap / DVQ_QSHARDS, rv, cv);
     return (int)hipGetLastError();
-}
-
-// does pass 1 of this op go through vq_assign_filter_kernel (whose grid can carry the resolver as consumer workgroups)?
-static bool pass1_is_fusable(int D, int K, long N, bool force_wide, const DvqRouted *rv, const DvqConv *cv, bool fold)
-{
-    if (resolver_slices(K) > 1) return false;                // sliced resolver (large codebooks): a launch of its own
-#ifdef DVQ_TUNING
-    if (g_tune.pipe && !fold && cv == nullptr) return false; // the persistent pass-1 form (tuning build) has no consumer role
-#endif
-    if (fold || cv != nullptr || rv != nullptr) return true;
-    return !(D == 256 && (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)));
 }
 
 template <int D>
 static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta, const float *E,
                         const float *mask, int HW, int K, long N, float *zq, long long *codes,
                         double *partials, const FilterWs &w, bool force_wide, const DvqRouted *rv,
-                        hipStream_t st, const DvqConv *cv, const DvqConv *fold_cv, const DvqFuse &fz)
+                        hipStream_t st, const DvqConv *cv, const DvqConv *fold_cv)
 {
     const int nb1 = (int)((N + 127) / 128);
     const char *img16 = img + dvq_img16_offset(K, D);       // the code loop runs on v_mfma_f32_16x16x32_f16
@@ -2324,16 +2142,16 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
     const DvqConv nocv = {};
     if (fold_cv != nullptr) {                                // img / meta: the folded codebook; z (or the branches): the conv's input
         if (rv == nullptr)
-            return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *fold_cv, fz);
+            return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *fold_cv);
         if (staged_select_ok(*rv))
-            return launch_pass1_form<D, 2, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv, fz);
-        return launch_pass1_form<D, 1, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv, fz);
+            return launch_pass1_form<D, 2, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv);
+        return launch_pass1_form<D, 1, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *fold_cv);
     }
     if (cv != nullptr) {                                     // the 1x1 conv as the prologue (D = 256; the ABI layer checked)
         if constexpr (D == 256) {
             if (rv != nullptr)
-                return launch_pass1_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *cv, fz);
-            return launch_pass1_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *cv, fz);
+                return launch_pass1_form<D, 1, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, *cv);
+            return launch_pass1_form<D, 0, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *cv);
         } else {
             return -1000;
         }
@@ -2346,8 +2164,8 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
 #endif
     if (rv != nullptr) {                                     // select fused in
         if (staged_select_ok(*rv))
-            return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv, fz);
-        return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv, fz);
+            return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv);
+        return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv);
     }
     if constexpr (D == 256) {
         if (force_wide || (K >= DVQ_WIDE_MIN_K && N >= 256L * 512)) {   // large codebook and enough tokens to fill every CU
@@ -2363,44 +2181,44 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
             return (int)hipGetLastError();
         }
     }
-    return launch_pass1_form<D, 0>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, nocv, fz);
+    return launch_pass1_form<D, 0>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, nocv);
 }
 
 template <int D>
 static int launch_resolver(const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                            int HWout, int K, float *zq, long long *codes, double *partials,
-                           const FilterWs &w, float *h_spill, const DvqFold *fd, hipStream_t st)
+                           const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st,
+                           const double *p1_partials, int np1)
 {
     const int nslice = resolver_slices(K);
     if (fd != nullptr)
         hipLaunchKernelGGL((vq_resolve_kernel<D, true>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
                            meta, en_all, E, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, h_spill, fd->cv);
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, fd->cv, p1_partials, np1);
     else
         hipLaunchKernelGGL((vq_resolve_kernel<D, false>), dim3(w.cap / RES_SLOTS, nslice), dim3(DVQ_RES_WAVES * 64), 0, st, img,
                            meta, en_all, E, HWout, K, zq, codes, partials, w.counters, w.exact_list, w.records,
-                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, h_spill, DvqConv{});
+                           w.cap / DVQ_QSHARDS, nslice, w.chunk_sync, Wout, h_spill, DvqConv{}, p1_partials, np1);
     return (int)hipGetLastError();
 }
 
 static int launch_resolver_d(int D, const char *img, const DvqF16Meta *meta, const float *en_all, const float *E,
                              int HWout, int K, float *zq, long long *codes, double *partials,
-                             const FilterWs &w, float *h_spill, const DvqFold *fd, hipStream_t st)
+                             const FilterWs &w, int Wout, float *h_spill, const DvqFold *fd, hipStream_t st,
+                             const double *p1_partials, int np1)
 {
     switch (D) {
-    case 64:  return launch_resolver<64>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
-    case 128: return launch_resolver<128>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
-    case 256: return launch_resolver<256>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, h_spill, fd, st);
+    case 64:  return launch_resolver<64>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st, p1_partials, np1);
+    case 128: return launch_resolver<128>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st, p1_partials, np1);
+    case 256: return launch_resolver<256>(img, meta, en_all, E, HWout, K, zq, codes, partials, w, Wout, h_spill, fd, st, p1_partials, np1);
     default:  return -1000;
     }
 }
 
 // Dense op: z [B, D, HW].  Routed op (rv != nullptr): one token per output position of rv (the select fused into
 // pass 1); N = B * HWout, mask = the codebook_mask pass 1 writes.
-// Kernels of one op.  Fused form (codebooks up to 2048 codes through vq_assign_filter_kernel, i.e. every reference config):
-//   [zero kernel unless ws_clean] -> pass 1 + resolver (consumer workgroups of the same grid) -> list kernel (rewrites the
-//   consumers decided, exact list, loss finalize);
-// otherwise: zero kernel -> pass 1 -> resolver -> list kernel.
+// Kernels of one op: [zero kernel unless ws_clean] -> pass 1 -> resolver -> list kernel (exact list, loss finalize, and its
+// finishing workgroup puts the counter block back to zero: the op leaves its workspace clean).
 int dvq_launch_filter(const float *z, const void *prep, const float *E, const float *mask,
                       int D, int HW, int K, long N, float *zq, long long *codes, double *partials,
                       void *ws_extra, bool pass1_only, bool force_wide, float *loss, float beta,
@@ -2415,60 +2233,36 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     const float *en_all = (const float *)((const char *)prep + dvq_prep_en_offset(K, D));
     const FilterWs w = carve_ws(ws_extra, N, D);
     const bool routed = rv != nullptr;
-    const int HWout = routed ? rv->HWout : HW;
-    float *h_spill = (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr;   // (h_all: pass 1 already wrote every token's row)
-    const int np1 = (int)((N + 127) / 128);
-    const bool fused = !pass1_only && pass1_is_fusable(D, K, N, force_wide, rv, cv, fd != nullptr);
-    DvqFuse fz = {};
-    if (fused) {
-        fz.ncons = fused_consumers(N);
-        fz.stamps = w.stamps;
-        fz.rewrites = w.rewrites;
-        fz.en_all = en_all;
-        fz.img32 = img;
-        fz.h_spill = h_spill;
-        fz.cons_partials = partials ? partials + np1 : nullptr;
-    }
-    if (!(fused && ws_clean)) {
+    int rc;
+    if (!ws_clean) {
         // A kernel rather than hipMemsetAsync: cheaper than the runtime's fill kernel, and the op stays a pure chain of
         // kernel nodes under hipGraph capture.
         const int nwords = DVQ_COUNTER_BYTES / 4 + (resolver_slices(K) > 1 ? w.cap / RES_SLOTS * 2 : 0);
-        const int nstamps = fused ? w.cap : 0;
-        hipLaunchKernelGGL(zero_counters_kernel, dim3(nstamps ? 32 : 1), dim3(256), 0, st, w.counters, nwords, w.stamps, nstamps);
-        int rc0 = (int)hipGetLastError();
-        if (rc0) return rc0;
+        hipLaunchKernelGGL(zero_counters_kernel, dim3(nwords > 4096 ? 8 : 1), dim3(256), 0, st, w.counters, nwords);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
     }
-    int rc;
+    const int np1 = (int)((N + 127) / 128);
     const DvqConv *fold_cv = fd ? &fd->cv : nullptr;
     switch (D) {
-    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
-    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
-    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv, fz); break;
+    case 64:  rc = launch_pass1<64>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv); break;
+    case 128: rc = launch_pass1<128>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv); break;
+    case 256: rc = launch_pass1<256>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, w, force_wide, rv, st, cv, fold_cv); break;
     default:  return -1000;
     }
     if (rc || pass1_only) return rc;
-    // partials layout: [pass 1: np1][fused: ncons consumers | unfused: one per resolver chunk][list kernel blocks]
-    const int nres = fused ? fz.ncons : w.cap / RES_SLOTS;
-    if (!fused) {
-        rc = launch_resolver_d(D, img, meta, en_all, E, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
-                               w, h_spill, fd, st);
-        if (rc) return rc;
-    }
-    double *partials3 = partials ? partials + np1 + nres : nullptr;
-    // the list kernel is the last of the op: it also sums all partials into loss[0..1]
-    DvqLossTail tail = {partials ? loss : nullptr, partials, w.counters + DVQ_C_TICKET,
-                        np1 + nres + list_blocks(N),
-                        1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS,
-                        nullptr, nullptr, nullptr, 0, 0};
+    const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
+    // (h_all: pass 1 already wrote every token's row)
+    rc = launch_resolver_d(D, img, meta, en_all, E, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
+                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, fd, st, partials, np1);
+    if (rc) return rc;
+    double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
+    // the list kernel is the last of the op: it also sums the partials into loss[0..1] and cleans the counter block; the
+    // resolver's partials already contain pass 1's (vq_resolve_kernel: p1_share)
+    const DvqLossTail tail = {partials ? loss : nullptr, partials ? partials + np1 : nullptr, w.counters + DVQ_C_TICKET,
+                              w.cap / RES_SLOTS + list_blocks(N),
+                              1.0 / ((double)N * D), beta, w.counters, w.cap / DVQ_QSHARDS};
     const int *list_count = w.counters + DVQ_C_EXACT;
-    if (fused) {
-        tail.mail = w.counters + DVQ_C_MAIL;
-        tail.rewrites = w.rewrites;
-        tail.records = w.records;
-        tail.rec_bytes = (int)rec_bytes(D);
-        tail.fold = fd != nullptr;
-        list_count = tail.mail;                              // (the live counter is zero again by then)
-    }
     // conv folded in: the list kernel computes its tokens' h itself, from the conv's input (dense z or the branches)
     if (fd != nullptr)
         return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,

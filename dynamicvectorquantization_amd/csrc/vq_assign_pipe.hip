@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void vq_assign_pipe_kernel(const PipeArgs a
                     RecMeta rm;
                     rm.n = tok_n; rm.xn = xn; rm.thr = thr; rm.prov = code;
                     rm.m = (SEL != 0) ? sel_mask : ((a.mask != nullptr) ? a.mask[tok_n] : 1.0f);
-                    rm.best = ~0ull; rm.pad = 0;
+                    rm.best = ~0ull; rm.rep = 1;
                     *(RecMeta *)(rec + (size_t)D * 4) = rm;
                 }
             }
