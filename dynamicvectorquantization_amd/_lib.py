@@ -31,7 +31,7 @@ ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "dvq_version", "dvq_last_error_string", "dvq_codebook_prep_bytes", "dvq_codebook_prepare_f32",
-    "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_fallback_count_offset",
+    "dvq_vq_assign_workspace_bytes", "dvq_vq_assign_nchw_f32", "dvq_vq_assign_flat_f32", "dvq_vq_assign_fallback_count_offset",
     "dvq_embed_gather_f32",
     "dvq_vq_assign_routed_workspace_bytes", "dvq_vq_assign_routed_dual_f32", "dvq_vq_assign_routed_triple_f32",
     "dvq_vq_assign_routed_fallback_count_offset",
@@ -80,6 +80,8 @@ def _load():
     lib.dvq_vq_assign_fallback_count_offset.argtypes = [i32, i32, i32, i32]
     lib.dvq_vq_assign_nchw_f32.restype = i32
     lib.dvq_vq_assign_nchw_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, i32, vp]
+    lib.dvq_vq_assign_flat_f32.restype = i32
+    lib.dvq_vq_assign_flat_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, vp, sz, i32, vp]
     lib.dvq_vq_assign_routed_workspace_bytes.restype = sz
     lib.dvq_vq_assign_routed_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.dvq_vq_assign_routed_fallback_count_offset.restype = sz

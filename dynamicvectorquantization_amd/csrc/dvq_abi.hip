@@ -193,6 +193,15 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
     return DVQ_OK;
 }
 
+// row-major latents: the same op on [N, D, 1] (the filter path reads / writes a token's row with 16-byte accesses when HW == 1)
+int dvq_vq_assign_flat_f32(const float *z, const float *codebook, const void *prep, const float *mask,
+                           int64_t N, int D, int K, float beta, float *zq, int64_t *codes, float *loss,
+                           void *ws, size_t ws_bytes, int mode, void *stream)
+{
+    if (N <= 0 || N >= ((int64_t)1 << 31)) { dvq_set_error("dvq_vq_assign_flat_f32: N=%lld out of range", (long long)N); return DVQ_EINVAL; }
+    return dvq_vq_assign_nchw_f32(z, codebook, prep, mask, (int)N, D, 1, K, beta, zq, codes, loss, ws, ws_bytes, mode, stream);
+}
+
 // ---- the 1x1 quant_conv fused into the assign (filter mode; D = 256) --------------------------------------------------
 static int conv_desc(const char *fn, const void *qconv_prep, float *h_buf, int h_all, int D, DvqConv *cv)
 {

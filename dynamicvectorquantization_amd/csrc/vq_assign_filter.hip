@@ -260,7 +260,11 @@ __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
 // the code image and the codebook rows) or with plain loads (vq_assign_filter_cached_kernel: a batch whose features FIT that cache
 // was just written by the encoder / read by the router gate, and plain loads are served from it: -6 % on the configs[3] per-GPU
 // step, profiles/r04_cache_policy.json)
-template <int D, int SEL, bool CONV, bool FOLD, bool NT>
+// FLAT: the latents are ROW-MAJOR [N, D] (a token's channels contiguous: quantize2_list.py:153-170, channel_last inputs,
+// VQEmbedding.forward) -- the same tensor as [B = N, D, HW = 1], but read and written as what it is: a lane's 8 channels of a
+// k-step are 32 contiguous bytes = two 16-byte accesses (32 loads and 32 stores per lane instead of 128 each; with lane = token
+// and 4-byte accesses at a stride of D * 4 bytes every wave-instruction touched 64 lines for 256 useful bytes).
+template <int D, int SEL, bool CONV, bool FOLD, bool NT, bool FLAT = false>
 __device__ __forceinline__ void pass1_body(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
@@ -270,6 +274,7 @@ __device__ __forceinline__ void pass1_body(
 {
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
+    static_assert(!FLAT || (SEL == 0 && !CONV), "the row-major form is a dense op");
     constexpr int NW = 4;
     constexpr int S16 = D / 16;
     constexpr int S32 = S16 / 2;
@@ -279,6 +284,13 @@ __device__ __forceinline__ void pass1_body(
     static_assert(CPW * NW == S16 && CPW <= 4, "a wave's chunks of a code tile are contiguous and within the instruction offset");
     constexpr int PER_TILE = CPW + 1;
     constexpr int NBUF = 4;
+    // FLAT: the per-wave transposition image of half a row per token (see the prologue)
+    constexpr int FLAT_RSH = D * 2 + 16;                     // bytes per token in the image
+    constexpr int FLAT_TRW = 32 * FLAT_RSH;                  // bytes per wave
+    constexpr int FLAT_LPT = D * 2 / 16;                     // lanes (16-byte pieces) per token-half
+    constexpr int FLAT_TPI = 64 / FLAT_LPT;                  // tokens per wave-instruction
+    constexpr int FLAT_IPH = 32 / FLAT_TPI;                  // wave-instructions per half
+    static_assert(!FLAT || NW * FLAT_TRW <= NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + NW * 2048, "the images fit the kernel's LDS");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
 
@@ -322,6 +334,7 @@ __device__ __forceinline__ void pass1_body(
     const int n = (n_raw < N) ? n_raw : -1;
     auto token_base = [&]() -> size_t {
         const long nn = (n >= 0) ? n : N - 1;
+        if constexpr (FLAT) return (size_t)nn * D + 8 * h;
         const long bimg = nn / HW;
         const int hw = (int)(nn - bimg * HW);
         return ((size_t)bimg * D + 8 * h) * HW + hw;
@@ -585,6 +598,42 @@ __device__ __forceinline__ void pass1_body(
         }
     } else if constexpr (CONV) {
         conv_prologue(z + token_base(), (size_t)HW);
+    } else if constexpr (FLAT) {
+        // Row-major latents.  Read as what they are -- every wave-instruction fetches whole 128-byte lines (a token's HALF row,
+        // D * 2 bytes, is contiguous: lane = 16-byte piece) -- and turned into the (token, 8 channels of a k-step) register
+        // layout through a wave-private LDS image [32 tokens][D / 2 floats + 16 B pad] (the pad makes the b128 reads of lanes
+        // c .. c + 7 hit distinct banks), one half of the channels at a time.  The image lives where the code ring will: the
+        // first code tiles are DMA'd after a workgroup barrier, and land while the fragments are converted.
+        // (The direct form -- lane = token, two 16-byte loads per k-step at a stride of D * 4 bytes -- touched every line from
+        // eight instructions and ran at 2x the NCHW kernel's time; profiles/r05_flat.json.)
+        char *tr = lds + wave * FLAT_TRW;
+        const long n0 = ((long)tile_id * NW + wave) * 32;    // the wave's first token (its 32 tokens are consecutive rows)
+        f32x4 tmp[2][FLAT_IPH];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < FLAT_IPH; ++i) {
+                long tk = n0 + i * FLAT_TPI + lane / FLAT_LPT;
+                tk = tk < N ? tk : N - 1;
+                const f32x4 *src = (const f32x4 *)(z + (size_t)tk * D + h2 * (D / 2)) + (lane % FLAT_LPT);
+                tmp[h2][i] = NT ? __builtin_nontemporal_load(src) : *src;
+            }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int i = 0; i < FLAT_IPH; ++i)
+                *(f32x4 *)(tr + (i * FLAT_TPI + lane / FLAT_LPT) * FLAT_RSH + (lane % FLAT_LPT) * 16) = tmp[h2][i];
+#pragma unroll
+            for (int sp = 0; sp < S16 / 2; ++sp) {
+                const int s = h2 * (S16 / 2) + sp;
+                const f32x4 lo = *(const f32x4 *)(tr + c * FLAT_RSH + (16 * sp + 8 * h) * 4);
+                const f32x4 hi = *(const f32x4 *)(tr + c * FLAT_RSH + (16 * sp + 8 * h + 4) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { zf[s][j] = lo[j]; zf[s][4 + j] = hi[j]; }
+            }
+        }
+        __syncthreads();                                     // every wave has read its image: the region becomes the code ring
+        for (int t = 0; t < pre; ++t) issue(t);
     } else {
         for (int t = 0; t < pre; ++t) issue(t);
         const __amdgpu_buffer_rsrc_t zr = wave_base(z);
@@ -890,10 +939,69 @@ __device__ __forceinline__ void pass1_body(
                     }
                 }
             };
-            if (zq != nullptr) finish(std::true_type{});
-            else finish(std::false_type{});
-            lsum *= m_tok;
+            if constexpr (!FLAT) {
+                if (zq != nullptr) finish(std::true_type{});
+                else finish(std::false_type{});
+                lsum *= m_tok;
+            }
         }
+    }
+    if constexpr (FLAT) {
+        // Row-major z_q: the lanes' values go through the wave's LDS image (one half of the channels at a time) and leave as
+        // whole 128-byte lines, 16 bytes per lane -- the prologue's path backwards.  The image overlays the code ring: every wave
+        // is past its last tile (barrier) and its surplus DMA has landed (the wait after the loop).
+        char *flat_tr = lds + wave * FLAT_TRW;
+        const bool store = zq != nullptr;                    // kernel argument: uniform
+        if (store) __syncthreads();
+        const bool mine = valid && !hopeless && (store || partials != nullptr);
+        const unsigned long long okmask = __ballot(valid && !hopeless && h == 0);
+        const long n0 = ((long)tile_id * NW + wave) * 32;
+        const float *ep = E + (size_t)(mine ? code : 0) * D + 8 * h;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            if (mine) {
+                constexpr int SB = (S16 / 2 < 2) ? S16 / 2 : 2;
+#pragma unroll
+                for (int sp0 = 0; sp0 < S16 / 2; sp0 += SB) {
+                    f32x4 eg[SB][2];
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) {
+                        eg[q][0] = *(const f32x4 *)(ep + 16 * (h2 * (S16 / 2) + sp0 + q));
+                        eg[q][1] = *(const f32x4 *)(ep + 16 * (h2 * (S16 / 2) + sp0 + q) + 4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) {
+                        const int sp = sp0 + q, s = h2 * (S16 / 2) + sp;
+                        f32x4 o[2];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float e = eg[q][j >> 2][j & 3];
+                            if constexpr (FOLD) {
+                                o[j >> 2][j & 3] = e;           // z_q := e[code] (see the NCHW form)
+                            } else {
+                                const float diff = __fsub_rn(e, zf[s][j]);
+                                o[j >> 2][j & 3] = __fadd_rn(zf[s][j], diff);
+                                lsum = __builtin_fmaf(diff, diff, lsum);
+                            }
+                        }
+                        if (store) {
+                            *(f32x4 *)(flat_tr + c * FLAT_RSH + (16 * sp + 8 * h) * 4) = o[0];
+                            *(f32x4 *)(flat_tr + c * FLAT_RSH + (16 * sp + 8 * h + 4) * 4) = o[1];
+                        }
+                    }
+                }
+            }
+            if (store) {
+#pragma unroll
+                for (int i = 0; i < FLAT_IPH; ++i) {
+                    const int tk = i * FLAT_TPI + lane / FLAT_LPT;
+                    const f32x4 v = *(const f32x4 *)(flat_tr + tk * FLAT_RSH + (lane % FLAT_LPT) * 16);
+                    if ((okmask >> tk) & 1ull)              // (hopeless tokens: the exact-list kernel writes their rows)
+                        __builtin_nontemporal_store(v, (f32x4 *)(zq + (size_t)(n0 + tk) * D + h2 * (D / 2)) + (lane % FLAT_LPT));
+                }
+            }
+        }
+        lsum *= m_tok;
     }
     if (umask != 0ull) {                                    // wave-uniform
         const int base = __shfl(slot_raw, 0);
@@ -1791,6 +1899,18 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_kernel(
     pass1_body<D, SEL, CONV, FOLD, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
 }
 
+// row-major latents [N, D] (FLAT, see pass1_body)
+template <int D, bool FOLD>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_flat_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
+{
+    pass1_body<D, 0, false, FOLD, true, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
+}
+
 // the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
 template <int D, int SEL, bool FOLD>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
@@ -1974,6 +2094,7 @@ struct DvqTune {
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
     int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
+    int flat;            // HW == 1 (row-major [N, D]) through the row-major form of pass 1 (0: through the NCHW kernel, for the A/B)
 };
 #ifndef DVQ_PIPE_DEFAULT
 #define DVQ_PIPE_DEFAULT 0
@@ -1983,12 +2104,13 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
+static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
     else if (!strcmp(key, "pipe")) g_tune.pipe = value;
+    else if (!strcmp(key, "flat")) g_tune.flat = value;
     else return -1;
     return 0;
 }
@@ -2000,8 +2122,10 @@ extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *s
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT};
+static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1};
 #endif
+
+static bool dvq_flat_form_enabled() { return g_tune.flat != 0; }
 
 // slots per shard (a multiple of RES_SLOTS); the whole record area holds DVQ_QSHARDS times that
 static int shard_capacity(long N)
@@ -2110,6 +2234,18 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
     const unsigned grid = (unsigned)((N + 127) / 128);
+    if constexpr (SEL == 0 && !CONV) {
+        // HW == 1 is a row-major [N, D] tensor: 16-byte accesses along a token's row (rows are 16-byte aligned: D % 16 == 0)
+        if (HW == 1 && dvq_flat_form_enabled() && (((uintptr_t)z | (uintptr_t)zq) & 15) == 0) {
+            static unsigned long long done_f = 0;
+            int rcf = dvq_allow_dynamic_lds((const void *)vq_assign_filter_flat_kernel<D, FOLD>, (int)shmem1, &done_f);
+            if (rcf) return rcf;
+            hipLaunchKernelGGL((vq_assign_filter_flat_kernel<D, FOLD>), dim3(grid), dim3(256), shmem1, st,
+                               z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                               w.cap / DVQ_QSHARDS, rv, cv);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (D == 256 && !CONV && SEL != 1) {
         // a batch whose features fit the memory-side cache (with room for what else is live): plain loads instead of non-temporal ones
         if ((size_t)N * D * sizeof(float) <= DVQ_CACHED_MAX_BYTES) {

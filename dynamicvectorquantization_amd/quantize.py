@@ -290,6 +290,15 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
                 _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), hb.data_ptr(), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(z.device)), "dvq_vq_assign_qconv_f32")
         return zq, codes, loss
+    if HW == 1:
+        # row-major [N, D] (channel_last inputs, VectorQuantize2List's concatenated rows, VQEmbedding.forward): the entry point
+        # whose pass 1 reads / writes a token's row with 16-byte accesses
+        with torch.cuda.device(z.device):
+            pbuf = prep.get(codebook)
+            ws.check(mode, _lib_handle.dvq_vq_assign_flat_f32(
+                z.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, K, float(beta),
+                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), *ws.begin(mode), _lib.stream_ptr(z.device)), "dvq_vq_assign_flat_f32")
+        return zq, codes, loss
     with torch.cuda.device(z.device):
         pbuf = prep.get(codebook)
         ws.check(mode, _lib_handle.dvq_vq_assign_nchw_f32(

@@ -101,6 +101,19 @@ DVQ_API int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const 
                            float *zq, int64_t *codes, float *loss,
                            void *ws, size_t ws_bytes, int mode, void *stream);
 
+/*
+ * The same op on ROW-MAJOR latents z [N, D] (a token's channels contiguous) -- what the reference builds before it calls the
+ * codebook: `rearrange(x, 'b c h w -> b (h w) c')` (quantize2_mask.py:160-167; channel_last=True inputs arrive that way),
+ * the concatenated item rows of VectorQuantize2List (quantize2_list.py:153-170) and VQEmbedding.forward's inputs [..., D]
+ * (quantize2_mask.py:117-128).  mask nullable [N]; zq nullable [N, D]; codes [N] int64.  Equivalent to
+ * dvq_vq_assign_nchw_f32 with B = N, HW = 1 (which takes the same row-major kernel form for HW == 1): in DVQ_MODE_FILTER
+ * pass 1 reads and writes each row with 16-byte accesses (z and zq 16-byte aligned; otherwise, and in DVQ_MODE_EXACT,
+ * lane-per-token 4-byte accesses).  Workspace: dvq_vq_assign_workspace_bytes(N, D, 1, K, mode).
+ */
+DVQ_API int dvq_vq_assign_flat_f32(const float *z, const float *codebook, const void *prep, const float *mask,
+                           int64_t N, int D, int K, float beta, float *zq, int64_t *codes, float *loss,
+                           void *ws, size_t ws_bytes, int mode, void *stream);
+
 /* Diagnostic: byte offset inside the workspace of two int32 counters of the last DVQ_MODE_FILTER
  * call on that workspace: [0] tokens queued for the resolver (best and runner-up closer than the
  * error bound), [1] tokens handed to the full exact pass (non-finite / unscalable tokens,

@@ -56,6 +56,37 @@ def eval_case():
          loss=np.float32(loss.item()), **kw)
 
 
+BIG_SHAPES = [(16, 32, 32), (3001,), (40, 50, 13)]            # 16384 + 3001 + 26000 = 45385 tokens: the filter path's dispatch size
+
+
+def big_items(E, seed):
+    out = []
+    for i, shp in enumerate(BIG_SHAPES):
+        n = int(np.prod(shp))
+        z = synth.z_tokens(E, 1, n, 1, seed + i)               # [1, D, n, 1]
+        out.append(np.ascontiguousarray(z[0, :, :, 0].T).reshape(shp + (E.shape[1],)))
+    return out
+
+
+def eval_big_case():
+    """the list quantizer at dispatch size (K = 1024, 45 385 tokens in three items): per item the CRC of all codes, the first 512
+    codes in full and the CRC of x_q (quantize2_list.py:153-170) -- what the row-major pass-1 form is pinned by"""
+    VQL = ref_class()
+    K, D = 1024, 256
+    E = synth.codebook_trained(K, D)
+    xs = big_items(E, 7510)
+    m = VQL(K, D)
+    m.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    m.eval()
+    with torch.no_grad():
+        xq, loss, (_, _, codes) = m([torch.from_numpy(x) for x in xs])
+    kw = {"codes_head%d" % i: c.numpy().reshape(-1)[:512].astype(np.int16) for i, c in enumerate(codes)}
+    kw.update({"codes_crc%d" % i: crc(c.numpy().astype(np.int64)) for i, c in enumerate(codes)})
+    kw.update({"xq_crc%d" % i: crc(q.numpy()) for i, q in enumerate(xq)})
+    save("vq2_list_eval_big", K=K, D=D, cb_crc=crc(E), x_crc=np.array([crc(x) for x in xs], dtype=np.uint32),
+         loss=np.float32(loss.item()), **kw)
+
+
 def train_case():
     VQL = ref_class()
     K, D = 16, 256                                             # every item has >= K tokens: no noise-tiling (unseeded RNG) in the restart
@@ -83,4 +114,5 @@ def train_case():
 
 if __name__ == "__main__":
     eval_case()
+    eval_big_case()
     train_case()

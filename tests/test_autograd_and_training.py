@@ -246,6 +246,81 @@ def test_list_quantizer_eval_golden(dev):
     assert C.loss_close(float(loss), g["loss"])
 
 
+BIG_LIST_SHAPES = [(16, 32, 32), (3001,), (40, 50, 13)]
+
+
+def _big_list_items(E, seed):
+    from dynamicvectorquantization_amd import synth
+    out = []
+    for i, shp in enumerate(BIG_LIST_SHAPES):
+        n = int(np.prod(shp))
+        z = synth.z_tokens(E, 1, n, 1, seed + i)
+        out.append(np.ascontiguousarray(z[0, :, :, 0].T).reshape(shp + (E.shape[1],)))
+    return out
+
+
+def test_oracle_matches_the_list_quantizer_at_dispatch_size(oracle_mod):
+    """CPU: the oracle (row-major tokens are [N, D, 1] to it) against the reference's list quantizer at K = 1024 on 45 385
+    tokens (tests/golden/vq2_list_eval_big.npz, made by oracle/gen_golden_list.py from the imported reference,
+    quantize2_list.py:153-170): codes of every item, x_q CRCs, the loss (mean over items of the per-item means)"""
+    from dynamicvectorquantization_amd import synth
+    g = C.load("vq2_list_eval_big")
+    K, D = int(g["K"]), int(g["D"])
+    E = synth.codebook_trained(K, D)
+    xs = _big_list_items(E, 7510)
+    assert C.crc(E) == g["cb_crc"] and [C.crc(x) for x in xs] == list(g["x_crc"])
+    losses = []
+    for i, x in enumerate(xs):
+        rows = x.reshape(-1, D)
+        o = oracle_mod.vq_assign_nchw(np.ascontiguousarray(rows[:, :, None, None]), E, None)     # [N, D, 1, 1]
+        codes = o["codes"].reshape(-1)
+        assert C.crc(codes.astype(np.int64)) == g["codes_crc%d" % i], i
+        assert np.array_equal(codes[:512], g["codes_head%d" % i].astype(np.int64)), i
+        assert C.crc(o["zq"].reshape(x.shape)) == g["xq_crc%d" % i], i
+        losses.append(oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25))
+    assert C.loss_close(float(np.mean(losses)), g["loss"])
+
+
+@pytest.mark.gpu
+def test_list_quantizer_at_dispatch_size_row_major_form(dev):
+    """the list quantizer at dispatch size goes through the ROW-MAJOR form of pass 1
+    (`dvq_vq_assign_flat_f32`: 16-byte accesses along a token's row): codes of all 45 385 tokens, x_q of every item bit-exact vs
+    the imported reference (tests/golden/vq2_list_eval_big.npz), loss 1e-5; the same rows through `VectorQuantize2(channel_last=
+    True)` and `VQEmbedding.forward`, and with a row pointer that is NOT 16-byte aligned (falls back to 4-byte accesses)"""
+    from dynamicvectorquantization_amd import synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, VectorQuantize2List, _CodebookPrep, vq_assign
+    g = C.load("vq2_list_eval_big")
+    K, D = int(g["K"]), int(g["D"])
+    E = synth.codebook_trained(K, D)
+    xs = _big_list_items(E, 7510)
+    m = VectorQuantize2List(K, D).to(dev).eval()
+    m.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    with torch.no_grad():
+        xq, loss, (_, _, codes) = m([torch.from_numpy(x).to(dev) for x in xs])
+    for i, x in enumerate(xs):
+        assert codes[i].shape == x.shape[:-1] and xq[i].shape == x.shape
+        assert C.crc(codes[i].cpu().numpy().astype(np.int64)) == g["codes_crc%d" % i], i
+        assert C.crc(xq[i].cpu().numpy()) == g["xq_crc%d" % i], i
+    assert C.loss_close(float(loss), g["loss"])
+    # channel_last module and the embedding's own forward on item 0
+    x0 = torch.from_numpy(xs[0]).to(dev)                      # [16, 32, 32, D]
+    vq = VectorQuantize2(K, D, accept_image_fmap=False, channel_last=True).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    with torch.no_grad():
+        q0, _, (_, _, c0) = vq(x0.reshape(16, 1024, D))
+        emb, ids = vq.codebook(x0)
+    assert torch.equal(c0.reshape(-1), codes[0].reshape(-1)) and torch.equal(q0.reshape(x0.shape), xq[0])
+    assert torch.equal(ids.reshape(-1), codes[0].reshape(-1))
+    assert np.array_equal(emb.cpu().numpy(), E[ids.cpu().numpy()])
+    # misaligned rows: a [N, D] view 4 bytes into a buffer
+    buf = torch.empty(3001 * D + 1, dtype=torch.float32, device=dev)
+    xv = buf[1:].view(3001, D)
+    xv.copy_(torch.from_numpy(xs[1]))
+    assert xv.data_ptr() % 16 == 4
+    zq, cc, _ = vq_assign(xv, torch.from_numpy(E).to(dev), _CodebookPrep())
+    assert torch.equal(cc, codes[1]) and torch.equal(zq, xq[1])
+
+
 @pytest.mark.gpu
 def test_list_quantizer_train_golden(dev, monkeypatch):
     """train mode: the EMA update after item i is what item i + 1 is quantized with (the reference's loop), gradients
