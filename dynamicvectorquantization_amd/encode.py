@@ -341,7 +341,7 @@ class CodeExchange:
                                              self.global_batch, group=self.group, async_op=True)
             return
         assert codes.is_contiguous() and codes.dtype == torch.int64 and codes.shape[0] == self.b_local
-        with torch.cuda.device(self.dev):
+        with _lib.on_device(self.dev):
             _lib.check(_lib.lib.dvq_exchange_pack(
                 codes.data_ptr(), _lib.ptr(grain) if self.gpi else 0, _lib.ptr(loss), numel, self.b_local, self.b_max,
                 self.cpi, self.gpi, self.num_codes, self.local.data_ptr(), _lib.stream_ptr(self.dev)),
@@ -357,7 +357,7 @@ class CodeExchange:
             return self._result
         self._pending.wait()                       # the current stream waits for the collective
         self._pending = None
-        with torch.cuda.device(self.dev):
+        with _lib.on_device(self.dev):
             _lib.check(_lib.lib.dvq_exchange_unpack(
                 self.gathered.data_ptr(), self.world, self.global_batch, self.cpi, self.gpi, self.num_codes,
                 self.g_codes.data_ptr(), _lib.ptr(self.g_grain), self.g_mean.data_ptr(), _lib.stream_ptr(self.dev)),

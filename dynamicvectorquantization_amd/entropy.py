@@ -36,7 +36,7 @@ class Entropy(nn.Sequential):
         out = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device)
         if B == 0:
             return out
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib.dvq_entropy_map_f32(x.data_ptr(), B, H, W, 16, out.data_ptr(),
                                                     _lib.stream_ptr(x.device)), "dvq_entropy_map_f32")
         return out

@@ -67,7 +67,7 @@ class DualGrainSeperatePermuter(nn.Module):
             raise ValueError("indices %s / grain_indices %s do not match coarse_hw=%d fine_hw=%d" %
                              (tuple(indices.shape), tuple(grain.shape), hc, self.fine_hw))
         dev = indices.device
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _lib.stream_ptr(dev)
             if max_len is not None:
                 Lc, Lf = int(max_len[0]), int(max_len[1])
@@ -103,7 +103,7 @@ class DualGrainSeperatePermuter(nn.Module):
         if tuple(cp.shape) != (B, Lc) or tuple(fp.shape) != (B, Lf):
             raise ValueError("content / position shapes differ")
         target = torch.empty((B, self.fine_hw, self.fine_hw), dtype=torch.int64, device=cc.device)
-        with torch.cuda.device(cc.device):
+        with _lib.on_device(cc.device):
             _lib.check(_L.dvq_permute_dual_backward_i64(cc.data_ptr(), fc.data_ptr(), cp.data_ptr(), fp.data_ptr(),
                                                         B, Lc, Lf, self.hw1, self.hw1,
                                                         self.coarse_position_eos_code, self.fine_position_eos_code,

@@ -44,7 +44,7 @@ class _ConvPrep:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             w2 = _lib.require_cuda_f32(w.detach().reshape(D, D), "quant_conv.weight")
             b2 = None if bias is None else _lib.require_cuda_f32(bias.detach(), "quant_conv.bias")
-            with torch.cuda.device(w.device):
+            with _lib.on_device(w.device):
                 _lib.check(_lib_handle.dvq_qconv_prepare_f32(w2.data_ptr(), _lib.ptr(b2), D, self.buf.data_ptr(),
                                                              self.buf.numel(), _lib.stream_ptr(w.device)),
                            "dvq_qconv_prepare_f32")
@@ -103,7 +103,7 @@ def quant_conv(conv, x):
     h = torch.empty_like(x)
     if B * HW == 0:
         return h
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         pbuf = _prep_of(conv).get(conv)
         _lib.check(_lib_handle.dvq_qconv_f32(x.data_ptr(), pbuf.data_ptr(), B, D, HW, h.data_ptr(),
                                              _lib.stream_ptr(x.device)), "dvq_qconv_f32")
@@ -154,7 +154,7 @@ def quant_conv_select(conv, h_coarse, h_fine, h_median=None, gate=None, entropy=
         indices = torch.empty((B, hc, wc), dtype=torch.int64, device=dev)
         cmask = torch.empty((B, 1, S * hc, S * wc), dtype=torch.float32, device=dev)
     if h.numel() > 0:
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             pbuf = _prep_of(conv).get(conv)
             _lib.check(_lib_handle.dvq_qconv_select_f32(
                 nb, g.data_ptr(), kind, thr, h_coarse.data_ptr(), _lib.ptr(h_median), h_fine.data_ptr(), pbuf.data_ptr(),

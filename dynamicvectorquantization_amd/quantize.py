@@ -169,6 +169,10 @@ class _CodebookPrep:
         key = (B, D, HW, K, mode, device, _lib.stream_ptr(device))
         ws = self._ws.get(key)
         if ws is None:
+            if nbytes is None and isinstance(HW, tuple):        # routed workspace: ("routed2" | "routed3", hc, wc)
+                nbytes = _lib_handle.dvq_vq_assign_routed_workspace_bytes(int(HW[0][-1]), B, D, HW[1], HW[2], K, mode)
+                if nbytes == 0:
+                    raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, HW[1], HW[2], K))
             if nbytes is None:
                 nbytes = _lib_handle.dvq_vq_assign_workspace_bytes(B, D, HW, K, mode)
             if len(self._ws) >= 8:                   # shapes rarely change: keep the table small
@@ -275,14 +279,14 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
         return zq, codes, loss
     ws = prep.workspace(B, D, HW, K, mode, z.device)
     if fold:
-        with torch.cuda.device(z.device):
+        with _lib.on_device(z.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
             ws.check(mode, _lib_handle.dvq_vq_assign_fold_f32(
                 z.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), B, D, HW, K,
                 _lib.ptr(zq), codes.data_ptr(), *ws.begin(mode), _lib.stream_ptr(z.device)), "dvq_vq_assign_fold_f32")
         return zq, codes, loss
     if conv is not None:
-        with torch.cuda.device(z.device):
+        with _lib.on_device(z.device):
             qbuf, hb, h_all = _conv_args(conv, prep, z.shape, z.device, h_buf)
             pbuf = prep.get(codebook)
             ws.check(mode, _lib_handle.dvq_vq_assign_qconv_f32(
@@ -293,13 +297,13 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
     if HW == 1:
         # row-major [N, D] (channel_last inputs, VectorQuantize2List's concatenated rows, VQEmbedding.forward): the entry point
         # whose pass 1 reads / writes a token's row with 16-byte accesses
-        with torch.cuda.device(z.device):
+        with _lib.on_device(z.device):
             pbuf = prep.get(codebook)
             ws.check(mode, _lib_handle.dvq_vq_assign_flat_f32(
                 z.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, K, float(beta),
                 _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), *ws.begin(mode), _lib.stream_ptr(z.device)), "dvq_vq_assign_flat_f32")
         return zq, codes, loss
-    with torch.cuda.device(z.device):
+    with _lib.on_device(z.device):
         pbuf = prep.get(codebook)
         ws.check(mode, _lib_handle.dvq_vq_assign_nchw_f32(
             z.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
@@ -372,12 +376,9 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
         if loss is not None:
             loss.fill_(float("nan"))
         return res
-    nbytes = _lib_handle.dvq_vq_assign_routed_workspace_bytes(2, B, D, hc, wc, K, mode)
-    if nbytes == 0:
-        raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
-    ws = prep.workspace(B, D, ("routed2", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    ws = prep.workspace(B, D, ("routed2", hc, wc), K, mode, h_fine.device)
     if fold:                                     # the conv folded into the codebook (see vq_assign): codes [+ z_q], no loss
-        with torch.cuda.device(h_fine.device):
+        with _lib.on_device(h_fine.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_fold_dual_f32(
                 g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), fbuf.data_ptr(),
@@ -386,7 +387,7 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
                 "dvq_vq_assign_routed_fold_dual_f32")
         return res
     if conv is not None:
-        with torch.cuda.device(h_fine.device):
+        with _lib.on_device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
             pbuf = prep.get(codebook)
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_dual_f32(
@@ -395,7 +396,7 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
                 indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), hb.data_ptr(), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_dual_f32")
         return res
-    with torch.cuda.device(h_fine.device):
+    with _lib.on_device(h_fine.device):
         pbuf = prep.get(codebook)
         ws.check(mode, _lib_handle.dvq_vq_assign_routed_dual_f32(
             g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(),
@@ -433,12 +434,9 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
         if loss is not None:
             loss.fill_(float("nan"))
         return res
-    nbytes = _lib_handle.dvq_vq_assign_routed_workspace_bytes(3, B, D, hc, wc, K, mode)
-    if nbytes == 0:
-        raise _lib.DvqError("routed assign: unsupported shape B=%d D=%d hc=%d wc=%d K=%d" % (B, D, hc, wc, K))
-    ws = prep.workspace(B, D, ("routed3", hc, wc), K, mode, h_fine.device, nbytes=nbytes)
+    ws = prep.workspace(B, D, ("routed3", hc, wc), K, mode, h_fine.device)
     if fold:
-        with torch.cuda.device(h_fine.device):
+        with _lib.on_device(h_fine.device):
             qbuf, pbuf, fbuf = _fold_args(conv, prep, codebook, loss is not None, mode)
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_fold_triple_f32(
                 g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
@@ -447,7 +445,7 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
                 "dvq_vq_assign_routed_fold_triple_f32")
         return res
     if conv is not None:
-        with torch.cuda.device(h_fine.device):
+        with _lib.on_device(h_fine.device):
             qbuf, hb, h_all = _conv_args(conv, prep, h_fine.shape, h_fine.device, h_buf)
             pbuf = prep.get(codebook)
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_triple_f32(
@@ -456,7 +454,7 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
                 _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), hb.data_ptr(), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_triple_f32")
         return res
-    with torch.cuda.device(h_fine.device):
+    with _lib.on_device(h_fine.device):
         pbuf = prep.get(codebook)
         ws.check(mode, _lib_handle.dvq_vq_assign_routed_triple_f32(
             g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), codebook.data_ptr(),
@@ -474,7 +472,7 @@ def embed_gather(codebook, idx):
     idx = idx.contiguous()
     K, D = codebook.shape
     out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=codebook.device)
-    with torch.cuda.device(codebook.device):
+    with _lib.on_device(codebook.device):
         _lib.check(_lib_handle.dvq_embed_gather_f32(codebook.data_ptr(), K, D, idx.data_ptr(), idx.numel(),
                                                     out.data_ptr(), _lib.stream_ptr(codebook.device)),
                    "dvq_embed_gather_f32")
@@ -532,7 +530,7 @@ class _VQStraightThrough(torch.autograd.Function):
             gl = g_loss.reshape(1).to(torch.float32).contiguous()
             m = None if mask is None else _lib.require_cuda_f32(mask, "codebook_mask")
             gz = torch.empty_like(z)
-            with torch.cuda.device(z.device):
+            with _lib.on_device(z.device):
                 _lib.check(_lib_handle.dvq_vq_backward_nchw_f32(
                     z.data_ptr(), snap.data_ptr(), codes.data_ptr(), _lib.ptr(m), _lib.ptr(gq), gl.data_ptr(),
                     float(ctx.coef_z * scale), B, D, HW, snap.shape[0], gz.data_ptr(), _lib.stream_ptr(z.device)),
@@ -542,7 +540,7 @@ class _VQStraightThrough(torch.autograd.Function):
             gw = torch.zeros(ctx.wshape, dtype=z.dtype, device=z.device)
             gl = g_loss.reshape(1).to(torch.float32).contiguous()
             m = None if mask is None else _lib.require_cuda_f32(mask, "codebook_mask")
-            with torch.cuda.device(z.device):
+            with _lib.on_device(z.device):
                 _lib.check(_lib_handle.dvq_vq_backward_codebook_nchw_f32(
                     z.data_ptr(), snap.data_ptr(), codes.data_ptr(), _lib.ptr(m), gl.data_ptr(), float(ctx.coef_e * scale),
                     B, D, HW, snap.shape[0], gw.data_ptr(), _lib.stream_ptr(z.device)), "dvq_vq_backward_codebook_nchw_f32")
@@ -641,7 +639,7 @@ class VQEmbedding(nn.Embedding):
             z = nchw.contiguous()
             B, HW = z.shape[0], z[0, 0].numel()
             codes = idxs.reshape(B, HW).contiguous()
-            with torch.cuda.device(z.device):
+            with _lib.on_device(z.device):
                 _lib.check(_lib_handle.dvq_ema_accumulate_nchw_f32(
                     z.data_ptr(), codes.data_ptr(), B, embed_dim, HW, n_embed, cluster_size.data_ptr(),
                     vsum.data_ptr(), _lib.stream_ptr(z.device)), "dvq_ema_accumulate_nchw_f32")

@@ -29,7 +29,7 @@ def entropy_gate(entropy, threshold):
     gate = torch.empty(tuple(entropy.shape) + (2,), dtype=torch.int64, device=entropy.device)
     if entropy.numel() == 0:
         return gate
-    with torch.cuda.device(entropy.device):
+    with _lib.on_device(entropy.device):
         _lib.check(_lib_handle.dvq_entropy_gate_f32(entropy.data_ptr(), entropy.numel(), float(threshold),
                                                     gate.data_ptr(), _lib.stream_ptr(entropy.device)),
                    "dvq_entropy_gate_f32")
@@ -69,7 +69,7 @@ def _route_select_dual_raw(gate, h_coarse, h_fine, out=None):
         cmask = torch.empty((B, 1, 2 * hc, 2 * wc), dtype=torch.float32, device=h_fine.device)
     if h_dual.numel() == 0:
         return {"h_dual": h_dual, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
-    with torch.cuda.device(h_fine.device):
+    with _lib.on_device(h_fine.device):
         _lib.check(_lib_handle.dvq_route_select_dual_f32(
             g.data_ptr(), gdt, h_coarse.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
             h_dual.data_ptr(), indices.data_ptr(), cmask.data_ptr(), _lib.stream_ptr(h_fine.device)),
@@ -97,7 +97,7 @@ def _route_select_dual_entropy_raw(entropy, threshold, h_coarse, h_fine, out=Non
         cmask = torch.empty((B, 1, 2 * hc, 2 * wc), dtype=torch.float32, device=h_fine.device)
         gate = torch.empty((B, hc, wc, 2), dtype=torch.int64, device=h_fine.device)
     if h_dual.numel() > 0:
-        with torch.cuda.device(h_fine.device):
+        with _lib.on_device(h_fine.device):
             _lib.check(_lib_handle.dvq_route_select_dual_entropy_f32(
                 entropy.data_ptr(), float(threshold), h_coarse.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
                 h_dual.data_ptr(), indices.data_ptr(), cmask.data_ptr(), gate.data_ptr(),
@@ -126,7 +126,7 @@ def _route_select_triple_raw(gate, h_coarse, h_median, h_fine, out=None):
         cmask = torch.empty((B, 1, 4 * hc, 4 * wc), dtype=torch.float32, device=h_fine.device)
     if h_triple.numel() == 0:
         return {"h_triple": h_triple, "indices": indices, "codebook_mask": cmask, "gate": gate.permute(0, 3, 1, 2)}
-    with torch.cuda.device(h_fine.device):
+    with _lib.on_device(h_fine.device):
         _lib.check(_lib_handle.dvq_route_select_triple_f32(
             g.data_ptr(), gdt, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), B, C, hc, wc,
             h_triple.data_ptr(), indices.data_ptr(), cmask.data_ptr(), _lib.stream_ptr(h_fine.device)),
@@ -258,7 +258,7 @@ class _GateWeightPrep:
             if self.buf is not None:
                 self._retired = (self._retired + [self.buf])[-2:]
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
-            with torch.cuda.device(w1.device):
+            with _lib.on_device(w1.device):
                 _lib.check(_lib_handle.dvq_router_gate_prepare_f32(
                     w1.data_ptr(), nb, C, hidden, self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
                     "dvq_router_gate_prepare_f32")
@@ -310,7 +310,7 @@ def fused_router_gate(gate, gate_type, norms, branches, weight_prep=None):
     ptr = lambda t: None if t is None else t.data_ptr()
     med = hs[1] if nb == 3 else None
     prep = weight_prep.get(w1, nb, C) if (weight_prep is not None and w1 is not None) else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib_handle.dvq_router_gate_f32(
             nb, hs[0].data_ptr(), ptr(med), hs[-1].data_ptr(), B, C, hc, wc, groups, float(eps),
             ptr(gw[0]), ptr(gb[0]), ptr(gw[1]) if nb == 3 else None, ptr(gb[1]) if nb == 3 else None,
