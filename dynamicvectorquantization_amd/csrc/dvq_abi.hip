@@ -121,7 +121,7 @@ int dvq_codebook_prepare_f32(const float *codebook, int K, int D, void *prep, si
                              void *stream)
 {
     if (!codebook || !prep || K <= 0) { dvq_set_error("dvq_codebook_prepare_f32: null pointer or K <= 0"); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("dvq_codebook_prepare_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_codebook_prepare_f32: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", D); return DVQ_EUNSUPPORTED; }
     if (prep_bytes < dvq_codebook_prep_bytes(K, D)) { dvq_set_error("dvq_codebook_prepare_f32: prep buffer %zu < %zu bytes", prep_bytes, dvq_codebook_prep_bytes(K, D)); return DVQ_EWORKSPACE; }
     if (((uintptr_t)prep & 255) != 0) { dvq_set_error("dvq_codebook_prepare_f32: prep must be 256-byte aligned"); return DVQ_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
@@ -156,7 +156,7 @@ int dvq_vq_assign_nchw_f32(const float *z, const float *codebook, const void *pr
 {
     if (!z || !codebook || !prep || !codes) { dvq_set_error("dvq_vq_assign_nchw_f32: null pointer"); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_vq_assign_nchw_f32: B=%d HW=%d K=%d must be positive", B, HW, K); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("dvq_vq_assign_nchw_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_vq_assign_nchw_f32: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", D); return DVQ_EUNSUPPORTED; }
     const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
     mode &= ~DVQ_MODE_WS_CLEAN;
     const bool pass1_only = (mode == DVQ_MODE_FILTER_PASS1);
@@ -270,7 +270,7 @@ int dvq_fold_prepare_f32(const float *codebook, int K, int D, const void *codebo
 {
     const char *fn = "dvq_fold_prepare_f32";
     if (!codebook || !codebook_prep || !conv_weight || !fold_prep || K <= 0) { dvq_set_error("%s: null pointer or K <= 0", fn); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", fn, D); return DVQ_EUNSUPPORTED; }
     if (fold_prep_bytes < dvq_fold_prep_bytes(K, D)) { dvq_set_error("%s: fold_prep buffer %zu < %zu bytes", fn, fold_prep_bytes, dvq_fold_prep_bytes(K, D)); return DVQ_EWORKSPACE; }
     if (((uintptr_t)fold_prep & 255) != 0 || ((uintptr_t)codebook_prep & 255) != 0) { dvq_set_error("%s: prep buffers must be 256-byte aligned", fn); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_fold_prep(codebook, K, D, codebook_prep, conv_weight, conv_bias, fold_prep, (hipStream_t)stream), fn);
@@ -285,7 +285,7 @@ int dvq_vq_assign_fold_f32(const float *x, const void *qconv_prep, const void *f
     mode &= ~DVQ_MODE_WS_CLEAN;
     if (!x || !codebook || !prep || !codes) { dvq_set_error("%s: null pointer", fn); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0 || K <= 0) { dvq_set_error("%s: B=%d HW=%d K=%d must be positive", fn, B, HW, K); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", fn, D); return DVQ_EUNSUPPORTED; }
     DvqFold fd;
     int rc = fold_desc(fn, qconv_prep, fold_prep, D, &fd);
     if (rc) return rc;
@@ -345,7 +345,7 @@ static int routed_common(const char *fn, int nb, const void *gate, int gate_kind
     if (B <= 0 || hc <= 0 || wc <= 0 || K <= 0) { dvq_set_error("%s: B=%d hc=%d wc=%d K=%d must be positive", fn, B, hc, wc, K); return DVQ_EINVAL; }
     if (gate_kind != DVQ_GATE_F32 && gate_kind != DVQ_GATE_I64 && gate_kind != DVQ_GATE_ENTROPY) { dvq_set_error("%s: gate_kind %d", fn, gate_kind); return DVQ_EINVAL; }
     if (gate_kind == DVQ_GATE_ENTROPY && nb != 2) { dvq_set_error("%s: the entropy gate is a dual-granularity router", fn); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", fn, D); return DVQ_EUNSUPPORTED; }
     int SC;
     if (!routed_dims(nb, hc, wc, &SC)) { dvq_set_error("%s: hc*wc=%ld exceeds %d coarse cells", fn, (long)hc * wc, DVQ_ROUTE_MAX_CELLS_ABI); return DVQ_EUNSUPPORTED; }
     const bool ws_clean = (mode & DVQ_MODE_WS_CLEAN) != 0;
@@ -689,7 +689,7 @@ size_t dvq_qconv_prep_bytes(int D) { return dim_ok(D) ? dvq_qconv_prep_bytes_imp
 int dvq_qconv_prepare_f32(const float *weight, const float *bias, int D, void *prep, size_t prep_bytes, void *stream)
 {
     if (!weight || !prep) { dvq_set_error("dvq_qconv_prepare_f32: null pointer"); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_prepare_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_prepare_f32: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", D); return DVQ_EUNSUPPORTED; }
     if (prep_bytes < dvq_qconv_prep_bytes(D)) { dvq_set_error("dvq_qconv_prepare_f32: prep buffer %zu < %zu bytes", prep_bytes, dvq_qconv_prep_bytes(D)); return DVQ_EWORKSPACE; }
     if (((uintptr_t)prep & 255) != 0) { dvq_set_error("dvq_qconv_prepare_f32: prep must be 256-byte aligned"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_qconv_prep(weight, bias, D, prep, (hipStream_t)stream), "qconv_prep");
@@ -699,7 +699,7 @@ int dvq_qconv_f32(const float *x, const void *prep, int B, int D, int HW, float 
 {
     if (!x || !prep || !h) { dvq_set_error("dvq_qconv_f32: null pointer"); return DVQ_EINVAL; }
     if (B <= 0 || HW <= 0) { dvq_set_error("dvq_qconv_f32: sizes must be positive"); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_f32: D=%d unsupported (64, 128, 256)", D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("dvq_qconv_f32: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", D); return DVQ_EUNSUPPORTED; }
     if ((long)B * HW >= (1L << 31)) { dvq_set_error("dvq_qconv_f32: tensor too large"); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_qconv(x, nullptr, prep, D, HW, (long)B * HW, h, (hipStream_t)stream), "qconv");
 }
@@ -717,7 +717,7 @@ int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_kind, floa
     if (B <= 0 || hc <= 0 || wc <= 0) { dvq_set_error("%s: sizes must be positive", fn); return DVQ_EINVAL; }
     if (gate_kind != DVQ_GATE_F32 && gate_kind != DVQ_GATE_I64 && gate_kind != DVQ_GATE_ENTROPY) { dvq_set_error("%s: gate_kind %d", fn, gate_kind); return DVQ_EINVAL; }
     if (gate_kind == DVQ_GATE_ENTROPY && num_branches != 2) { dvq_set_error("%s: the entropy gate is a dual-granularity router", fn); return DVQ_EINVAL; }
-    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (64, 128, 256)", fn, D); return DVQ_EUNSUPPORTED; }
+    if (!dim_ok(D)) { dvq_set_error("%s: D=%d unsupported (kernel widths 64, 128, 256; a multiple of 32 below 256 runs EXACTLY at the next width with zero channels appended to latents and codebook, as the Python drop-in does)", fn, D); return DVQ_EUNSUPPORTED; }
     const int SC = (num_branches == 2) ? 2 : 4;
     const long N = (long)B * SC * hc * SC * wc;
     if (N >= (1L << 31)) { dvq_set_error("%s: tensor too large", fn); return DVQ_EUNSUPPORTED; }

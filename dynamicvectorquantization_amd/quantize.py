@@ -81,6 +81,7 @@ class _CodebookPrep:
 
     def invalidate(self):
         self.key = None
+        self._padded = None
         self._hbuf.clear()       # the [B, D, *spatial] scratch tensors of the fused-conv ops (one per shape and stream) are re-made on demand
 
     def get(self, codebook):
@@ -151,6 +152,17 @@ class _CodebookPrep:
             else:
                 cur.wait_event(ent[2][1])
         return pbuf, ent[1]
+
+    def padded_codebook(self, codebook, Dp):
+        """[K, Dp] copy of `codebook` with zero channels appended (widths served by padding, _padded_width), rebuilt when the
+        codebook tensor changes; `get()` then prepares THAT tensor"""
+        key = (codebook.data_ptr(), codebook._version, tuple(codebook.shape), Dp)
+        ent = getattr(self, "_padded", None)
+        if ent is None or ent[0] != key:
+            Ep = codebook.new_zeros((codebook.shape[0], Dp))
+            Ep[:, :codebook.shape[1]] = codebook.detach()
+            ent = self._padded = (key, Ep)
+        return ent[1]
 
     def used(self, device):
         """called after an op that read the image was queued on the current stream (only needed while the codebook can
@@ -240,6 +252,44 @@ def _fold_args(conv, prep, codebook, want_loss, mode):
     return qbuf, pbuf, fbuf
 
 
+KERNEL_WIDTHS = (64, 128, 256)          # channel counts the assign kernels are instantiated for
+
+
+def _padded_width(D):
+    """the kernel width a codebook of D channels runs at: D itself, or -- D a multiple of 32 below 256 -- the next kernel width
+    with ZERO channels appended to latents and codebook.  That is exact, not approximate: a zero channel adds fma(0, 0, acc) =
+    acc to the sequential dot chain and + 0 to a partial sum of the norm whose 32-way grouping does not depend on D, so distances,
+    codes and z_q are the reference's bit for bit (pinned for D = 32, 96, 160, 192, 224 by oracle/validate_against_reference.py
+    and tests/test_gpu_parity.py).  Other widths (not a multiple of 32: ATen's reduction order for the tail is not pinned; above
+    256: no kernel) raise."""
+    if D in KERNEL_WIDTHS:
+        return D
+    if D > 0 and D % 32 == 0 and D < KERNEL_WIDTHS[-1]:
+        return min(w for w in KERNEL_WIDTHS if w >= D)
+    raise _lib.DvqError("codebook_dim %d: the MI355X kernels serve 64, 128 and 256 channels, and 32, 96, 160, 192, 224 by exact "
+                        "zero padding; other widths are not supported (INTEGRATION.md)" % D)
+
+
+def _vq_assign_padded(z, codebook, prep, mask, beta, want_zq, want_loss, mode, out, Dp):
+    """vq_assign for a width the kernels are not instantiated for: run at Dp >= D with zero channels (see _padded_width)"""
+    B, D = z.shape[0], z.shape[1]
+    zp = z.new_zeros((B, Dp) + tuple(z.shape[2:]))
+    zp[:, :D] = z
+    Ep = prep.padded_codebook(codebook, Dp)
+    zq_p, codes, loss_p = vq_assign(zp, Ep, prep, mask, beta, want_zq, want_loss, mode)
+    zq = zq_p[:, :D].contiguous() if want_zq else None
+    loss = None
+    if loss_p is not None:
+        mean = loss_p[0] * (float(Dp) / float(D))          # the kernel divided by N * Dp; the padding's squared error is exactly 0
+        loss = torch.stack([mean, beta * mean + mean])
+    if out is not None:
+        for dst, src in zip(out, (zq, codes, loss)):
+            if dst is not None and src is not None:
+                dst.copy_(src)
+        return out
+    return zq, codes, loss
+
+
 def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=True,
               mode=_lib.MODE_FILTER, out=None, conv=None, h_buf=None, fold=False):
     """z [B, D, *spatial] f32 cuda, codebook [K, D] -> (zq or None, codes [B, *spatial] i64, loss[2] or None).
@@ -266,6 +316,11 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
         mask = _lib.require_cuda_f32(mask, "codebook_mask")
         if mask.numel() != B * HW:
             raise ValueError("codebook_mask has %d elements, expected B*H*W = %d" % (mask.numel(), B * HW))
+    Dp = _padded_width(D)
+    if Dp != D and B * HW > 0:
+        if conv is not None or fold:
+            raise _lib.DvqError("the fused / folded quant_conv needs a kernel width (64, 128, 256 channels), got %d" % D)
+        return _vq_assign_padded(z, codebook, prep, mask, beta, want_zq, want_loss, mode, out, Dp)
     if out is not None:
         zq, codes, loss = out
     else:

@@ -18,7 +18,14 @@
  *   - return value: DVQ_OK (0) or a negative DVQ_E* code; the message of the
  *     last failure on the calling thread is dvq_last_error_string();
  *   - tensors are dense, C-contiguous, float32 unless stated; code indices and
- *     grain indices are int64 (the reference's dtype).
+ *     grain indices are int64 (the reference's dtype);
+ *   - channel counts (codebook_dim D): the assign kernels are instantiated for 64, 128 and
+ *     256 (every reference config uses 256); other values return DVQ_EUNSUPPORTED.  A
+ *     multiple of 32 below 256 (32, 96, 160, 192, 224) is served EXACTLY at the next kernel
+ *     width by appending zero channels to latents and codebook -- a zero channel adds
+ *     fma(0, 0, acc) = acc to the dot chain and + 0 to the norm's partial sums, whose 32-way
+ *     grouping does not depend on D -- which is what the Python drop-in does
+ *     (quantize.py: _padded_width); divide the returned loss mean by D / D_padded.
  */
 #ifndef DVQ_H_
 #define DVQ_H_

@@ -161,6 +161,12 @@ if __name__ == "__main__":
     res.append(check_vq2(1, 32, 32, 16384, "trained", 24))
     for D in (64, 128, 512):
         res.append(check_vq2(1, 16, 16, 512, "trained", 30 + D, D=D))
+    # the widths the drop-in serves by zero padding (quantize._padded_width): the oracle's orders (sequential-k chain, the
+    # 32-partial-sum norm) hold for every multiple of 32 -- trained-like and tie-stress codebooks, VQGAN class included
+    for D in (32, 96, 160, 192, 224):
+        res.append(check_vq2(2, 16, 16, 512, "trained", 40 + D, D=D))
+        res.append(check_vq2(1, 16, 16, 300, "default", 50 + D, D=D, masked=False))
+        res.append(check_vqgan(1, 8, 8, 128, 60 + D, legacy=False, D=D))
     if big:
         res.append(check_vq2(64, 32, 32, 1024, "trained", 25))
         res.append(check_vq2(16, 32, 32, 16384, "default", 26))

@@ -674,3 +674,50 @@ def test_fused_router_gate_fuzz(dev):
         err = float((fused - ref).abs().max())
         assert err < 1e-4 * max(1.0, float(ref.abs().max())), (case, nbr, Cc, hc, wc, B, norm, gate_type, err)
 
+
+
+@pytest.mark.parametrize("D", [32, 96, 160, 192, 224])
+def test_widths_served_by_zero_padding(dev, oracle_mod, D):
+    """the reference classes take any codebook_dim (quantize2_mask.py:136-155); the kernels exist for 64 / 128 /
+    256 channels and the drop-in serves every other multiple of 32 below 256 by appending ZERO channels (exact: fma(0, 0, acc) and
+    + 0 in the norm's partial sums).  Codes and z_q bit-exact vs the oracle (itself pinned against the imported reference at these
+    widths: oracle/validate_against_reference.py), loss 1e-5: VectorQuantize2 with a mask, tie-stress codebook, row-major input,
+    VectorQuantizer2; a width that is NOT a multiple of 32 raises."""
+    from dynamicvectorquantization_amd import _lib, synth
+    from dynamicvectorquantization_amd.quantize import VectorQuantize2, VectorQuantizer2
+    K = 512
+    for kind, seed in (("trained", 40 + D), ("default", 50 + D)):
+        E = synth.codebook_trained(K, D) if kind == "trained" else synth.codebook_default_init(K, D)
+        z = synth.z_tokens(E, 3, 16, 16, seed) * (np.float32(1.0) if kind == "trained" else np.float32(0.002))
+        mask = np.where(synth.bernoulli(seed + 1, (3, 1, 16, 16), 0.5), 1.0, 0.25).astype(np.float32)
+        o = oracle_mod.vq_assign_nchw(z, E, mask)
+        for mode in (_lib.MODE_FILTER, _lib.MODE_EXACT):
+            xq, loss, codes = _run_vq2(dev, z, E, mask, mode)
+            assert np.array_equal(codes.reshape(3, -1), o["codes"]), (D, kind, mode)
+            assert np.array_equal(xq, o["zq"]), (D, kind, mode)
+            assert C.loss_close(loss, oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25)), (D, kind, mode)
+    # row-major tokens (channel_last) and the taming class
+    E = synth.codebook_trained(K, D)
+    z = synth.z_tokens(E, 2, 8, 8, 70 + D)
+    o = oracle_mod.vq_assign_nchw(z, E, None)
+    vq = VectorQuantize2(K, D, accept_image_fmap=False, channel_last=True).to(dev).eval()
+    vq.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    with torch.no_grad():
+        xq, loss, (_, _, codes) = vq(torch.from_numpy(z.reshape(2, D, 64)).to(dev).permute(0, 2, 1).contiguous())
+    assert np.array_equal(codes.cpu().numpy(), o["codes"])
+    assert np.array_equal(xq.permute(0, 2, 1).cpu().numpy().reshape(z.shape), o["zq"])
+    g = VectorQuantizer2(K, D, beta=0.25, legacy=False).to(dev).eval()
+    g.embedding.weight.data.copy_(torch.from_numpy(E))
+    with torch.no_grad():
+        zq, gl, (_, _, idx) = g(torch.from_numpy(z).to(dev))
+    assert np.array_equal(idx.cpu().numpy().reshape(2, -1), o["codes"]) and np.array_equal(zq.cpu().numpy(), o["zq"])
+    assert C.loss_close(float(gl), oracle_mod.vq_loss(o["sqerr"], o["numel"], 0.25, legacy=False))
+    # training-mode forward + backward runs at this width (EMA statistics, straight-through gradient)
+    vt = VectorQuantize2(K, D).to(dev).train()
+    vt.codebook.weight.data[:-1].copy_(torch.from_numpy(E))
+    x = torch.from_numpy(z).to(dev).requires_grad_(True)
+    xq, loss, _ = vt(x)
+    (xq.sum() + loss).backward()
+    assert x.grad is not None and bool(torch.isfinite(x.grad).all())
+    with pytest.raises(_lib.DvqError):
+        VectorQuantize2(64, 48).to(dev).eval()(torch.zeros(1, 48, 4, 4, device=dev))
