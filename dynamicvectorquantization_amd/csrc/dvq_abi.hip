@@ -68,7 +68,9 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
 int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
 size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid);
 size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid);
-int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st);
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st, bool has_tail);
+int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *const *gn_b, int nb, int C, int Hid, void *prep,
+                                        hipStream_t st);
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
                            int B, int C, int hc, int wc, int groups, float eps,
                            const float *W1, const float *b1, const float *W2, const float *b2,
@@ -580,7 +582,22 @@ int dvq_router_gate_prepare_f32(const float *w1, int nb, int C, int hidden, void
     if (C % 8 != 0 || nb * C > 1280) { dvq_set_error("%s: C=%d unsupported (C %% 8 == 0, num_branches*C <= 1280)", fn, C); return DVQ_EUNSUPPORTED; }
     if (w1_prep_bytes < dvq_router_gate_prep_bytes(nb, C, hidden)) { dvq_set_error("%s: buffer %zu < %zu bytes", fn, w1_prep_bytes, dvq_router_gate_prep_bytes(nb, C, hidden)); return DVQ_EWORKSPACE; }
     if (((uintptr_t)w1_prep & 255) != 0) { dvq_set_error("%s: buffer must be 256-byte aligned", fn); return DVQ_EINVAL; }
-    return hip_rc(dvq_launch_router_gate_prepare(w1, nb, C, hidden, w1_prep, (hipStream_t)stream), "router_gate_prepare");
+    return hip_rc(dvq_launch_router_gate_prepare(w1, nb, C, hidden, w1_prep, (hipStream_t)stream, true), "router_gate_prepare");
+}
+
+int dvq_router_gate_prepare_norm_f32(int nb, int C, int hidden, const float *gn_w_coarse, const float *gn_b_coarse,
+                                     const float *gn_w_median, const float *gn_b_median,
+                                     const float *gn_w_fine, const float *gn_b_fine, void *w1_prep, size_t w1_prep_bytes, void *stream)
+{
+    const char *fn = "dvq_router_gate_prepare_norm_f32";
+    if (nb != 2 && nb != 3) { dvq_set_error("%s: num_branches=%d (2 or 3)", fn, nb); return DVQ_EINVAL; }
+    if (!w1_prep || !gn_w_coarse || !gn_b_coarse || !gn_w_fine || !gn_b_fine || (nb == 3 && (!gn_w_median || !gn_b_median)) || C <= 0 || hidden <= 0) {
+        dvq_set_error("%s: null pointer or non-positive size", fn); return DVQ_EINVAL;
+    }
+    if (w1_prep_bytes < dvq_router_gate_prep_bytes(nb, C, hidden)) { dvq_set_error("%s: buffer %zu < %zu bytes", fn, w1_prep_bytes, dvq_router_gate_prep_bytes(nb, C, hidden)); return DVQ_EWORKSPACE; }
+    const float *w[3] = {gn_w_coarse, nb == 3 ? gn_w_median : gn_w_fine, gn_w_fine};
+    const float *b[3] = {gn_b_coarse, nb == 3 ? gn_b_median : gn_b_fine, gn_b_fine};
+    return hip_rc(dvq_launch_router_gate_prepare_norm(w, b, nb, C, hidden, w1_prep, (hipStream_t)stream), fn);
 }
 
 int dvq_router_gate_f32(int nb, const float *h_coarse, const float *h_median, const float *h_fine,

@@ -58,10 +58,11 @@ struct DvqGateArgs {
 #ifndef DVQ_POOL_WPE
 #define DVQ_POOL_WPE 8           // workgroups per CU the pooling pass is compiled for (a streaming pass lives on occupancy)
 #endif
+#define DVQ_GATE_NORM_MAGIC 0x44563531      // tail of the weight prep: [magic][max |gn_w|, max |gn_b| per branch] (dvq_router_gate_prepare_norm_f32)
 template <bool IMG, bool NT>
 __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArgs a, float2 *__restrict__ ab,
                                                         float *__restrict__ pool, char *__restrict__ ximg,
-                                                        float *__restrict__ xs)
+                                                        float *__restrict__ xs, const float *__restrict__ nbound)
 {
     const int G = a.groups > 0 ? a.groups : a.C / 8;
     const int cpg = a.C / G;
@@ -75,7 +76,17 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float xscale = 1.0f;
     if (IMG) {
+        // the fp16 range bound max_k (|w_k| sqrt(n_br) + |b_k|).  With the per-branch maxima of the GroupNorm parameters prepared
+        // once per parameter version (nbound; a slightly larger bound: max |w| and max |b| need not sit on one channel) it is six
+        // scalars; without them every workgroup scans all F parameters: a dependent load chain and a barrier of its own, 5 of
+        // 46 us at B = 128 and 39 of 314 us at B = 1024 (profiles/r05_gate_pool.json)
         float bound = 0.0f;
+        if (nbound != nullptr && __builtin_bit_cast(int, nbound[0]) == DVQ_GATE_NORM_MAGIC) {
+            for (int br = 0; br < a.nb; ++br) {
+                const float n = (float)cpg * (float)(a.hc * a.scale[br]) * (float)(a.wc * a.scale[br]);
+                bound = fmaxf(bound, nbound[1 + 2 * br] * sqrtf(n) * 1.0001f + nbound[2 + 2 * br]);
+            }
+        } else {
         for (int k = tid; k < F; k += 256) {
             const int br = k / a.C, ch = k - br * a.C;
             const float n = (float)cpg * (float)(a.hc * a.scale[br]) * (float)(a.wc * a.scale[br]);
@@ -86,6 +97,7 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
         if (lane == 0) s_bound[wave] = bound;
         __syncthreads();
         bound = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3]));
+        }
         float inv = 1.0f;
         if (!(bound < 16384.0f) && bound < __builtin_inff()) {
             int e;
@@ -228,8 +240,10 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
 // ---- 2. hidden-layer weight W1 [Hid, F] -> split fp16 tile images (Fp = F rounded up to 16, S = Fp/16):
 //   imgH / imgL [t][s][lane = 32h + c][j < 8] = hi / lo of W1[32t + c][16s + 8h + j]   (zero padded)
 __global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__ W1, int Hid, int F, int Fp,
-                                                       _Float16 *__restrict__ imgH, _Float16 *__restrict__ imgL)
+                                                       _Float16 *__restrict__ imgH, _Float16 *__restrict__ imgL,
+                                                       float *__restrict__ tail)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tail != nullptr) tail[0] = 0.0f;   // no GroupNorm maxima (yet): gate_pool_kernel, nbound
     const size_t per_tile = (size_t)32 * Fp;
     const size_t total = (size_t)((Hid + 31) / 32) * per_tile;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -874,8 +888,38 @@ size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups
            gate_part_bytes(nb, B, hc, wc, Hid) + 512;
 }
 
+// per-branch maxima of the GroupNorm parameters -> the tail of the weight prep (see gate_pool_kernel: nbound)
+__global__ __launch_bounds__(256) void gate_norm_bound_kernel(const float *w0, const float *b0, const float *w1, const float *b1,
+                                                              const float *w2, const float *b2, int nb, int C, float *out)
+{
+    __shared__ float red[6][4];
+    const float *ws[3] = {w0, w1, w2}, *bs[3] = {b0, b1, b2};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int br = 0; br < 3; ++br) {
+        float mw = 0.0f, mb = 0.0f;
+        if (br < nb)
+            for (int i = threadIdx.x; i < C; i += 256) { mw = fmaxf(mw, fabsf(ws[br][i])); mb = fmaxf(mb, fabsf(bs[br][i])); }
+        // NaN parameters: fmaxf drops them -- a NaN weight poisons the logits whatever the scale, nothing to protect
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, off)); mb = fmaxf(mb, __shfl_xor(mb, off)); }
+        if (lane == 0) { red[2 * br][wave] = mw; red[2 * br + 1][wave] = mb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) out[1 + threadIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+    if (threadIdx.x == 0) out[0] = __builtin_bit_cast(float, (int)DVQ_GATE_NORM_MAGIC);
+}
+
+int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *const *gn_b, int nb, int C, int Hid, void *prep,
+                                        hipStream_t st)
+{
+    float *tail = (float *)((char *)prep + gate_img_bytes(nb, C, Hid));
+    hipLaunchKernelGGL(gate_norm_bound_kernel, dim3(1), dim3(256), 0, st, gn_w[0], gn_b[0], gn_w[1], gn_b[1],
+                       nb == 3 ? gn_w[2] : nullptr, nb == 3 ? gn_b[2] : nullptr, nb, C, tail);
+    return (int)hipGetLastError();
+}
+
 // hidden-layer weight -> split fp16 tile images (kept by the caller across calls while the weight is unchanged)
-int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st)
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st, bool has_tail)
 {
     const int F = nb * C, Fp = (F + 15) & ~15;
     _Float16 *imgH = (_Float16 *)prep;
@@ -883,7 +927,8 @@ int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void
     size_t total = (size_t)((Hid + 31) / 32) * 32 * Fp;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL);
+    hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL,
+                       has_tail ? (float *)((char *)prep + gate_img_bytes(nb, C, Hid)) : nullptr);
     return (int)hipGetLastError();
 }
 
@@ -921,7 +966,7 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     char *after = (char *)pool + (pool_area > ximg_area ? pool_area : ximg_area);
     const _Float16 *imgH = (const _Float16 *)w1_prep;
     if (act != 0 && imgH == nullptr) {
-        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, after, st);
+        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, after, st, false);
         if (rc) return rc;
         imgH = (const _Float16 *)after;
     }
@@ -933,6 +978,9 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     const bool gemm_form = act != 0 && groups > 0 && cpg % 8 == 0 && cpg <= 64 && (size_t)nb * cpg * hc * wc * 4 <= 48 * 1024 &&
                            F % 16 == 0 && (S16 == 8 || S16 == 12 || S16 == 16 || S16 == 24 || S16 == 32 || S16 == 48);
     if (gemm_form) {
+        // (prepared images carry the GroupNorm maxima in their tail when dvq_router_gate_prepare_norm_f32 ran; images rebuilt inside
+        // this call do not)
+        const float *nbound = (w1_prep != nullptr) ? (const float *)((const char *)w1_prep + gate_img_bytes(nb, C, Hid)) : nullptr;
         char *ximg = (char *)pool;
         const _Float16 *imgLg = imgL;
         float *part = (float *)(after + gate_img_bytes(nb, C, Hid));
@@ -942,10 +990,10 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
             (void)hipMemsetAsync(ximg + (size_t)(nblocks - 1) * S16 * 2048, 0, (size_t)S16 * 2048, st);
         if (cached)
             hipLaunchKernelGGL((gate_pool_kernel<true, false>), dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
-                               stats, pool, ximg, xs);
+                               stats, pool, ximg, xs, nbound);
         else
             hipLaunchKernelGGL((gate_pool_kernel<true, true>), dim3(B * groups), dim3(256), (size_t)nb * cpg * hc * wc * sizeof(float), st, a,
-                               stats, pool, ximg, xs);
+                               stats, pool, ximg, xs, nbound);
         int ncu = 256;
         {
             int dev = 0, n = 256;
@@ -989,10 +1037,10 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     }
     if (cached)
         hipLaunchKernelGGL((gate_pool_kernel<false, false>), dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
-                           nullptr, nullptr);
+                           nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL((gate_pool_kernel<false, true>), dim3(B * (groups > 0 ? groups : C / 8)), dim3(256), 0, st, a, stats, pool,
-                           nullptr, nullptr);
+                           nullptr, nullptr, nullptr);
     // two blocks of 32 cells per workgroup when the split tile of 64 cells fits the LDS and there are enough cells to keep
     // every CU busy that way
     const size_t shmem2 = ((size_t)2 * 32 * Fp + (size_t)(1 + nb) * Hid) * sizeof(float);

@@ -246,9 +246,14 @@ class _GateWeightPrep:
     def invalidate(self):
         self.key = None
 
-    def get(self, w1, nb, C):
+    def get(self, w1, nb, C, gn=None):
+        """gn: (weights, biases) of the branches' GroupNorms, coarse -> fine (None: no normalisation): their per-branch maxima
+        are prepared into the same buffer (`dvq_router_gate_prepare_norm_f32`) and refreshed when a parameter's version changes"""
         hidden = w1.shape[0]
         key = (w1.data_ptr(), w1._version, tuple(w1.shape), w1.device)
+        gkey = None if gn is None else tuple((t.data_ptr(), t._version) for t in gn[0] + gn[1])
+        if key == self.key and gkey != getattr(self, "gkey", None):
+            self.key = None                              # (simplest: a changed GroupNorm parameter rebuilds the whole prep)
         if key != self.key:
             nbytes = _lib_handle.dvq_router_gate_prep_bytes(nb, C, hidden)
             if nbytes == 0:
@@ -262,10 +267,18 @@ class _GateWeightPrep:
                 _lib.check(_lib_handle.dvq_router_gate_prepare_f32(
                     w1.data_ptr(), nb, C, hidden, self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
                     "dvq_router_gate_prepare_f32")
+                if gn is not None:
+                    gw, gb = gn
+                    p = lambda t: t.data_ptr()
+                    _lib.check(_lib_handle.dvq_router_gate_prepare_norm_f32(
+                        nb, C, hidden, p(gw[0]), p(gb[0]), p(gw[1]) if nb == 3 else None, p(gb[1]) if nb == 3 else None,
+                        p(gw[-1]), p(gb[-1]), self.buf.data_ptr(), self.buf.numel(), _lib.stream_ptr(w1.device)),
+                        "dvq_router_gate_prepare_norm_f32")
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(w1.device))
                 self._built = (_lib.stream_ptr(w1.device), ev)
             self.key = key
+            self.gkey = gkey
         elif self._built is not None and not torch.cuda.is_current_stream_capturing():
             if self._built[0] != _lib.stream_ptr(w1.device):     # built on another stream: order this one behind it, once
                 if self._built[1].query():
@@ -309,7 +322,8 @@ def fused_router_gate(gate, gate_type, norms, branches, weight_prep=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()
     med = hs[1] if nb == 3 else None
-    prep = weight_prep.get(w1, nb, C) if (weight_prep is not None and w1 is not None) else None
+    prep = (weight_prep.get(w1, nb, C, gn=(gw, gb) if groups > 0 else None)
+            if (weight_prep is not None and w1 is not None) else None)
     with _lib.on_device(dev):
         _lib.check(_lib_handle.dvq_router_gate_f32(
             nb, hs[0].data_ptr(), ptr(med), hs[-1].data_ptr(), B, C, hc, wc, groups, float(eps),
