@@ -69,6 +69,7 @@ int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hi
 size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid);
 size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid);
 int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st, bool has_tail);
+int dvq_launch_restart_pick(unsigned long long seed, long long n, int k, long long *out, hipStream_t st);
 int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *const *gn_b, int nb, int C, int Hid, void *prep,
                                         hipStream_t st);
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
@@ -560,6 +561,15 @@ int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, int B, int
     if (B <= 0 || D <= 0 || HW <= 0 || K <= 0) { dvq_set_error("dvq_ema_accumulate_nchw_f32: sizes must be positive"); return DVQ_EINVAL; }
     return hip_rc(dvq_launch_ema_accumulate(z, (const long long *)codes, D, HW, (long)B * HW, K, cluster_size, vectors_sum,
                                             (hipStream_t)stream), "ema_accumulate");
+}
+
+int dvq_restart_pick_i64(uint64_t seed, int64_t n, int k, int64_t *out, void *stream)
+{
+    if (!out) { dvq_set_error("dvq_restart_pick_i64: null pointer"); return DVQ_EINVAL; }
+    if (k < 1 || k > 2048 || n < 16 * (int64_t)k || n > 0xFFFFFFFFll) {
+        dvq_set_error("dvq_restart_pick_i64: k=%d n=%lld (1 <= k <= 2048, 16 k <= n < 2^32)", k, (long long)n); return DVQ_EUNSUPPORTED;
+    }
+    return hip_rc(dvq_launch_restart_pick((unsigned long long)seed, (long long)n, k, (long long *)out, (hipStream_t)stream), "restart_pick");
 }
 
 size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden)

@@ -191,3 +191,87 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
                            cluster_size, vectors_sum);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dead-code restart: which K of the n input vectors replace dead codes.  The reference takes `torch.randperm(n_vectors)[:K]`
+// (quantize2_mask.py:93-96): on the GPU that is a sort of n = 262 144 keys, ~115 us of a 1-ms training step, to keep 1 024 of them.
+// The first K entries of a uniform random permutation are K draws without replacement; drawing independently and keeping first
+// occurrences is the same distribution.  One workgroup: 2K counter-based draws (splitmix64 of seed + i, multiply-high into
+// [0, n)), an LDS hash table that keeps for every value its smallest draw index, a block scan over the "first occurrence" flags,
+// the first K survivors in draw order.  Fewer than K distinct values among 2K draws (n >= 16 K: never in practice) leaves the
+// missing slots at their own index.  K <= 2048.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(1024) void restart_pick_kernel(unsigned long long seed, long long n, int k, int hbits,
+                                                            long long *__restrict__ out)
+{
+    extern __shared__ unsigned long long tab[];              // [1 << hbits] (value << 32 | smallest draw index), ~0 = empty
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = 1 << hbits, M = 2 * k;
+    for (int i = tid; i < H; i += 1024) tab[i] = ~0ull;
+    for (int i = tid; i < k; i += 1024) out[i] = i;          // (a slot no survivor reaches keeps a valid index)
+    __syncthreads();
+    const int per = (M + 1023) / 1024;                       // consecutive draws per thread: draw order = thread order
+    unsigned d[4];
+    bool keep[4];
+    for (int j = 0; j < per; ++j) {
+        const int i = tid * per + j;
+        d[j] = (unsigned)__umul64hi(splitmix64(seed + (unsigned long long)i), (unsigned long long)n);
+        keep[j] = false;
+        if (i >= M) continue;
+        const unsigned long long packed = ((unsigned long long)d[j] << 32) | (unsigned)i;
+        unsigned slot = (unsigned)(splitmix64(d[j]) >> 40) & (H - 1);
+        for (;;) {
+            const unsigned long long cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == ~0ull) {
+                if (atomicCAS(&tab[slot], ~0ull, packed) == ~0ull) break;
+            } else if ((unsigned)(cur >> 32) == d[j]) {
+                atomicMin(&tab[slot], packed);
+                break;
+            } else {
+                slot = (slot + 1) & (H - 1);
+            }
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int j = 0; j < per; ++j) {
+        const int i = tid * per + j;
+        if (i >= M) continue;
+        unsigned slot = (unsigned)(splitmix64(d[j]) >> 40) & (H - 1);
+        while ((unsigned)(tab[slot] >> 32) != d[j]) slot = (slot + 1) & (H - 1);
+        keep[j] = (unsigned)tab[slot] == (unsigned)i;         // this draw is the value's first occurrence
+        cnt += keep[j];
+    }
+    int incl = cnt;                                           // block-wide exclusive scan of cnt
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int rank = base + incl - cnt;
+    for (int j = 0; j < per; ++j)
+        if (keep[j]) { if (rank < k) out[rank] = (long long)d[j]; ++rank; }
+}
+
+int dvq_launch_restart_pick(unsigned long long seed, long long n, int k, long long *out, hipStream_t st)
+{
+    if (k < 1 || k > 2048 || n < 1 || n > 0xFFFFFFFFll) return -1000;
+    int hbits = 3;
+    while ((1 << hbits) < 8 * k) ++hbits;                    // table = 4 x the draws
+    static unsigned long long done = 0;
+    const size_t shm = (size_t)(1 << hbits) * sizeof(unsigned long long);
+    int rc = dvq_allow_dynamic_lds((const void *)restart_pick_kernel, (int)shm, &done);
+    if (rc) return rc;
+    hipLaunchKernelGGL(restart_pick_kernel, dim3(1), dim3(1024), shm, st, seed, n, k, hbits, out);
+    return (int)hipGetLastError();
+}

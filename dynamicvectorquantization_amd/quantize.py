@@ -252,6 +252,27 @@ def _fold_args(conv, prep, codebook, want_loss, mode):
     return qbuf, pbuf, fbuf
 
 
+_TORCH_RANDPERM = torch.randperm        # (tests and goldens pin the dead-code restart by replacing torch.randperm)
+
+
+def _restart_pick(n, k, device):
+    """the first k entries of a uniform random permutation of range(n) -- what the reference's dead-code restart takes from
+    `torch.randperm(n_vectors)` (quantize2_mask.py:93-96) -- without permuting all n: drawing indices independently and keeping
+    first occurrences IS sequential sampling without replacement, i.e. the same distribution (`dvq_restart_pick_i64`: one small
+    workgroup, 2k counter-based draws, an LDS hash table; fewer than k distinct values among them does not happen for n >= 16 k,
+    and a slot that stayed empty would keep its own index).  The full
+    permutation is a 262 144-key device sort, ~115 us of the 1.04-ms training step at B = 256 (rocprofv3: profiles/
+    r05_train_step.json).  Small batches, CPU tensors and a caller that replaced torch.randperm (the tests pin the permutation
+    that way) take torch.randperm itself."""
+    if torch.randperm is not _TORCH_RANDPERM or n < 16 * k or k > 2048 or device.type != "cuda":
+        return torch.randperm(n, device=device)[:k]
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF     # the CPU generator: torch.manual_seed governs it
+    out = torch.empty(k, dtype=torch.int64, device=device)
+    with _lib.on_device(device):
+        _lib.check(_lib_handle.dvq_restart_pick_i64(seed, n, k, out.data_ptr(), _lib.stream_ptr(device)), "dvq_restart_pick_i64")
+    return out
+
+
 KERNEL_WIDTHS = (64, 128, 256)          # channel counts the assign kernels are instantiated for
 
 
@@ -730,7 +751,7 @@ class VQEmbedding(nn.Embedding):
         if n_vectors < n_embed:
             vectors = self._tile_with_noise(vectors.reshape(-1, vectors.shape[-1]), n_embed)
             n_vectors = vectors.shape[0]
-        pick = torch.randperm(n_vectors, device=vectors.device)[:n_embed]
+        pick = _restart_pick(n_vectors, n_embed, vectors.device)
         if vectors.dim() == 3:                            # the permuted view [B, HW, D] of NCHW latents: K rows by (image, position)
             hw = vectors.shape[1]
             chosen = vectors[torch.div(pick, hw, rounding_mode="floor"), pick % hw].contiguous()

@@ -339,6 +339,15 @@ DVQ_API int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, in
                                 float *cluster_size, float *vectors_sum, void *stream);
 
 /*
+ * Dead-code restart of the training-mode codebook update: the reference takes the first K entries of torch.randperm(n_vectors)
+ * as the input vectors that replace dead codes (quantize2_mask.py:93-96) -- on a GPU a full sort of n keys to keep K of them.
+ * out [k] int64 = k DISTINCT indices of [0, n), every index equally likely, in random order (the distribution of a permutation's
+ * prefix: independent draws, first occurrences kept), a pure function of (seed, n, k); one small workgroup.
+ * 1 <= k <= 2048, 16 k <= n < 2^32.  RNG parity with torch is not possible either way.
+ */
+DVQ_API int dvq_restart_pick_i64(uint64_t seed, int64_t n, int k, int64_t *out, void *stream);
+
+/*
  * Fused feature-router gate (inference), the forward of DualGrainFeatureRouter
  * (modules/dynamic_modules/RouterDual.py:35-43) and TripleGrainFeatureRouter
  * (modules/dynamic_modules/RouterTriple.py:46-56): GroupNorm per branch, average pooling of the

@@ -434,3 +434,31 @@ def test_codebook_gradient_kernel_vs_index_add(dev, D, HW, K):
         assert torch.equal(gw[K], torch.full((D,), 0.5, device=dev))                 # the padding row is never touched
         run()                                                                         # it ACCUMULATES
         assert float((gw[:K].double() - 2 * want[:K]).abs().max() / want.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_restart_pick_is_a_prefix_of_a_random_permutation(dev):
+    """the dead-code restart takes `torch.randperm(n)[:K]` in the reference (quantize2_mask.py:93-96); `_restart_pick` samples the
+    same distribution without the device-wide sort: K distinct indices of range(n), every index equally likely, order random;
+    and a replaced torch.randperm (how tests / goldens pin the restart) is honoured"""
+    from dynamicvectorquantization_amd import quantize
+    n, k = 262144, 1024
+    hits = torch.zeros(n, dtype=torch.int64, device=dev)
+    first = []
+    for _ in range(200):
+        p = quantize._restart_pick(n, k, dev)
+        assert p.shape == (k,) and p.dtype == torch.int64
+        assert int(p.min()) >= 0 and int(p.max()) < n and torch.unique(p).numel() == k
+        hits[p] += 1
+        first.append(int(p[0]))
+    # 204 800 draws over 262 144 cells: the lower / upper half of the range get half the draws each (5 sigma = 0.6 %)
+    lo = int(hits[: n // 2].sum())
+    assert abs(lo - 102400) < 1200, lo
+    assert len(set(first)) > 190                                  # the leading entry moves
+    import torch as _t
+    real = _t.randperm
+    try:
+        _t.randperm = lambda m, device=None, **kw: _t.arange(m - 1, -1, -1, device=device)
+        assert quantize._restart_pick(n, 4, dev).tolist() == [n - 1, n - 2, n - 3, n - 4]
+    finally:
+        _t.randperm = real
