@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="consecutive steps (independent batches) are issued round-robin on this many HIP streams, each "
                          "with its own outputs / workspace / exchange buffers, so a step's latency-bound tail (resolver, "
-                         "list kernel, counter zero, exchange) runs under the next batch's pass 1; 1 = strictly serial")
+                         "list kernel, exchange) runs under the next batch's pass 1; 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -915,6 +915,13 @@ def run_rank(a):
     dom_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     for i in range(-3, nev):
+        # the profiling mode leaves its workspace's queue counters dirty; they are zeroed HERE, in front of the bracket, and the
+        # workspace declared clean, so that the events enclose the pass-1 kernel and nothing else (rounds 1-4 had the op's own
+        # 5-us counter-zero kernel inside the bracket)
+        lw = getattr(wl.prep_dom, "_last_ws", None)
+        if lw is not None and hasattr(lw[1], "clean"):
+            lw[1].t[:min(lw[1].t.numel(), 4 << 20)].zero_()
+            lw[1].clean = True
         wl.dominant(wl.slots[0], dom_ev[i] if i >= 0 else scratch)
     torch.cuda.synchronize()
     dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
@@ -950,12 +957,15 @@ def run_rank(a):
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
     roof.update({"kernel": wl.dominant_kernel_name(), "traffic_source": tsrc,
-                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events on the launch stream around the pass-1 launch (a 4-us "
-                 "counter-zero kernel precedes it in the same op and is inside the bracket), one launch at a time after "
+                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events on the launch stream around the pass-1 launch alone (profiling "
+                 "mode on a workspace declared clean: no other kernel is inside the bracket), one launch at a time after "
                  "the timed region. Inside the timed region consecutive steps overlap on config.streams HIP streams, so a "
                  "kernel trace of THIS command shows stretched, overlapping per-kernel durations; the trace of the same "
-                 "command with --streams 1 (profiles/r04_bench_kernel_stats.csv) is the one this figure agrees with "
+                 "command with --streams 1 (profiles/r05_bench_kernel_stats.csv) is the one this figure agrees with "
                  "(kernel_ms_rocprof, when that summary was made from these sources)",
+                 "serial_over_kernel": (serial_ms / dom_ms) if (serial_ms and dom_ms) else None,
+                 "op_kernels": "pass 1 -> resolver -> list kernel (exact list, loss finalize, counter clean-up); no counter-zero "
+                               "kernel in the steady state (DVQ_MODE_WS_CLEAN)",
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                  "algorithmic_note": "SURVEY.md 8d count of the VQ forward per launch of this kernel: every position read once "
                                      "(1 KiB), z_q written once (1 KiB; not in --path tokens: 1032 + 4 B per token), int64 "
