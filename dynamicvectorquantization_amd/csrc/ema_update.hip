@@ -172,6 +172,109 @@ __global__ __launch_bounds__(256) void ema_zero_kernel(float *__restrict__ a, si
     for (size_t i = i0; i < nb; i += stride) b[i] = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same statistics with a BIG tile (round 5): 1024 tokens x 32 channels per workgroup, the tile in LDS (128 KiB: one workgroup per
+// CU), the tokens of the tile chained by code (LDS atomicExch on a [K] head table), one float-atomic row per (code PRESENT in the
+// tile, 32 channels).  The kernel above is bound by the L2 float-atomic rate (67 M adds at B = 256 = 308 us: 0.87 TB/s of the guide's
+// 1.3 TB/s for 256-byte contiguous adds) and a 64-token tile has nothing to combine when the codes are spread (62 distinct codes of
+// 64); 1024 tokens hold K (1 - e^-1) = 647 distinct codes of K = 1024, so 37 % of the adds disappear -- more with the 2 x 2 / 4 x 4
+// copies of coarse cells and a skewed codebook.  Needs HW % 4 == 0 (16-byte loads along the tokens), D % 32 == 0, K <= 4096.
+// ---------------------------------------------------------------------------------------------
+#ifndef EMA_BIG
+#define EMA_BIG 1                // 0: the 64-token kernel everywhere (A/B)
+#endif
+#define EMA_BT 1024              // tokens per tile
+#define EMA_BC 32                // channels per tile
+#define EMA_BSTR (EMA_BT + 4)    // floats per channel row in LDS
+#ifndef EMA_BTHREADS
+#define EMA_BTHREADS 1024         // 16 waves: the chain walk below is a chain of dependent LDS reads, it lives on waves in flight
+#endif
+__global__ __launch_bounds__(EMA_BTHREADS) void ema_accumulate_big_kernel(const float *__restrict__ z, const long long *__restrict__ codes,
+                                                                 int D, int HW, long N, int K, float *__restrict__ cluster_size,
+                                                                 float *__restrict__ vectors_sum)
+{
+    constexpr int NT = EMA_BTHREADS, NWV = NT / 64, PPW = 128 / NWV;     // 128 wave-pieces of the tile, PPW per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = (float *)smem;                                         // [EMA_BC][EMA_BSTR]
+    short *nxt = (short *)(smem + (size_t)EMA_BC * EMA_BSTR * 4);        // [EMA_BT] next token of the same code, -1 = end
+    int *head = (int *)((char *)nxt + EMA_BT * 2);                       // [K] last token of the tile with this code, -1 = none
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // persistent: a workgroup walks items (token block, 32-channel slice) with stride gridDim.x, and the NEXT item's tile is on
+    // its way into registers while this item's chains are walked (one workgroup per CU: nobody else would hide the loads)
+    const int nslice = D / EMA_BC;
+    const long nitems = ((N + EMA_BT - 1) / EMA_BT) * nslice;
+    f32x4 v[PPW];
+    auto fetch = [&](long item) {
+        const long tok0 = (item / nslice) * EMA_BT;
+        const int c0 = (int)(item % nslice) * EMA_BC;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave * PPW + i;                                // piece: channel q / 4, tokens (q % 4) * 256 + 4 lane ..
+            const int ch = q >> 2, t4 = (q & 3) * 256 + 4 * lane;
+            long n = tok0 + t4;
+            n = n < N ? n : (N - 4 > 0 ? N - 4 : 0);                     // (HW % 4 == 0: N is a multiple of 4)
+            const long b = n / HW;
+            const int hw = (int)(n - b * HW);
+            v[i] = __builtin_nontemporal_load((const f32x4 *)(z + ((size_t)b * D + c0 + ch) * HW + hw));
+        }
+    };
+    long item = blockIdx.x;
+    if (item < nitems) fetch(item);
+    for (; item < nitems; item += gridDim.x) {
+        const long tok0 = (item / nslice) * EMA_BT;
+        const int c0 = (int)(item % nslice) * EMA_BC;
+        for (int i = tid; i < K; i += NT) head[i] = -1;
+        __syncthreads();                                                 // head[] is initialised (and the previous item's walk is over)
+        for (int t = tid; t < EMA_BT; t += NT) {
+            const long n = tok0 + t;
+            const long long cj = (n < N) ? codes[n] : -1;
+            short nx = (short)-2;                                        // not in any chain
+            if (cj >= 0 && cj < K) nx = (short)atomicExch(&head[(int)cj], t);
+            nxt[t] = nx;
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave * PPW + i;
+            const int ch = q >> 2, t4 = (q & 3) * 256 + 4 * lane;
+            *(f32x4 *)(tile + ch * EMA_BSTR + t4) = v[i];
+        }
+        __syncthreads();
+        if (item + gridDim.x < nitems) fetch(item + gridDim.x);
+        // one (code, channel) per lane: 2 codes x 32 channels per wave-instruction; walk the code's chain, ONE atomic per present
+        // code.  Four codes per lane at a time: the walks are chains of dependent LDS reads (head -> value, next -> ...),
+        // interleaved they overlap each other's latency.
+        const int ch = lane & 31, hsel = lane >> 5;
+        const float *row = tile + ch * EMA_BSTR;
+        constexpr int STEP = 2 * NWV;
+        const bool count_here = (item % nslice) == 0;
+        for (int k0 = 2 * wave + hsel; k0 < K; k0 += 4 * STEP) {
+            int t[4], cnt[4];
+            float sum[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * STEP;
+                t[u] = k < K ? head[k] : -1;
+                sum[u] = 0.0f;
+                cnt[u] = 0;
+            }
+            while (t[0] >= 0 || t[1] >= 0 || t[2] >= 0 || t[3] >= 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t[u] >= 0) { sum[u] += row[t[u]]; t[u] = nxt[t[u]]; ++cnt[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * STEP;
+                if (cnt[u] > 0) {
+                    atomicAdd(&vectors_sum[(size_t)k * D + c0 + ch], sum[u]);
+                    if (count_here && ch == 0) atomicAdd(&cluster_size[k], (float)cnt[u]);
+                }
+            }
+        }
+        __syncthreads();                                                 // tile / head / nxt are free for the next item
+    }
+}
+
 int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int HW, long N, int K,
                               float *cluster_size, float *vectors_sum, hipStream_t st)
 {
@@ -183,7 +286,18 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(ema_zero_kernel, dim3(blocks), dim3(256), 0, st, cluster_size, (size_t)K, vectors_sum, n);
     }
-    if (K <= 8192)
+    if (K <= 4096 && (HW & 3) == 0 && (D & 31) == 0 && N >= 64 * EMA_BT && EMA_BIG) {
+        static unsigned long long done = 0;
+        const size_t shm = (size_t)EMA_BC * EMA_BSTR * 4 + EMA_BT * 2 + (size_t)K * 4;
+        int rc = dvq_allow_dynamic_lds((const void *)ema_accumulate_big_kernel, (int)shm, &done);
+        if (rc) return rc;
+        int ncu = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const long nitems = ((N + EMA_BT - 1) / EMA_BT) * (D / EMA_BC);
+        const unsigned grid = (unsigned)(nitems < ncu ? nitems : (ncu > 0 ? ncu : 256));
+        hipLaunchKernelGGL(ema_accumulate_big_kernel, dim3(grid), dim3(EMA_BTHREADS), shm, st, z,
+                           codes, D, HW, N, K, cluster_size, vectors_sum);
+    } else if (K <= 8192)
         hipLaunchKernelGGL(ema_accumulate_kernel<true>, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)K * sizeof(int), st, z,
                            codes, D, HW, N, K, cluster_size, vectors_sum);
     else
