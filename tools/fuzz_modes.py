@@ -47,9 +47,15 @@ def run(ncases=150, seed=12345, verbose=True):
       zq0, c0, l0 = vq_assign(zt_, Et_, pe, mt_, mode=_lib.MODE_EXACT)
       fmode = _lib.MODE_FILTER_WIDE if (D == 256 and case % 3 == 0) else _lib.MODE_FILTER     # every third D=256 case: wide pass 1
       zq1, c1, l1 = vq_assign(zt_, Et_, pf, mt_, mode=fmode)
+      # the same tokens ROW-MAJOR [N, D] through the row-major form of pass 1 (dvq_vq_assign_flat_f32): same bits
+      zr_ = zt_.reshape(B, D, -1).permute(0, 2, 1).reshape(-1, D).contiguous()
+      mr_ = None if mt_ is None else mt_.reshape(-1)
+      zq2, c2, l2 = vq_assign(zr_, Et_, _CodebookPrep(), mr_, mode=_lib.MODE_FILTER)
       torch.cuda.synchronize()
-      okc = torch.equal(c0, c1)
-      okz = bool(((zq0 == zq1) | (torch.isnan(zq0) & torch.isnan(zq1))).all())
+      okc = torch.equal(c0, c1) and torch.equal(c0.reshape(-1), c2)
+      zq2n = zq2.reshape(B, -1, D).permute(0, 2, 1).reshape(zq0.shape)
+      okz = bool(((zq0 == zq1) | (torch.isnan(zq0) & torch.isnan(zq1))).all()) and \
+            bool(((zq0 == zq2n) | (torch.isnan(zq0) & torch.isnan(zq2n))).all())
       a, b = float(l0[1]), float(l1[1])
       # the loss sums per-token fp32 terms; a rewritten token's provisional term is taken back in a different
       # fp32 order, so the two modes agree to ~1e-7 of the typical squared error, not of the final sum
