@@ -68,7 +68,7 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
 int dvq_launch_entropy_map(const float *img, int B, int H, int W, float *out, hipStream_t st);
 size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups, int Hid);
 size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid);
-int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st, bool has_tail);
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st);
 int dvq_launch_restart_pick(unsigned long long seed, long long n, int k, long long *out, hipStream_t st);
 int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *const *gn_b, int nb, int C, int Hid, void *prep,
                                         hipStream_t st);
@@ -592,7 +592,7 @@ int dvq_router_gate_prepare_f32(const float *w1, int nb, int C, int hidden, void
     if (C % 8 != 0 || nb * C > 1280) { dvq_set_error("%s: C=%d unsupported (C %% 8 == 0, num_branches*C <= 1280)", fn, C); return DVQ_EUNSUPPORTED; }
     if (w1_prep_bytes < dvq_router_gate_prep_bytes(nb, C, hidden)) { dvq_set_error("%s: buffer %zu < %zu bytes", fn, w1_prep_bytes, dvq_router_gate_prep_bytes(nb, C, hidden)); return DVQ_EWORKSPACE; }
     if (((uintptr_t)w1_prep & 255) != 0) { dvq_set_error("%s: buffer must be 256-byte aligned", fn); return DVQ_EINVAL; }
-    return hip_rc(dvq_launch_router_gate_prepare(w1, nb, C, hidden, w1_prep, (hipStream_t)stream, true), "router_gate_prepare");
+    return hip_rc(dvq_launch_router_gate_prepare(w1, nb, C, hidden, w1_prep, (hipStream_t)stream), "router_gate_prepare");
 }
 
 int dvq_router_gate_prepare_norm_f32(int nb, int C, int hidden, const float *gn_w_coarse, const float *gn_b_coarse,

@@ -99,11 +99,12 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
         bound = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3]));
         }
         float inv = 1.0f;
-        if (!(bound < 16384.0f) && bound < __builtin_inff()) {
+        if (bound > 0.0f && bound < __builtin_inff()) {
             int e;
             (void)frexpf(bound, &e);                         // bound = m 2^e, m in [0.5, 1)
-            xscale = ldexpf(1.0f, 13 - e);                   // brings the bound below 2^13
-            inv = ldexpf(1.0f, e - 13);
+            const int sh = 13 - e < 100 ? 13 - e : 100;      // brings the bound into [2^12, 2^13): up as well as down -- the bound is
+            xscale = ldexpf(1.0f, sh);                       // ~sqrt(n) above typical values, whose lo halves would otherwise be fp16
+            inv = ldexpf(1.0f, -sh);                         // subnormals (an absolute 2^-25 instead of 22 significand bits)
         }
         if (blockIdx.x == 0 && tid == 0) xs[0] = inv;
     }
@@ -239,11 +240,42 @@ __global__ __launch_bounds__(256, DVQ_POOL_WPE) void gate_pool_kernel(DvqGateArg
 
 // ---- 2. hidden-layer weight W1 [Hid, F] -> split fp16 tile images (Fp = F rounded up to 16, S = Fp/16):
 //   imgH / imgL [t][s][lane = 32h + c][j < 8] = hi / lo of W1[32t + c][16s + 8h + j]   (zero padded)
+//   The images hold w * 2^sh with the power of two that brings max |W1| into [2^14, 2^15): fp16 keeps 11 bits below 2^-14 no
+//   longer (subnormals), so without it lo = fp16(w - hi) of a default-initialised layer (|w| ~ 0.04, w - hi ~ 2e-5) is already a
+//   subnormal and a layer of small weights (|w| ~ 1e-5, e.g. behind GroupNorm weights of a few thousand) would lose hi as well --
+//   a golden of that shape is off by 2e-3 without the scale.  tail[DVQ_GATE_WMAX] = max |W1| (w1_max_kernel),
+//   tail[DVQ_GATE_WINV] = 2^-sh for the matrix kernels' epilogues (exact: applied to the fp32 accumulators).
+#define DVQ_GATE_WMAX 8
+#define DVQ_GATE_WINV 9
+__global__ __launch_bounds__(256) void w1_max_kernel(const float *__restrict__ W1, size_t n, unsigned *__restrict__ wmax)
+{
+    __shared__ unsigned red[4];
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(fabsf(W1[i])));           // non-negative floats order like their bits (NaN above infinity)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(wmax, max(max(red[0], red[1]), max(red[2], red[3])));
+}
 __global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__ W1, int Hid, int F, int Fp,
                                                        _Float16 *__restrict__ imgH, _Float16 *__restrict__ imgL,
                                                        float *__restrict__ tail)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && tail != nullptr) tail[0] = 0.0f;   // no GroupNorm maxima (yet): gate_pool_kernel, nbound
+    const float wmax = tail[DVQ_GATE_WMAX];
+    float wscale = 1.0f, winv = 1.0f;
+    if (wmax > 0.0f && wmax < __builtin_inff()) {            // zero, infinite or NaN weights: as they are
+        int e;
+        (void)frexpf(wmax, &e);                              // wmax = m 2^e, m in [0.5, 1)
+        const int sh = 15 - e < 100 ? 15 - e : 100;
+        wscale = ldexpf(1.0f, sh);
+        winv = ldexpf(1.0f, -sh);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tail[0] = 0.0f;                                      // no GroupNorm maxima (yet): gate_pool_kernel, nbound
+        tail[DVQ_GATE_WINV] = winv;
+    }
     const size_t per_tile = (size_t)32 * Fp;
     const size_t total = (size_t)((Hid + 31) / 32) * per_tile;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -252,7 +284,7 @@ __global__ __launch_bounds__(256) void w1_split_kernel(const float *__restrict__
         const int s16 = r >> 9, lane = (r >> 3) & 63, j = r & 7;
         const int k = 16 * s16 + 8 * (lane >> 5) + j;
         const int row = t * 32 + (lane & 31);
-        const float w = (row < Hid && k < F) ? W1[(size_t)row * F + k] : 0.0f;
+        const float w = (row < Hid && k < F) ? W1[(size_t)row * F + k] * wscale : 0.0f;
         const _Float16 hi = (_Float16)w;
         imgH[i] = hi;
         imgL[i] = (_Float16)(w - (float)hi);
@@ -269,7 +301,8 @@ template <int G, int CB>
 __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     DvqGateArgs a, const float2 *__restrict__ ab, const float *__restrict__ pool,
     const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL, const float *__restrict__ b1,
-    const float *__restrict__ W2, const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate)
+    const float *__restrict__ W2, const float *__restrict__ b2, int Hid, int act, float *__restrict__ gate,
+    const float *__restrict__ wtail)
 {
     // LDS: per cell block XH | XL halves [Fp/16][64 lanes = 32h + cell][8] each (B operands), then bias / output rows
     extern __shared__ __attribute__((aligned(16))) float X[];
@@ -435,12 +468,13 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
     // SIMD plus software pipelining: the fragments of the next three groups of four k-steps (3 x 8 loads = 96 VGPRs) are
     // in flight while the current group's MFMAs run.  Groups are numbered through this wave's tiles:
     // g -> (tile wave + GATE_NW (g / GPT), k-steps 4 (g % GPT) ..).
+    const float hid_scale = inv_scale * wtail[DVQ_GATE_WINV];         // feature scale and weight scale (w1_split_kernel), both powers of two
     auto epilogue = [&](int t, const f32x16 &acc, float (&pt)[G]) {    // bias, activation, contraction with the output layer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (j < Hid) {
-                const float yv = acc[r] * inv_scale + PB[j];
+                const float yv = acc[r] * hid_scale + PB[j];
                 // SiLU with the fast exp and division (v_exp_f32 / v_rcp_f32 based, ~1-2 ulp): the library expf + IEEE division were
                 // a fifth of the kernel; the logits' tolerance is 1e-4 (measured error unchanged at ~1e-6)
                 const float hv = (act == 1) ? __fdividef(yv, 1.0f + __expf(-yv)) : (yv > 0.0f ? yv : 0.0f);
@@ -578,7 +612,7 @@ template <int G, int S>
 __global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
     const char *__restrict__ ximg, const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL,
     const float *__restrict__ b1, const float *__restrict__ W2, int Hid, int act, long ncell, int nblocks,
-    const float *__restrict__ xs, float *__restrict__ part)
+    const float *__restrict__ xs, float *__restrict__ part, const float *__restrict__ wtail)
 {
     constexpr int CH = (S % 8 == 0) ? 8 : 4;                 // k-steps per ring chunk
     constexpr int NCH = S / CH;                              // chunks per cell block
@@ -632,7 +666,7 @@ __global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
         if (j < Hid && tile_ok) v = (row == 0) ? b1[j] : W2[(size_t)(row - 1) * Hid + j];
         PB[wave * (1 + G) * 32 + i] = v;
     }
-    const float inv_scale = xs[0];
+    const float inv_scale = xs[0] * wtail[DVQ_GATE_WINV];    // feature scale (gate_pool_kernel) and weight scale (w1_split_kernel)
     const float *pb = PB + wave * (1 + G) * 32;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // A fragments and the first RING - 2 chunks (mine) are here
 
@@ -884,7 +918,7 @@ size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups
     (void)groups;
     const size_t pool = align256r((size_t)B * nb * C * hc * wc * sizeof(float));
     const size_t ximg = gate_ximg_bytes(nb, B, C, hc, wc);
-    return align256r((size_t)B * nb * C * sizeof(float2)) + (pool > ximg ? pool : ximg) + gate_img_bytes(nb, C, Hid) +
+    return align256r((size_t)B * nb * C * sizeof(float2)) + (pool > ximg ? pool : ximg) + gate_img_bytes(nb, C, Hid) + 256 +
            gate_part_bytes(nb, B, hc, wc, Hid) + 512;
 }
 
@@ -919,7 +953,8 @@ int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *c
 }
 
 // hidden-layer weight -> split fp16 tile images (kept by the caller across calls while the weight is unchanged)
-int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st, bool has_tail)
+// (prep: images + the 256-byte tail, always)
+int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st)
 {
     const int F = nb * C, Fp = (F + 15) & ~15;
     _Float16 *imgH = (_Float16 *)prep;
@@ -927,8 +962,14 @@ int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void
     size_t total = (size_t)((Hid + 31) / 32) * 32 * Fp;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL,
-                       has_tail ? (float *)((char *)prep + gate_img_bytes(nb, C, Hid)) : nullptr);
+    float *tail = (float *)((char *)prep + gate_img_bytes(nb, C, Hid));
+    (void)hipMemsetAsync(tail + DVQ_GATE_WMAX, 0, sizeof(float), st);
+    const size_t nw = (size_t)Hid * F;
+    int mblocks = (int)((nw + 256 * 16 - 1) / (256 * 16));
+    if (mblocks > 512) mblocks = 512;
+    if (mblocks < 1) mblocks = 1;
+    hipLaunchKernelGGL(w1_max_kernel, dim3(mblocks), dim3(256), 0, st, W1, nw, (unsigned *)(tail + DVQ_GATE_WMAX));
+    hipLaunchKernelGGL(w1_split_kernel, dim3(blocks), dim3(256), 0, st, W1, Hid, F, Fp, imgH, imgL, tail);
     return (int)hipGetLastError();
 }
 
@@ -966,11 +1007,12 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
     char *after = (char *)pool + (pool_area > ximg_area ? pool_area : ximg_area);
     const _Float16 *imgH = (const _Float16 *)w1_prep;
     if (act != 0 && imgH == nullptr) {
-        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, after, st, false);
+        int rc = dvq_launch_router_gate_prepare(W1, nb, C, Hid, after, st);
         if (rc) return rc;
         imgH = (const _Float16 *)after;
     }
     const _Float16 *imgL = imgH ? imgH + (size_t)((Hid + 31) / 32) * 32 * Fp : nullptr;
+    const float *wtail = imgH ? (const float *)((const char *)imgH + gate_img_bytes(nb, C, Hid)) : nullptr;   // act == 0: unused
     // the GEMM form (gate_gemm_kernel): a hidden layer with GroupNorm'd inputs whose groups are whole octets of channels that fit the
     // pooling workgroup's LDS, F a multiple of 16 with an instantiated number of k-steps
     const int cpg = groups > 0 ? C / groups : 0;
@@ -983,7 +1025,7 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         const float *nbound = (w1_prep != nullptr) ? (const float *)((const char *)w1_prep + gate_img_bytes(nb, C, Hid)) : nullptr;
         char *ximg = (char *)pool;
         const _Float16 *imgLg = imgL;
-        float *part = (float *)(after + gate_img_bytes(nb, C, Hid));
+        float *part = (float *)(after + gate_img_bytes(nb, C, Hid) + 256);
         float *xs = (float *)((char *)part + gate_part_bytes(nb, B, hc, wc, Hid));
         const int nblocks = (int)((ncell + 31) / 32);
         if ((ncell & 31) != 0)                               // the last block's unused cell columns must hold finite values
@@ -1012,7 +1054,7 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
             int rc = dvq_allow_dynamic_lds((const void *)gate_gemm_kernel<GG, SS>, (int)shm, &done_);                  \
             if (rc) return rc;                                                                                         \
             hipLaunchKernelGGL((gate_gemm_kernel<GG, SS>), dim3(CG, HG), dim3(256), shm, st, ximg, imgH, imgLg, b1, W2, \
-                               Hid, act, ncell, nblocks, xs, part);                                                    \
+                               Hid, act, ncell, nblocks, xs, part, wtail);                                             \
         } while (0)
         if (nb == 2) {
             switch (S16) {
@@ -1060,7 +1102,7 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
         int rc = dvq_allow_dynamic_lds((const void *)router_gate_kernel<GG, CC>, 160 * 1024 - 256, &done_);            \
         if (rc) return rc;                                                                                             \
         hipLaunchKernelGGL((router_gate_kernel<GG, CC>), dim3(grid), dim3(GATE_NW * 64), shmem, st, a, stats, pool,    \
-                           imgH, imgL, b1, W2, b2, Hid, act, gate);                                                    \
+                           imgH, imgL, b1, W2, b2, Hid, act, gate, wtail);                                             \
     } while (0)
     if (nb == 2) { if (cb2) DVQ_GATE_LAUNCH(2, 2); else DVQ_GATE_LAUNCH(2, 1); }
     else         { if (cb2) DVQ_GATE_LAUNCH(3, 2); else DVQ_GATE_LAUNCH(3, 1); }
