@@ -108,7 +108,7 @@ struct DvqLossTail {
 };
 #define DVQ_QSHARDS 64        // the pass-1 -> resolver queue is sharded this many ways (power of two)
 #define DVQ_QCOUNT0 8         // counters[DVQ_QCOUNT0 + shard] = tokens queued in that shard
-#define DVQ_COUNTER_BYTES 512
+#define DVQ_COUNTER_BYTES 1024
 // The counter block (ints) at the start of the filter path's workspace.  "report" words are only ever overwritten (what
 // dvq_vq_assign_fallback_count_offset points at); "live" words are zero between ops: the list kernel's finishing workgroup puts
 // them back (so does each chunk's last resolver slice with its ticket pair), and the zero kernel in front of the op is only
@@ -118,6 +118,8 @@ struct DvqLossTail {
 #define DVQ_C_EXACT    2      // live: exact-list append counter
 #define DVQ_C_TICKET   4      // live: finalize ticket of the list kernel
 #define DVQ_C_PREPASS  5
+#define DVQ_SPLIT_TICKET0 128     // live: counters[DVQ_SPLIT_TICKET0 + token block] = slices done (split form of pass 1, small batches)
+#define DVQ_SPLIT_MAX_BLOCKS 64   // ... which serves up to this many token blocks of 128 (beyond: no gain measured, profiles/r05_small_batch.json)
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
 // gate just read -- above it with the non-temporal hint.  profiles/r04_cache_policy.json: one batch at a time, plain loads pay up to

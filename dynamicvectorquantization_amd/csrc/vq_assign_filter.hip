@@ -250,6 +250,11 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // diagnostic of the tuning build only: per-token (best, second, 2W, code) of the production arithmetic for the bound audit
 // (tools/bound_audit.py --production).  Written to a buffer of its own; no output value is computed from it.
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
+// ... and stage stamps of the split form's workgroups (100-MHz wall clock): [workgroup][8] (tools/split_timeline.py)
+__device__ unsigned long long *g_dvq_stamps = nullptr;
+#define DVQ_STAMP(i) do { if (SPLIT && g_dvq_stamps != nullptr && threadIdx.x == 0) g_dvq_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define DVQ_STAMP(i) do { } while (0)
 #endif
 
 // (Round 5 built the resolver INTO this launch -- consumer workgroups appended to the grid, records handed over with sc1
@@ -264,14 +269,22 @@ __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
 // VQEmbedding.forward) -- the same tensor as [B = N, D, HW = 1], but read and written as what it is: a lane's 8 channels of a
 // k-step are 32 contiguous bytes = two 16-byte accesses (32 loads and 32 stores per lane instead of 128 each; with lane = token
 // and 4-byte accesses at a stride of D * 4 bytes every wave-instruction touched 64 lines for 256 useful bytes).
-template <int D, int SEL, bool CONV, bool FOLD, bool NT, bool FLAT = false>
+// SPLIT (small batches: fewer token blocks than CUs; vq_assign_filter_split_kernel): `ksplit` workgroups share a token block, each
+// scores it against its own slice of the code tiles -- a lone workgroup's code loop is an issue-bound ~1330 cycles per tile whoever
+// else is on the chip, 20 of the 27 us the kernel takes for BASELINE configs[0] (1024 tokens on 8 of 256 CUs) -- and leaves
+// (best, second, code) per token in `split`; the workgroup that takes a block's last ticket merges them (lower slice wins ties, as
+// the lower tile does in the loop) and runs the epilogue of the whole block.  Everything downstream sees what one workgroup
+// would have produced, up to which of two equal scores is called best (tokens that close are undecided either way).
+template <int D, int SEL, bool CONV, bool FOLD, bool NT, bool FLAT = false, bool SPLIT = false>
 __device__ __forceinline__ void pass1_body(
     const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
     const float *__restrict__ E, const float *__restrict__ mask,
     int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
     double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
-    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv)
+    char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv,
+    f32x4 *__restrict__ split = nullptr, int ksplit = 1)
 {
+    static_assert(!SPLIT || (SEL == 0 && !CONV && !FOLD), "the split form is a dense op");
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
     static_assert(!FLAT || (SEL == 0 && !CONV), "the row-major form is a dense op");
@@ -293,11 +306,16 @@ __device__ __forceinline__ void pass1_body(
     static_assert(!FLAT || NW * FLAT_TRW <= NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + NW * 2048, "the images fit the kernel's LDS");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *enraw = (float *)(lds + NBUF * IMG_BYTES);        // [NBUF][NW][64] accumulator seeds, per-wave copy
+    DVQ_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int T = dvq_num_tiles(K);
+    // SPLIT: this workgroup's slice of the code tiles [t_lo, t_lo + T) -- the loop below runs on slice-relative tile numbers
+    const int ks = SPLIT ? (int)(blockIdx.x % (unsigned)ksplit) : 0;
+    const int t_lo = SPLIT ? (int)((long)dvq_num_tiles(K) * ks / ksplit) : 0;
+    const int T = SPLIT ? (int)((long)dvq_num_tiles(K) * (ks + 1) / ksplit) - t_lo : dvq_num_tiles(K);
+    if constexpr (SPLIT) img += (size_t)t_lo * TILE_STRIDE;
     const float sB = meta->scale_b;
     char *scr = lds + NBUF * IMG_BYTES + NBUF * NW * 64 * 4 + wave * 2048;   // this wave's permutation scratch
 
@@ -325,7 +343,7 @@ __device__ __forceinline__ void pass1_body(
 #pragma unroll
         for (int q = 0; q < PER_TILE; ++q) issue_piece(t, q);
     };
-    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_id = SPLIT ? (int)(blockIdx.x / (unsigned)ksplit) : xcd_swizzle(blockIdx.x, gridDim.x);
     // SEL == 2 parks the coarser branches in the ring slots from `pre` on: 2 slots = D x 128 B for the 2x-coarser
     // branch (dual: slots 2, 3; triple: slots 1, 2), slot 3 for the triple's 4x-coarser branch (D x 32 B)
     const int pre = (SEL == 2) ? ((rv.G == 2) ? 2 : 1) : 3;  // code tiles in flight before the prologue
@@ -728,6 +746,7 @@ __device__ __forceinline__ void pass1_body(
         asm volatile("" ::: "memory");
     }
     for (int t = pre; t < 3; ++t) issue(t);                  // (SEL == 2) the code tiles that waited for those slots
+    DVQ_STAMP(1);
 
     // ---- 16x16x32 code loop: fragment F = c2 * S32 + s' of the tile feeds two MFMAs (token halves t2 = 0, 1);
     // accumulator acc16[c2][t2][i] = code 16 c2 + 4 (lane >> 4) + i against token 16 t2 + (lane & 15)
@@ -840,7 +859,7 @@ __device__ __forceinline__ void pass1_body(
             const int r = (int)(__float_as_uint(mb) & 15u);
             rb[t2] = mb;
             rs[t2] = ms;
-            rc[t2] = mt * 32 + 16 * (r >> 2) + 4 * mq + (r & 3);
+            rc[t2] = (mt + t_lo) * 32 + 16 * (r >> 2) + 4 * mq + (r & 3);
         }
         const int srcl = c & 15;
         const float x0 = __shfl(rb[0], srcl), x1 = __shfl(rb[1], srcl);
@@ -849,6 +868,51 @@ __device__ __forceinline__ void pass1_body(
         best = (c >> 4) ? x1 : x0;
         second = (c >> 4) ? y1 : y0;
         code = (c >> 4) ? c1 : c0;
+    }
+    DVQ_STAMP(2);
+    if constexpr (SPLIT) {
+        // hand-off without fences (MI355X guide, inter-workgroup visibility: every payload store write-through (sc1) and drained by
+        // its wave, the workgroup's barrier, ONE agent-scope add per workgroup; the workgroup whose add came last reads with sc1
+        // loads after a barrier its adding wave joins).  A __threadfence() pair instead cost 3-70 us with the grid size.
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        __shared__ int s_last;
+        gu64 *mine = (gu64 *)(split + ((size_t)tile_id * ksplit) * 128 + wave * 32 + c);      // [block][slice][128 tokens] x 16 B
+        if (h == 0) {
+            gu64 *e = mine + (size_t)ks * 128 * 2;
+            __hip_atomic_store(e, ((unsigned long long)__float_as_uint(second) << 32) | __float_as_uint(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(e + 1, (unsigned long long)(unsigned)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        DVQ_STAMP(3);
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[DVQ_SPLIT_TICKET0 + tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == ksplit - 1);
+            if (old == ksplit - 1)                           // self-cleaning (DVQ_MODE_WS_CLEAN)
+                __hip_atomic_store(&counters[DVQ_SPLIT_TICKET0 + tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        DVQ_STAMP(4);
+        if (!s_last) return;
+        float mb = -__builtin_inff(), ms = -__builtin_inff();
+        int mc = 0;
+        unsigned long long e0[8], e1[8];                     // all slices' entries in flight at once (ksplit <= 8; past the end: repeats)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kk = k < ksplit ? k : ksplit - 1;
+            e0[k] = __hip_atomic_load(mine + (size_t)kk * 128 * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e1[k] = __hip_atomic_load(mine + (size_t)kk * 128 * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float eb = __uint_as_float((unsigned)e0[k]), es = __uint_as_float((unsigned)(e0[k] >> 32));
+            const bool other_wins = k < ksplit && eb > mb;
+            ms = (k < ksplit) ? fmaxf(other_wins ? mb : eb, fmaxf(ms, es)) : ms;
+            mc = other_wins ? (int)(unsigned)e1[k] : mc;
+            mb = other_wins ? eb : mb;
+        }
+        best = mb; second = ms; code = mc;
+        DVQ_STAMP(5);
     }
     const float thr = best - thr2W;
     const bool final_ok = (best - second) > thr2W;
@@ -871,7 +935,9 @@ __device__ __forceinline__ void pass1_body(
     const int sel_rep = (SEL == 0 || sel_mask < 0.0f) ? (SEL == 0 ? 1 : 0) : (sel_mask == 1.0f ? 1 : (sel_mask == 0.25f ? 2 : 4));
     const bool queued = undecided && sel_rep > 0;           // sel_rep: 0 for a copy, else positions per edge of the lane's cell
     const unsigned long long umask = __ballot(queued && h == 0);
-    const int shard = blockIdx.x & (DVQ_QSHARDS - 1);
+    // (SPLIT: which workgroup merges a block varies from run to run -- the shard is a function of the tokens, per wave, so that the
+    // queue's layout, the fallback counts and the resolver's chunks do not)
+    const int shard = (SPLIT ? tile_id * NW + wave : (int)blockIdx.x) & (DVQ_QSHARDS - 1);
     int slot_raw = 0;
     if (umask != 0ull && lane == 0) slot_raw = atomicAdd(&counters[DVQ_QCOUNT0 + shard], (int)__popcll(umask));
     if (valid && hopeless && h == 0) {
@@ -904,7 +970,9 @@ __device__ __forceinline__ void pass1_body(
         m_tok = (SEL != 0) ? __builtin_fabsf(sel_mask) : ((mask != nullptr) ? mask[n] : 1.0f);
         if (zq != nullptr || partials != nullptr) {
             const float *ep = E + (size_t)code * D + 8 * h;
-            constexpr int SB = (S16 < 2) ? S16 : 2;     // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline)
+            // gathers per batch: 2 k-steps (A/B on MI355X: 2 beats 1, 4, 8 and a 3-deep pipeline) where other workgroups hide the
+            // latency; the split form's merging workgroup is alone on its CU and takes 8 (two round trips instead of eight)
+            constexpr int SB = SPLIT ? ((S16 < 8) ? S16 : 8) : ((S16 < 2) ? S16 : 2);
             // `zq != nullptr` is tested ONCE (a scalar branch on the kernel argument): with the test
             // inside the loop on the per-lane pointer every one of the 128 stores became its own
             // exec-masked branch to an out-of-line block.
@@ -1003,6 +1071,7 @@ __device__ __forceinline__ void pass1_body(
         }
         lsum *= m_tok;
     }
+    DVQ_STAMP(6);
     if (umask != 0ull) {                                    // wave-uniform
         const int base = __shfl(slot_raw, 0);
         int slot = base + (int)__popcll(umask & ((1ull << c) - 1ull));   // rank among the wave's queued tokens
@@ -1045,8 +1114,9 @@ __device__ __forceinline__ void pass1_body(
         double *red = (double *)lds;
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
-        if (tid == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) partials[SPLIT ? tile_id : (int)blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+    DVQ_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1743,22 +1813,23 @@ __device__ __forceinline__ double resolve_chunk(
                 atomicMin(&gm->best, best[tid]);
             }
             if (overflow && tid == 0) atomicOr(oflag, 1);
+            // everything handed over is an agent-scope atomic (and read back with agent-scope loads): what the ticket needs is
+            // that every wave's atomics have COMPLETED before it is taken -- a counter wait per wave and the barrier, no cache
+            // write-back / invalidate (a __threadfence() pair here cost 1.5 - 3 us per slice on a small batch)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
-                __threadfence();
-                misc[2] = (atomicAdd(ticket, 1) == nslice - 1);
-            }
+            if (tid == 0)
+                misc[2] = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslice - 1);
             __syncthreads();
             if (!misc[2]) { *not_last = true; return 0.0; }   // not the last slice (its partial is written by the last)
-            __threadfence();
             if (tid < nlive) {
                 const RecMeta *gm = (const RecMeta *)(records + (size_t)(base + tid) * rec_bytes(D) + (size_t)D * 4);
                 best[tid] = __hip_atomic_load(&gm->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid == 0) {
                 misc[3] = __hip_atomic_load(oflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ticket[0] = 0;                                   // every slice has been here: the pair is clean for the next op
-                ticket[1] = 0;
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every slice has been here: the
+                __hip_atomic_store(ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // pair is clean for the next op
             }
             __syncthreads();
             overflow = misc[3] != 0;
@@ -1909,6 +1980,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_flat_kernel(
     char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv)
 {
     pass1_body<D, 0, false, FOLD, true, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records, rec_cap, rv, cv);
+}
+
+// small batches: `ksplit` workgroups per token block, each on its slice of the code tiles (SPLIT, see pass1_body)
+template <int D, bool FLAT>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_split_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, f32x4 *__restrict__ split, int ksplit)
+{
+    const DvqRouted rv = {};
+    const DvqConv cv = {};
+    pass1_body<D, 0, false, false, false, FLAT, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records,
+                                                      rec_cap, rv, cv, split, ksplit);
 }
 
 // the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
@@ -2095,6 +2181,7 @@ struct DvqTune {
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
     int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
     int flat;            // HW == 1 (row-major [N, D]) through the row-major form of pass 1 (0: through the NCHW kernel, for the A/B)
+    int split;           // small batches: several workgroups per token block (SPLIT form of pass 1); 0: never (for the A/B)
 };
 #ifndef DVQ_PIPE_DEFAULT
 #define DVQ_PIPE_DEFAULT 0
@@ -2104,25 +2191,27 @@ int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, c
                     int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
                     int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1};
+static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1, 1};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
     else if (!strcmp(key, "pipe")) g_tune.pipe = value;
     else if (!strcmp(key, "flat")) g_tune.flat = value;
+    else if (!strcmp(key, "split")) g_tune.split = value;
     else return -1;
     return 0;
 }
 // device buffer the tuning build's pass 1 writes its per-token diagnostics to (null = off): tokdbg [N][4] f32 = best, second,
-// 2W, code.  (The first argument was round 3's clock-stamp buffer; it is ignored.)
+// 2W, code; stamps [workgroup][8] u64 = stage times of the split form of pass 1 (null = off)
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *stamps, void *tokdbg)
 {
-    (void)stamps;
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_stamps), &stamps, sizeof(void *));
+    if (rc) return rc;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1};
+static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1, 1};
 #endif
 
 static bool dvq_flat_form_enabled() { return g_tune.flat != 0; }
@@ -2156,11 +2245,27 @@ static int resolver_slices(int K)
 
 // ws_extra: [counters DVQ_COUNTER_BYTES][chunk ticket + overflow flag: 2 ints per resolver chunk]
 //           [exact list N ints][records cap * rec_bytes]
+// the split form of pass 1 (small batches): slices per token block, 1 = not taken.  As many as keep the grid within one workgroup
+// per CU (256) and leave a slice two code tiles, at most 8.
+static int split_slices(int K, long N)
+{
+    const long nb = (N + 127) / 128;
+    if (!g_tune.split || nb > DVQ_SPLIT_MAX_BLOCKS) return 1;
+    int ks = 8;
+    while (ks > 1 && (nb * ks > 256 || dvq_num_tiles(K) / ks < 2)) ks >>= 1;
+    return ks;
+}
+static size_t split_bytes(long N)
+{
+    const long nb = (N + 127) / 128;
+    return nb <= DVQ_SPLIT_MAX_BLOCKS ? align256((size_t)nb * 8 * 128 * sizeof(f32x4)) : 0;
+}
+
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
 {
     (void)HW; (void)K;
     return DVQ_COUNTER_BYTES + align256((size_t)rec_capacity(N) / RES_SLOTS * 2 * sizeof(int)) +
-           align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D));
+           align256((size_t)N * sizeof(int)) + align256((size_t)rec_capacity(N) * rec_bytes(D)) + split_bytes(N);
 }
 
 int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st)
@@ -2200,6 +2305,7 @@ struct FilterWs {
     int *counters, *chunk_sync, *exact_list;
     char *records;
     int cap;
+    f32x4 *split;                                            // [token block][slice < 8][128] of the split form (small batches), else null
 };
 
 static FilterWs carve_ws(void *ws_extra, long N, int D)
@@ -2211,7 +2317,7 @@ static FilterWs carve_ws(void *ws_extra, long N, int D)
     const size_t sync_bytes = align256((size_t)w.cap / RES_SLOTS * 2 * sizeof(int));
     w.exact_list = (int *)((char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes);
     w.records = (char *)ws_extra + DVQ_COUNTER_BYTES + sync_bytes + align256((size_t)N * sizeof(int));
-    (void)D;
+    w.split = split_bytes(N) ? (f32x4 *)(w.records + align256((size_t)w.cap * rec_bytes(D))) : nullptr;
     return w;
 }
 
@@ -2234,6 +2340,26 @@ static int launch_pass1_form(const float *z, const char *img16, const DvqF16Meta
     static unsigned long long done = 0;
     const size_t shmem1 = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
     const unsigned grid = (unsigned)((N + 127) / 128);
+    if constexpr (SEL == 0 && !CONV && !FOLD) {
+        // fewer token blocks than CUs: several workgroups per block, each on a slice of the code tiles
+        const int ks = split_slices(K, N);
+        if (ks > 1 && w.split != nullptr) {
+            const bool flat = HW == 1 && dvq_flat_form_enabled() && (((uintptr_t)z | (uintptr_t)zq) & 15) == 0;
+            static unsigned long long done_s = 0, done_sf = 0;
+            int rcs = flat ? dvq_allow_dynamic_lds((const void *)vq_assign_filter_split_kernel<D, true>, (int)shmem1, &done_sf)
+                           : dvq_allow_dynamic_lds((const void *)vq_assign_filter_split_kernel<D, false>, (int)shmem1, &done_s);
+            if (rcs) return rcs;
+            if (flat)
+                hipLaunchKernelGGL((vq_assign_filter_split_kernel<D, true>), dim3(grid * ks), dim3(256), shmem1, st,
+                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                                   w.cap / DVQ_QSHARDS, w.split, ks);
+            else
+                hipLaunchKernelGGL((vq_assign_filter_split_kernel<D, false>), dim3(grid * ks), dim3(256), shmem1, st,
+                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                                   w.cap / DVQ_QSHARDS, w.split, ks);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (SEL == 0 && !CONV) {
         // HW == 1 is a row-major [N, D] tensor: 16-byte accesses along a token's row (rows are 16-byte aligned: D % 16 == 0)
         if (HW == 1 && dvq_flat_form_enabled() && (((uintptr_t)z | (uintptr_t)zq) & 15) == 0) {

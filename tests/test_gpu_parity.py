@@ -546,13 +546,15 @@ def test_hot_path_is_graph_capturable(dev):
     assert torch.equal(got[2], loss)
 
 
-def test_filter_queue_overflow_falls_back_to_exact(dev):
+@pytest.mark.parametrize("B", [16, 8, 4])
+def test_filter_queue_overflow_falls_back_to_exact(dev, B):
     """a codebook with widely mixed norms leaves most tokens undecided: every shard of the resolver queue
-    fills up and the remainder goes through the exact list; output still equals the exact mode bit for bit"""
+    fills up and the remainder goes through the exact list; output still equals the exact mode bit for bit
+    (B = 8, 4: the split form of pass 1 -- several workgroups per token block -- with full shards)"""
     from dynamicvectorquantization_amd import synth, _lib
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign
     rng = np.random.default_rng(3)
-    K, D, B = 1024, 256, 16
+    K, D = 1024, 256
     E = synth.codebook_trained(K, D, seed=77)
     E = np.ascontiguousarray(E * np.exp2(rng.integers(-5, 5, size=(K, 1))).astype(np.float32))
     zt = torch.from_numpy(synth.z_tokens(E, B, 32, 32, 4242)).to(dev)
@@ -562,7 +564,10 @@ def test_filter_queue_overflow_falls_back_to_exact(dev):
     zq0, c0, l0 = vq_assign(zt, Et, pe, mask, mode=_lib.MODE_EXACT)
     zq1, c1, l1 = vq_assign(zt, Et, pf, mask, mode=_lib.MODE_FILTER)
     queued, listed = pf.fallback_count()
-    assert queued == 4096 and listed > 1000, (queued, listed)        # 64 shards x 64 slots full, the rest listed
+    if B == 16:
+        assert queued == 4096 and listed > 1000, (queued, listed)    # 64 shards x 64 slots full, the rest listed
+    else:
+        assert queued >= 1024 and listed > 1000, (queued, listed)    # full shards
     assert torch.equal(c0, c1) and torch.equal(zq0, zq1)
     assert abs(float(l0[1]) - float(l1[1])) <= 1e-6 * abs(float(l0[1]))
 
