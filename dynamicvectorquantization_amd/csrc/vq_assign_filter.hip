@@ -253,8 +253,11 @@ __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
 // ... and stage stamps of the split form's workgroups (100-MHz wall clock): [workgroup][8] (tools/split_timeline.py)
 __device__ unsigned long long *g_dvq_stamps = nullptr;
 #define DVQ_STAMP(i) do { if (SPLIT && g_dvq_stamps != nullptr && threadIdx.x == 0) g_dvq_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// ... and of the resolver's workgroups, behind those: [4096 + workgroup][8]
+#define DVQ_RSTAMP(i) do { if (g_dvq_stamps != nullptr && threadIdx.x == 0 && blockIdx.y == 0) g_dvq_stamps[(size_t)(4096 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define DVQ_STAMP(i) do { } while (0)
+#define DVQ_RSTAMP(i) do { } while (0)
 #endif
 
 // (Round 5 built the resolver INTO this launch -- consumer workgroups appended to the grid, records handed over with sc1
@@ -1516,8 +1519,8 @@ struct ResLds {
     static constexpr int REWR = BEST + RES_SLOTS * 8;        // [RES_SLOTS] int
     static constexpr int MISC = REWR + RES_SLOTS * 4;        // [8] int: 0 candidate count, 1 rewrite count, 2 last slice, 3 overflow flag,
                                                              //          4 live slots of the chunk, 5 chunk is the shard's last
-    static constexpr int RED = MISC + 32;                    // [4] double
-    static constexpr int BYTES = RED + 32;
+    static constexpr int RED = MISC + 32;                    // [DVQ_RES_WAVES] double
+    static constexpr int BYTES = RED + 8 * DVQ_RES_WAVES;
     static_assert(CAND % 16 == 0 && BEST % 8 == 0 && RED % 8 == 0, "carve alignment");
 };
 
@@ -1584,6 +1587,7 @@ __device__ __forceinline__ double resolve_chunk(
         }
     }
     __syncthreads();
+    DVQ_RSTAMP(2);
     const bool live = c < nlive;
     const char *rec = srec + (live ? c : 0) * RB;
     f16x8 zh[S16];
@@ -1749,8 +1753,8 @@ __device__ __forceinline__ double resolve_chunk(
         if (!(DVQ_FOLD_ABL & 2)) {
             // the reference's norm of h (ATen order: 32 partial sums a[i % 32], ((a[l] + a[l+8]) + a[l+16]) + a[l+24], then l = 0..7
             // left to right) for the exact chains: 8 lanes per token, lane l owns a[l], a[l+8], a[l+16], a[l+24]
-            static_assert(RW * 64 == RES_SLOTS * 8, "8 lanes per queued token");
-            const int tk = tid >> 3, l8 = tid & 7;
+            static_assert(RW * 64 >= RES_SLOTS * 8, "8 lanes per queued token");
+            const int tk = (tid >> 3) < RES_SLOTS ? (tid >> 3) : RES_SLOTS - 1, l8 = tid & 7;   // (threads past the last token: idle repeats)
             const float *hv = (const float *)(srec + tk * RB);
             float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int k0 = 0; k0 < D; k0 += 32)
@@ -1760,7 +1764,7 @@ __device__ __forceinline__ double resolve_chunk(
             float sn = __shfl(tl, lane & ~7);
 #pragma unroll
             for (int i = 1; i < 8; ++i) sn = __fadd_rn(sn, __shfl(tl, (lane & ~7) + i));
-            if (l8 == 0 && tk < nlive) ((RecMeta *)(srec + tk * RB + (size_t)D * 4))->xn = sn;
+            if (l8 == 0 && (tid >> 3) < nlive) ((RecMeta *)(srec + tk * RB + (size_t)D * 4))->xn = sn;
         }
         __syncthreads();
     }
@@ -1769,6 +1773,7 @@ __device__ __forceinline__ double resolve_chunk(
     bool overflow = ncand_raw > RES_CAND;             // hand the whole group to the exact list
     const int ncand = overflow ? 0 : ncand_raw;
 
+    DVQ_RSTAMP(3);
     // ---- exact chains: one thread per (token, candidate)
     for (int i = tid; i < ncand; i += RW * 64) {
         const unsigned pc = cand[i];
@@ -1836,6 +1841,7 @@ __device__ __forceinline__ double resolve_chunk(
         }
     }
 
+    DVQ_RSTAMP(4);
     // ---- winners; slots whose winner differs from pass 1 are rewritten
     if (tid < nlive) {
         const char *r2 = srec + tid * RB;
@@ -1902,6 +1908,7 @@ __device__ __forceinline__ double resolve_chunk(
         delta *= (float)(rep * rep);
         dsum += (double)delta;
     }
+    DVQ_RSTAMP(5);
     double tot = 0.0;
     if (want_loss) {
 #pragma unroll
@@ -1917,7 +1924,7 @@ __device__ __forceinline__ double resolve_chunk(
 }
 
 template <int D, bool FOLD>
-__global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
+__global__ __launch_bounds__(DVQ_RES_WAVES * 64, DVQ_RES_WAVES > 4 ? 1 : 2) void vq_resolve_kernel(
     const char *__restrict__ img, const DvqF16Meta *__restrict__ meta, const float *__restrict__ en_all,
     const float *__restrict__ E, int HW, int K,
     float *__restrict__ zq, long long *__restrict__ codes, double *__restrict__ partials,
@@ -1927,6 +1934,7 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
 {
     __shared__ __attribute__((aligned(16))) char L[ResLds<D>::BYTES];
     (void)meta;
+    DVQ_RSTAMP(0);
     // The workgroup that writes chunk blockIdx.x's partial (also for an empty chunk) folds its share of pass 1's per-block loss
     // sums into it, in a fixed order: the list kernel's finishing workgroup then adds gridDim.x numbers instead of np1 more.
     auto p1_share = [&]() -> double {
@@ -1952,11 +1960,13 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, 2) void vq_resolve_kernel(
     tps = (tps + DVQ_RES_WAVES - 1) / DVQ_RES_WAVES * DVQ_RES_WAVES;
     const int t_begin = slice * tps, t_end = (t_begin + tps < T) ? t_begin + tps : T;
     const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
+    DVQ_RSTAMP(1);
     bool not_last;
     const double tot = resolve_chunk<D, FOLD>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, Wout, zq, codes, counters,
                                               exact_list, records, nslice, chunk_sync + 2 * blockIdx.x, h_spill, cv,
                                               partials != nullptr, &not_last);
     if (!not_last && partials != nullptr && threadIdx.x == 0) partials[blockIdx.x] = tot + p1_share();
+    DVQ_RSTAMP(6);
 }
 
 template <int D, int SEL, bool CONV, bool FOLD = false>
