@@ -287,7 +287,8 @@ __device__ __forceinline__ void pass1_body(
     char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv,
     f32x4 *__restrict__ split = nullptr, int ksplit = 1)
 {
-    static_assert(!SPLIT || (SEL == 0 && !CONV && !FOLD), "the split form is a dense op");
+    static_assert(!SPLIT || (SEL != 2 && !CONV && !FOLD), "the split form: dense or per-lane select, no conv");
+    static_assert(!(SPLIT && FLAT && SEL != 0), "row-major latents are a dense op");
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
     static_assert(!FLAT || (SEL == 0 && !CONV), "the row-major form is a dense op");
@@ -2007,6 +2008,20 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_split_kernel(
                                                       rec_cap, rv, cv, split, ksplit);
 }
 
+// ... with the router select fused in (per-lane form; every slice's workgroup writes the same indices / codebook_mask / gate)
+template <int D>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_split_sel_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, f32x4 *__restrict__ split, int ksplit)
+{
+    const DvqConv cv = {};
+    pass1_body<D, 1, false, false, false, false, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records,
+                                                       rec_cap, rv, cv, split, ksplit);
+}
+
 // the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
 template <int D, int SEL, bool FOLD>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
@@ -2435,6 +2450,16 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
                                w.records, w.cap / DVQ_QSHARDS, rv, st);
 #endif
     if (rv != nullptr) {                                     // select fused in
+        if (const int ks = split_slices(K, N); ks > 1 && w.split != nullptr) {   // small batch: several workgroups per token block
+            static unsigned long long done_ss = 0;
+            const size_t shm = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
+            int rcs = dvq_allow_dynamic_lds((const void *)vq_assign_filter_split_sel_kernel<D>, (int)shm, &done_ss);
+            if (rcs) return rcs;
+            hipLaunchKernelGGL((vq_assign_filter_split_sel_kernel<D>), dim3((unsigned)nb1 * ks), dim3(256), shm, st,
+                               z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                               w.cap / DVQ_QSHARDS, *rv, w.split, ks);
+            return (int)hipGetLastError();
+        }
         if (staged_select_ok(*rv))
             return launch_pass1_form<D, 2>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv);
         return launch_pass1_form<D, 1>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, *rv, st, nocv);
