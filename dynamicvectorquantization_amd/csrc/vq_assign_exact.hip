@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256, FOLDCONV ? 1 : 2) void vq_assign_exact_kernel(
             }
         }
         if (*flag && tail.loss != nullptr) {
-            __threadfence();
+            if (nwork > 1) __threadfence();    // (an empty list -- the usual case -- has nobody else's stores to wait for: the fence
+                                               // alone was ~2 us of this kernel's 5)
             // partials of the earlier kernels are plain memory by now; this kernel's own need
             // device-coherent loads (they were written by blocks on other XCDs)
             const int nprev = tail.nparts - (int)gridDim.x;
