@@ -133,6 +133,12 @@ def _load():
         lib.dvq_tuning_buffers.argtypes = [vp, vp]
         lib.dvq_tuning_pipe_stamps.restype = i32
         lib.dvq_tuning_pipe_stamps.argtypes = [vp]
+        # tools/ only: DVQ_TUNE="key=value,..." sets A/B switches of the tuning build for a whole process (e.g. bench.py under
+        # tools/ab_lib.sh); the product library exports no such symbol and this branch is not taken
+        for kv in filter(None, os.environ.get("DVQ_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            if lib.dvq_tuning_set(k.strip().encode(), int(v)) != 0:
+                raise DvqError("DVQ_TUNE: unknown switch %r" % k)
     lib.dvq_debug_filter_scores_f32.restype = i32
     lib.dvq_debug_filter_scores_f32.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.dvq_exchange_bytes.restype = sz
