@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""ISA check for the hand-issued asynchronous loads of the conv prologue (vq_assign_filter_kernel<256, SEL, true>): the x values of
+"""ISA check for the hand-issued asynchronous loads of the conv prologue (vq_assign_filter_kernel<256, SEL, true> and the small-batch
+vq_assign_filter_split_conv_kernel<256, SEL>): the x values of
 k-step g are loaded with `asm volatile("global_load_dword ... nt")` three k-steps before they are used and waited for with a COUNTED
 s_waitcnt; hipcc believes the destination registers are defined at the asm statement, so nothing it schedules between the load and
 its covering wait may read, copy, spill or overwrite them.  The 8 loads of group g are covered by the (g + 1)-th vmcnt wait after
@@ -33,6 +34,10 @@ def check(path):
     names = [l.split(":")[0] for l in s.splitlines()
              if l.startswith("_Z23vq_assign_filter_kernelILi256") and "ELb1ELb0EE" in l.split(":")[0]]   # <256, SEL, CONV = true, FOLD = false>
     assert names, "no CONV instantiation of vq_assign_filter_kernel in %s" % path
+    split = sorted({l.split(":")[0] for l in s.splitlines()               # the small-batch form with the same prologue
+                    if l.startswith("_Z34vq_assign_filter_split_conv_kernelILi256") and ":" in l})
+    assert len(split) == 2, "expected the SEL = 0 / 1 instantiations of vq_assign_filter_split_conv_kernel, found %r" % split
+    names += split
     report = []
     for name in names:
         i = s.index("\n" + name + ":")
