@@ -87,6 +87,15 @@ class _CodebookPrep:
     def get(self, codebook):
         K, D = codebook.shape
         key = (codebook.data_ptr(), codebook._version, K, D, codebook.device)
+        if key == self.key:
+            # steady state: no Stream object is made (torch.cuda.current_stream() alone is ~5 us of every call)
+            b = self._built
+            if b is None:
+                return self.buf
+            if b[0] == _lib.stream_ptr(codebook.device):     # built on this stream: ordered; forget the event once it has completed
+                if not torch.cuda.is_current_stream_capturing() and b[1].query():
+                    self._built = None
+                return self.buf
         cur = torch.cuda.current_stream(codebook.device)
         if key != self.key:
             nbytes = _lib_handle.dvq_codebook_prep_bytes(K, D)
@@ -637,6 +646,19 @@ class _VQStraightThrough(torch.autograd.Function):
         return gz, gw, None, None, None, None, None, None
 
 
+def _vq_straight_through(z, weight, mask, prep, K, coef_z, coef_e, mode):
+    """_VQStraightThrough.apply when a graph is being recorded; the bare op otherwise.  (needs_input_grad inside a Function mirrors
+    requires_grad of the inputs whether or not autograd is recording: under no_grad -- every inference call of the drop-in modules,
+    whose weight is a Parameter -- the Function would still snapshot the codebook: a 1-MiB copy kernel and ~10 us of host time per
+    call for a backward nobody can ask for.)"""
+    if torch.is_grad_enabled() and (z.requires_grad or weight.requires_grad):
+        return _VQStraightThrough.apply(z, weight, mask, prep, K, coef_z, coef_e, mode)
+    zq, codes, loss = vq_assign(z, weight[:K], prep, mask, beta=(coef_z if coef_e == 1.0 else coef_e), mode=mode)
+    if prep.track_users:
+        prep.used(z.device)
+    return zq, loss[1], codes
+
+
 class VQEmbedding(nn.Embedding):
     """EMA codebook; same parameters/buffers as the reference class (quantize2_mask.py:10-132):
     weight [K+1, D] (row K is the padding row), cluster_size_ema [K], embed_ema [K, D]."""
@@ -849,7 +871,7 @@ class VectorQuantize2(_CodebookOps, nn.Module):
         if self.training:
             self.codebook._prep.invalidate()             # training: optimizers / EMA may write through .data
         self.codebook._prep.track_users = self.training
-        zq, loss, codes = _VQStraightThrough.apply(z, self.codebook.weight, mask, self.codebook._prep, K,
+        zq, loss, codes = _vq_straight_through(z, self.codebook.weight, mask, self.codebook._prep, K,
                                                    float(self.beta), 1.0, self.assign_mode)
         if self.training and self.codebook.ema:
             with torch.no_grad():
@@ -918,7 +940,7 @@ class VectorQuantize2List(_CodebookOps, nn.Module):
             if self.training:
                 self.codebook._prep.invalidate()
             self.codebook._prep.track_users = self.training
-            zq, l_i, codes = _VQStraightThrough.apply(z, self.codebook.weight, None, self.codebook._prep, K,
+            zq, l_i, codes = _vq_straight_through(z, self.codebook.weight, None, self.codebook._prep, K,
                                                       float(self.beta), 1.0, self.assign_mode)
             if self.training and self.codebook.ema:
                 with torch.no_grad():
@@ -1011,7 +1033,7 @@ class VectorQuantizer2(nn.Module):
         if self.training:
             self._prep.invalidate()                      # the optimizer may have stepped through .data
         self._prep.track_users = self.training
-        z_q, loss, codes = _VQStraightThrough.apply(z, self.embedding.weight, None, self._prep, self.n_e,
+        z_q, loss, codes = _vq_straight_through(z, self.embedding.weight, None, self._prep, self.n_e,
                                                     coef_z, coef_e, self.assign_mode)
         min_encoding_indices = codes.reshape(-1)
         if self.remap is not None:
