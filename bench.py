@@ -888,22 +888,29 @@ def run_rank(a):
                                                              "+ permuter) with the quant_conv folded into the codebook")
 
     # the same K steps strictly serial (one stream, one slot's buffers): what a caller without stream slots gets
+    # (HIP events around blocks of >= 200 steps: with the driver's --steps 20 a wall-clock bracket of 20 steps = 4 ms carried the
+    # synchronize / first-launch latency and the clock ramp after the idle gap -- 0.241 against 0.223 ms on the same box)
     serial_ms, serial_blocks = None, None
+    n_ser = max(a.steps, 200)
     if S > 1:
         serial_blocks = []
-        for _ in range(3):
+        for _ in range(10):
             wl.step(wl.slots[0])
         for r in range(R):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
+            for _ in range(5):
                 wl.step(wl.slots[0])
+            e0.record()
+            for _ in range(n_ser):
+                wl.step(wl.slots[0])
+            e1.record()
             torch.cuda.synchronize()
-            serial_blocks.append((time.perf_counter() - t1) / a.steps * 1e3)
+            serial_blocks.append(e0.elapsed_time(e1) / n_ser)
         serial_ms = float(np.median(serial_blocks))
     # the step's ops (all their kernels) and, below, the dominant kernel alone: HIP events on the launch stream, serial,
     # after the timed region (inside it the ops of consecutive steps overlap across the stream slots)
-    nev = min(a.steps, 200)
+    nev = 200                                                 # (not --steps: 20 brackets are too few for a 2 % question)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     for i in range(-3, nev):
         wl.step(wl.slots[0], ev[i] if i >= 0 else None)
@@ -981,6 +988,7 @@ def run_rank(a):
             "ms_per_step_blocks": [d / a.steps * 1e3 for d in dts],
             "serial_ms_per_step": serial_ms,
             "serial_ms_per_step_min_max": [min(serial_blocks), max(serial_blocks)] if serial_blocks else None,
+            "serial_steps_per_block": n_ser if serial_blocks else a.steps,
             "serial_value": wl.Bglobal / (serial_ms * 1e-3) if world == 1 else None, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
