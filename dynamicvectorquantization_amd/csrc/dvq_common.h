@@ -119,6 +119,9 @@ struct DvqLossTail {
 #define DVQ_C_TICKET   4      // live: finalize ticket of the list kernel
 #define DVQ_C_PREPASS  5
 #define DVQ_SPLIT_TICKET0 128     // live: counters[DVQ_SPLIT_TICKET0 + token block] = slices done (split form of pass 1, small batches)
+#ifndef DVQ_SPLIT_MAX_SLICES
+#define DVQ_SPLIT_MAX_SLICES 8    // slices per token block at most (a power of two; 16: no faster at B = 4, 16 x 16, and the merge spills)
+#endif
 #define DVQ_SPLIT_MAX_BLOCKS 64   // ... which serves up to this many token blocks of 128 (beyond: no gain measured, profiles/r05_small_batch.json)
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router

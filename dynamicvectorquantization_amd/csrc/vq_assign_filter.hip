@@ -900,15 +900,15 @@ __device__ __forceinline__ void pass1_body(
         if (!s_last) return;
         float mb = -__builtin_inff(), ms = -__builtin_inff();
         int mc = 0;
-        unsigned long long e0[8], e1[8];                     // all slices' entries in flight at once (ksplit <= 8; past the end: repeats)
+        unsigned long long e0[DVQ_SPLIT_MAX_SLICES], e1[DVQ_SPLIT_MAX_SLICES];   // all slices' entries in flight at once (past the end: repeats)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < DVQ_SPLIT_MAX_SLICES; ++k) {
             const int kk = k < ksplit ? k : ksplit - 1;
             e0[k] = __hip_atomic_load(mine + (size_t)kk * 128 * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             e1[k] = __hip_atomic_load(mine + (size_t)kk * 128 * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < DVQ_SPLIT_MAX_SLICES; ++k) {
             const float eb = __uint_as_float((unsigned)e0[k]), es = __uint_as_float((unsigned)(e0[k] >> 32));
             const bool other_wins = k < ksplit && eb > mb;
             ms = (k < ksplit) ? fmaxf(other_wins ? mb : eb, fmaxf(ms, es)) : ms;
@@ -2289,14 +2289,14 @@ static int split_slices(int K, long N)
 {
     const long nb = (N + 127) / 128;
     if (!g_tune.split || nb > DVQ_SPLIT_MAX_BLOCKS) return 1;
-    int ks = 8;
+    int ks = DVQ_SPLIT_MAX_SLICES;
     while (ks > 1 && (nb * ks > 256 || dvq_num_tiles(K) / ks < 2)) ks >>= 1;
     return ks;
 }
 static size_t split_bytes(long N)
 {
     const long nb = (N + 127) / 128;
-    return nb <= DVQ_SPLIT_MAX_BLOCKS ? align256((size_t)nb * 8 * 128 * sizeof(f32x4)) : 0;
+    return nb <= DVQ_SPLIT_MAX_BLOCKS ? align256((size_t)nb * DVQ_SPLIT_MAX_SLICES * 128 * sizeof(f32x4)) : 0;
 }
 
 size_t dvq_filter_ws_extra_bytes(int D, int HW, int K, long N)
