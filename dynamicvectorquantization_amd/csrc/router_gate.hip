@@ -608,16 +608,19 @@ __global__ __launch_bounds__(GATE_NW * 64) void router_gate_kernel(
 #ifndef DVQ_GEMM_ABL
 #define DVQ_GEMM_ABL 0           // timing experiments of the tuning build only (results WRONG): 1 no ring DMA in the loop, 2 no MFMAs,
 #endif                           // 4 no epilogue, 8 no B-fragment reads
+#ifndef DVQ_GEMM_CH16
+#define DVQ_GEMM_CH16 1          // ring chunks of 16 k-steps (4 slots) instead of 8 (8 slots): half the workgroup barriers, the kernel -2 ... -4 %
+#endif                           // (same box; profiles/r05_gate_counters.json)
 template <int G, int S>
 __global__ __launch_bounds__(256, 1) void gate_gemm_kernel(
     const char *__restrict__ ximg, const _Float16 *__restrict__ imgH, const _Float16 *__restrict__ imgL,
     const float *__restrict__ b1, const float *__restrict__ W2, int Hid, int act, long ncell, int nblocks,
     const float *__restrict__ xs, float *__restrict__ part, const float *__restrict__ wtail)
 {
-    constexpr int CH = (S % 8 == 0) ? 8 : 4;                 // k-steps per ring chunk
+    constexpr int CH = (DVQ_GEMM_CH16 && S % 16 == 0) ? 16 : ((S % 8 == 0) ? 8 : 4);   // k-steps per ring chunk
     constexpr int NCH = S / CH;                              // chunks per cell block
     constexpr int CHB = CH * 2048;                           // bytes per chunk (hi + lo)
-    constexpr int RING = 8;
+    constexpr int RING = (CH == 16) ? 4 : 8;                 // 128 KiB of ring either way
     constexpr int PPW = CH * 2 / 4;                          // 1-KiB DMA pieces per wave and chunk
     static_assert(S % CH == 0 && PPW >= 1, "S is a multiple of 4");
     extern __shared__ __attribute__((aligned(16))) char glds[];       // [RING][CHB] | PB [4 waves][1 + G][32] | red [4][G][32]
@@ -1049,8 +1052,9 @@ int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn
 #define DVQ_GEMM_LAUNCH(GG, SS)                                                                                        \
         do {                                                                                                           \
             static unsigned long long done_ = 0;                                                                       \
-            constexpr int CHB_ = ((SS % 8 == 0) ? 8 : 4) * 2048;                                                       \
-            const size_t shm = 8 * (size_t)CHB_ + (4 * (1 + GG) * 32 + 4 * GG * 32) * sizeof(float);                   \
+            constexpr int CH_ = (DVQ_GEMM_CH16 && SS % 16 == 0) ? 16 : ((SS % 8 == 0) ? 8 : 4);                         \
+            constexpr int CHB_ = CH_ * 2048;                                                                           \
+            const size_t shm = (CH_ == 16 ? 4 : 8) * (size_t)CHB_ + (4 * (1 + GG) * 32 + 4 * GG * 32) * sizeof(float); \
             int rc = dvq_allow_dynamic_lds((const void *)gate_gemm_kernel<GG, SS>, (int)shm, &done_);                  \
             if (rc) return rc;                                                                                         \
             hipLaunchKernelGGL((gate_gemm_kernel<GG, SS>), dim3(CG, HG), dim3(256), shm, st, ximg, imgH, imgLg, b1, W2, \
