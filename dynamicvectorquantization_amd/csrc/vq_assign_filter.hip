@@ -287,7 +287,7 @@ __device__ __forceinline__ void pass1_body(
     char *__restrict__ records, int rec_cap, const DvqRouted &rv, const DvqConv &cv,
     f32x4 *__restrict__ split = nullptr, int ksplit = 1)
 {
-    static_assert(!SPLIT || (SEL != 2 && !FOLD), "the split form: dense or per-lane select, with or without the conv prologue");
+    static_assert(!SPLIT || SEL != 2, "the split form: dense or per-lane select; plain, with the conv prologue, or on the folded codebook");
     static_assert(!(SPLIT && FLAT && SEL != 0), "row-major latents are a dense op");
     static_assert(!CONV || (D == 256 && SEL != 2), "the conv prologue exists for D = 256, dense or per-lane select");
     static_assert(!(CONV && FOLD), "the conv is either computed (CONV) or folded into the code image (FOLD)");
@@ -2035,6 +2035,19 @@ __global__ __launch_bounds__(256, 2) void vq_assign_filter_split_conv_kernel(
                                                        rec_cap, rv, cv, split, ksplit);
 }
 
+// ... and on the conv-folded codebook (loss-free inference / stage-2 tokenisation of single images)
+template <int D, int SEL>
+__global__ __launch_bounds__(256, 2) void vq_assign_filter_split_fold_kernel(
+    const float *__restrict__ z, const char *__restrict__ img, const DvqF16Meta *__restrict__ meta,
+    const float *__restrict__ E, const float *__restrict__ mask,
+    int HW, int K, long N, float *__restrict__ zq, long long *__restrict__ codes,
+    double *__restrict__ partials, int *__restrict__ counters, int *__restrict__ exact_list,
+    char *__restrict__ records, int rec_cap, const DvqRouted rv, const DvqConv cv, f32x4 *__restrict__ split, int ksplit)
+{
+    pass1_body<D, SEL, false, true, false, false, true>(z, img, meta, E, mask, HW, K, N, zq, codes, partials, counters, exact_list, records,
+                                                        rec_cap, rv, cv, split, ksplit);
+}
+
 // the same kernel with plain loads of the latents, for batches that fit the memory-side cache (dense or staged select, no conv)
 template <int D, int SEL, bool FOLD>
 __global__ __launch_bounds__(256, 2) void vq_assign_filter_cached_kernel(
@@ -2441,6 +2454,22 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
     const DvqRouted none = {};
     const DvqConv nocv = {};
     if (fold_cv != nullptr) {                                // img / meta: the folded codebook; z (or the branches): the conv's input
+        if (const int ks = split_slices(K, N); ks > 1 && w.split != nullptr) {   // small batch: several workgroups per token block
+            static unsigned long long done_f0 = 0, done_f1 = 0;
+            const size_t shm = 4 * (size_t)(D / 16) * 1024 + 4 * 4 * 64 * sizeof(float) + 4 * 2048;
+            int rcs = rv != nullptr ? dvq_allow_dynamic_lds((const void *)vq_assign_filter_split_fold_kernel<D, 1>, (int)shm, &done_f1)
+                                    : dvq_allow_dynamic_lds((const void *)vq_assign_filter_split_fold_kernel<D, 0>, (int)shm, &done_f0);
+            if (rcs) return rcs;
+            if (rv != nullptr)
+                hipLaunchKernelGGL((vq_assign_filter_split_fold_kernel<D, 1>), dim3((unsigned)nb1 * ks), dim3(256), shm, st,
+                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                                   w.cap / DVQ_QSHARDS, *rv, *fold_cv, w.split, ks);
+            else
+                hipLaunchKernelGGL((vq_assign_filter_split_fold_kernel<D, 0>), dim3((unsigned)nb1 * ks), dim3(256), shm, st,
+                                   z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w.counters, w.exact_list, w.records,
+                                   w.cap / DVQ_QSHARDS, none, *fold_cv, w.split, ks);
+            return (int)hipGetLastError();
+        }
         if (rv == nullptr)
             return launch_pass1_form<D, 0, false, true>(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, w, none, st, *fold_cv);
         if (staged_select_ok(*rv))
