@@ -77,6 +77,10 @@ def parse():
                     help="consecutive steps (independent batches) are issued round-robin on this many HIP streams, each "
                          "with its own outputs / workspace / exchange buffers, so a step's latency-bound tail (resolver, "
                          "list kernel, exchange) runs under the next batch's pass 1; 1 = strictly serial")
+    ap.add_argument("--configs", choices=["auto", "full", "small", "off"], default="auto",
+                    help="default command only (1 GPU, weak, --path routed, filter): after the timed region, measure and check every "
+                         "BASELINE.json config in the reference's own op order (pixels -> entropy map / feature-router gate -> select + "
+                         "quant_conv + assign) and report them under 'configs'; auto = full at the default batch, small when --batch is given")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -221,9 +225,8 @@ def cpu_baseline(E, target_s):
 
     reps, dt = loop(one_pass, target_s * 0.6)
     res = {"value": nb * reps / dt, "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": "%d passes over %d images of the weak-scaling workload (gate + select + VQ assign), oracle C "
-                     "port: OpenMP over 4-token x 32-code register tiles (%d threads) + AVX2 FMA chains, "
-                     "%.1f s" % (reps, nb, cores, dt)}
+           "sample": "%d passes x %d images (gate + select + VQ assign), oracle C port, OpenMP %d threads + AVX2, %.1f s"
+                     % (reps, nb, cores, dt)}
 
     torch.set_num_threads(cores)
     nt = 16
@@ -247,8 +250,7 @@ def cpu_baseline(E, target_s):
 
     reps2, dt2 = loop(torch_pass, target_s * 0.4)
     res["torch_ops"] = {"value": nt * reps2 / dt2, "unit": "images/s", "cores": cores, "kind": "port",
-                        "sample": "%d passes over %d images, the reference's op sequence as torch-CPU ops (where / "
-                                  "addmm / argmin / index_select / masked mean), torch %s, %d threads, %.1f s"
+                        "sample": "%d passes x %d images, the reference's op sequence as torch-CPU ops, torch %s, %d threads, %.1f s"
                                   % (reps2, nt, torch.__version__, cores, dt2)}
     return res
 
@@ -690,6 +692,290 @@ class StrongTriple:
                 "loss_rel_err": abs(float(slot.loss[1]) - ol) / abs(ol)}
 
 
+
+# ------------------------------------------------------------------------------------------------
+# every BASELINE.json config in the reference's own op order (rank 0, N = 1, default command)
+# ------------------------------------------------------------------------------------------------
+def _ev_ms(fn, n, warm=5):
+    """mean milliseconds of fn() over n back-to-back calls on the current stream (HIP events)"""
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def _pass1_ms(run, prep, n=60):
+    """pass 1 of a filter-path op ALONE: `run()` issues the op in MODE_FILTER_PASS1 through `prep` (a _CodebookPrep of its
+    own); the profiling mode leaves the queue counters dirty, so they are zeroed in FRONT of every bracket and the workspace is
+    declared clean -- the events enclose the pass-1 kernel and nothing else"""
+    import numpy as np
+    import torch
+    evs = []
+    for i in range(-3, n):
+        lw = getattr(prep, "_last_ws", None)
+        if lw is not None and hasattr(lw[1], "clean"):
+            lw[1].t[:min(lw[1].t.numel(), 4 << 20)].zero_()
+            lw[1].clean = True
+        e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        e[0].record()
+        run()
+        e[1].record()
+        if i >= 0:
+            evs.append(e)
+    torch.cuda.synchronize()
+    return float(np.mean([s.elapsed_time(e) for s, e in evs]))
+
+
+def configs_block(dev, small=False):
+    """BASELINE.json's five configs, each in the op order the reference's `encode` runs after the CNN trunk
+    (models/stage1/vqgan.py:68-72; dqvae_dual_feat.py:59-68; dqvae_dual_entropy.py:124-134 incl. the Entropy module on the
+    PIXELS; dqvae_triple_feat.py:68-77), through the drop-in modules, strictly serial on one stream: `ms` = HIP events over
+    back-to-back module calls; `stage_ms` = the same for each stage alone (+ pass 1 of the assign alone); `frac` = SURVEY 8d
+    algorithmic bytes of the stage / its time / 8 TB/s (K = 16384: flops against the matrix peak); `share` = stage / step;
+    parity on a stated sample of images against the oracle (codes / z_q / grain / mask bit-exact GIVEN the conv output h the op
+    scored, h within 1e-5 sum|w||x| of the float64 conv, entropy map within 1e-5, loss 1e-5 when the sample is the batch).
+    `small`: reduced batches (tests)."""
+    import numpy as np
+    import torch
+
+    from dynamicvectorquantization_amd import _lib, qconv, synth
+    from dynamicvectorquantization_amd.encode import encode_dual, encode_fixed, encode_triple
+    from dynamicvectorquantization_amd.entropy import Entropy
+    from dynamicvectorquantization_amd.quantize import (VectorQuantize2, VectorQuantizer2, _CodebookPrep, vq_assign,
+                                                        vq_assign_routed_dual, vq_assign_routed_triple)
+    from dynamicvectorquantization_amd.router import (DualGrainFeatureRouter, DualGrainFixedEntropyRouter,
+                                                      TripleGrainFeatureRouter)
+    from oracle import oracle
+    from oracle.entropy_torch import entropy_map as entropy_ref
+    oracle.build()
+    t_start = time.perf_counter()
+    K, D = 1024, 256
+    nsteps = 20 if small else 200
+    E_np = synth.codebook_trained(K, D)
+    E = torch.from_numpy(E_np).to(dev)
+    # the models' quant_conv (orthogonal matrix + bias) and branch inputs = pre-images of z_tokens under it: the QUANTIZER sees
+    # the headline distribution, as in WeakDual (see there)
+    q, _ = np.linalg.qr(synth.normal(6012, (D, D), 0.0, 1.0).astype(np.float64))
+    cb = synth.normal(6013, (D,), 0.0, 0.1)
+    conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(q.astype(np.float32).reshape(D, D, 1, 1)).to(dev))
+        conv.bias.copy_(torch.from_numpy(cb).to(dev))
+    q64 = conv.weight.detach().double().reshape(D, D)
+    b64 = conv.bias.detach().double()
+
+    def pre(t_np, B):
+        t = tile_images(torch.from_numpy(t_np).to(dev), B).double() - b64[None, :, None, None]
+        return torch.einsum("oc,bohw->bchw", q64, t).float().contiguous()
+
+    nb = 8 if small else 32
+    base32 = synth.z_tokens(E_np, nb, 32, 32, 2301)
+    base16 = synth.z_tokens(E_np, nb, 16, 16, 2311)
+    base8 = synth.z_tokens(E_np, nb, 8, 8, 2321)
+    w64 = q64.cpu().numpy()
+    bias64 = b64.cpu().numpy()
+
+    def vq2():
+        m = VectorQuantize2(K, D).to(dev).eval()
+        with torch.no_grad():
+            m.codebook.weight[:-1].copy_(E)
+        m.invalidate_codebook_cache()
+        return m
+
+    def seeded(router, seed):
+        sd = {k: torch.from_numpy(synth.seeded_param(seed, i, k, tuple(v.shape))) for i, (k, v) in enumerate(router.state_dict().items())}
+        router.load_state_dict(sd)
+        return router.to(dev).eval()
+
+    def check_h(h, x_sel, n):
+        """largest |h - conv64(x)| / (1e-5 sum |w||x|) over the first n images"""
+        x64 = x_sel[:n].astype(np.float64)
+        ref = np.einsum("ok,bkhw->bohw", w64, x64) + bias64[None, :, None, None]
+        bound = np.einsum("ok,bkhw->bohw", np.abs(w64), np.abs(x64)) + np.abs(bias64)[None, :, None, None]
+        return float((np.abs(h[:n] - ref) / (1e-5 * bound + 1e-30)).max())
+
+    def routed(name, B, ns, feats, router=None, images=None, no_conv_too=False):
+        """one routed config: [Entropy ->] router gate -> select + quant_conv + assign (one op); feats = (h_coarse, [h_median,] h_fine)"""
+        triple = len(feats) == 3
+        vq = vq2()
+        cbk = vq.codebook
+        hc, hf = feats[0], feats[-1]
+        hm = feats[1] if triple else None
+        ent_mod = Entropy(16, 256, 256).to(dev) if images is not None else None
+        with torch.no_grad():
+            if images is not None:
+                def full():
+                    return encode_dual(router, vq, hf, hc, entropy=ent_mod(images), quant_conv=conv)
+            elif triple:
+                def full():
+                    return encode_triple(router, vq, hf, hm, hc, quant_conv=conv)
+            else:
+                def full():
+                    return encode_dual(router, vq, hf, hc, quant_conv=conv)
+            res = full()
+            torch.cuda.synchronize()
+            ms = _ev_ms(full, nsteps)
+            stage, nbytes = {}, {}
+            if images is not None:
+                stage["entropy_map"] = _ev_ms(lambda: ent_mod(images), nsteps)
+                nbytes["entropy_map"] = images.numel() * 4 + B * 256 * 4
+                ent = ent_mod(images)
+                gate_kw = dict(entropy=ent, threshold=router.fine_grain_threshold)
+            else:
+                if triple:
+                    stage["router_gate"] = _ev_ms(lambda: router(h_fine=hf, h_median=hm, h_coarse=hc), nsteps)
+                    gate = router(h_fine=hf, h_median=hm, h_coarse=hc)
+                else:
+                    stage["router_gate"] = _ev_ms(lambda: router(h_fine=hf, h_coarse=hc), nsteps)
+                    gate = router(h_fine=hf, h_coarse=hc)
+                nbytes["router_gate"] = sum(t.numel() for t in feats) * 4 + sum(p.numel() for p in router.parameters()) * 4 + gate.numel() * 4
+                gate_kw = dict(gate=gate)
+
+            def op(mode=_lib.MODE_FILTER, prep=cbk._prep, h_buf=None, cv=conv, out=None, want_loss=True):
+                if triple:
+                    return vq_assign_routed_triple(hc, hm, hf, cbk.codes, prep, gate_kw["gate"], beta=vq.beta, mode=mode, conv=cv,
+                                                   h_buf=h_buf, out=out, want_loss=want_loss)
+                return vq_assign_routed_dual(hc, hf, cbk.codes, prep, beta=vq.beta, mode=mode, conv=cv, h_buf=h_buf, out=out,
+                                             want_loss=want_loss, **gate_kw)
+            stage["assign_op"] = _ev_ms(op, nsteps)
+            pdom = _CodebookPrep()
+            r0 = op()
+            outs = (r0["zq"], r0["codes"], None, r0["indices"], r0["codebook_mask"]) + ((r0["gate"],) if images is not None else ())
+            if not triple and images is None:
+                outs = outs + (None,)
+            stage["pass1"] = _pass1_ms(lambda: op(mode=_lib.MODE_FILTER_PASS1, prep=pdom, out=outs, want_loss=False), pdom,
+                                       n=20 if small else 60)
+            ntok = B * 1024
+            nbytes["pass1"] = ntok * 2060 + K * D * 4
+            ent_d = {"workload": name, "B": B, "ms": ms, "images_per_s": B / (ms * 1e-3), "stage_ms": stage,
+                     "frac": {k: nbytes[k] / (stage[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in nbytes},
+                     "share": {k: stage[k] / ms for k in stage if k != "pass1"}}
+            if no_conv_too:
+                ent_d["ms_no_conv"] = _ev_ms(lambda: encode_dual(router, vq, hf, hc, entropy=ent_mod(images)), nsteps)
+            # parity: the op once more with a full h_buf (it then writes the conv output of EVERY token beside the same codes)
+            hb = torch.empty_like(hf)
+            r1 = op(h_buf=hb)
+            torch.cuda.synchronize()
+            quant, emb_loss, info, grain, gate_out = res
+            same = (torch.equal(r1["codes"], info[2]) and torch.equal(r1["zq"], quant) and torch.equal(r1["indices"], grain)
+                    and torch.equal(r1["loss"][1], emb_loss))
+            h = hb[:ns].cpu().numpy()
+            if images is not None:
+                eref = entropy_ref(images[:min(ns, 8)].cpu()).numpy()
+                ent_d["entropy_max_abs_err"] = float(np.abs(ent[:min(ns, 8)].cpu().numpy() - eref).max())
+                og = oracle.entropy_gate(ent[:ns].cpu().numpy(), router.fine_grain_threshold)
+                osel = oracle.route_select_dual(og, hc[:ns].cpu().numpy(), hf[:ns].cpu().numpy())
+                xsel = osel["h_dual"]
+            elif triple:
+                osel = oracle.route_select_triple(gate[:ns].cpu().numpy(), hc[:ns].cpu().numpy(), hm[:ns].cpu().numpy(), hf[:ns].cpu().numpy())
+                xsel = osel["h_triple"]
+            else:
+                osel = oracle.route_select_dual(gate[:ns].cpu().numpy(), hc[:ns].cpu().numpy(), hf[:ns].cpu().numpy())
+                xsel = osel["h_dual"]
+            o = oracle.vq_assign_nchw(h, E_np, osel["codebook_mask"])
+            mism = {"codes": int((r1["codes"][:ns].cpu().numpy().reshape(ns, -1) != o["codes"]).sum()),
+                    "zq": int((r1["zq"][:ns].cpu().numpy() != o["zq"]).sum()),
+                    "grain": int((grain[:ns].cpu().numpy() != osel["indices"]).sum()),
+                    "mask": int((r1["codebook_mask"][:ns].cpu().numpy() != osel["codebook_mask"]).sum()),
+                    "rerun_with_h_buf": int(not same)}
+            ent_d.update({"checked_images": ns, "mismatches": mism, "code_mismatches": mism["codes"],
+                          "h_err_over_bound": check_h(h, xsel, min(ns, 8)),
+                          "fine_ratio": float((grain != 0).float().mean()) if not triple else None})
+            if ns == B:
+                ol = float(oracle.vq_loss(o["sqerr"], o["numel"], 0.25))
+                ent_d["loss_rel_err"] = abs(float(emb_loss) - ol) / abs(ol)
+        del hb, r1, r0, res
+        return ent_d
+
+    out = {}
+    # configs[0]: VQModel.encode (models/stage1/vqgan.py:68-72): quant_conv -> VectorQuantizer2 (beta .25, legacy False), B = 4, 16 x 16
+    with torch.no_grad():
+        B0 = 4
+        vqg = VectorQuantizer2(K, D, beta=0.25, legacy=False).to(dev).eval()
+        vqg.embedding.weight.copy_(E)
+        vqg.invalidate_codebook_cache()
+        x0 = pre(base16, B0)
+        f0 = lambda: encode_fixed(vqg, x0, quant_conv=conv)
+        zq0, loss0, info0 = f0()
+        ms0 = _ev_ms(f0, nsteps)
+        st0 = {"quant_conv": _ev_ms(lambda: qconv.quant_conv(conv, x0), nsteps)}
+        h0 = qconv.quant_conv(conv, x0)
+        st0["assign_op"] = _ev_ms(lambda: vqg(h0), nsteps)
+        o0 = oracle.vq_assign_nchw(h0.cpu().numpy(), E_np, None)
+        ol0 = float(oracle.vq_loss(o0["sqerr"], o0["numel"], 0.25))
+        out["cfg0"] = {"workload": "fixed-granularity VQModel.encode: 1x1 quant_conv -> VectorQuantizer2, B=4, 16x16x256, K=1024", "B": B0,
+                       "ms": ms0, "images_per_s": B0 / (ms0 * 1e-3), "stage_ms": st0, "share": {k: v / ms0 for k, v in st0.items()},
+                       "frac": {"assign_op": (B0 * 256 * 2056 + K * D * 4) / (st0["assign_op"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "checked_images": B0, "code_mismatches": int((info0[2].cpu().numpy().reshape(B0, -1) != o0["codes"]).sum()),
+                       "mismatches": {"zq": int((zq0.cpu().numpy() != o0["zq"]).sum())},
+                       "h_err_over_bound": check_h(h0.cpu().numpy(), x0.cpu().numpy(), B0),
+                       "loss_rel_err": abs(float(loss0) - ol0) / abs(ol0)}
+    # configs[1]: DualGrainVQModel.encode with the feature router (dqvae_dual_feat.py:59-68), B = 64
+    B1 = 8 if small else 64
+    r2 = seeded(DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu"), 6102)
+    out["cfg1"] = routed("dual feature-router: fused gate -> select + quant_conv + assign (one op), K=1024", B1, B1,
+                         (pre(base16, B1), pre(base32, B1)), router=r2)
+    # configs[2]: DualGrainVQModel.encode with the entropy router (dqvae_dual_entropy.py:124-134): PIXELS -> Entropy -> gate -> ...
+    B2 = 16 if small else 256
+    jpath = os.path.join(ROOT, "tests", "golden", "entropy_thresholds_imagenet_train_patch-16.json")
+    rent = DualGrainFixedEntropyRouter(jpath, 0.5)
+    nimg = min(B2, 32)
+    imgs = tile_images(torch.from_numpy(synth.images_flat_noise(5000, nimg)[0]).to(dev), B2)
+    out["cfg2"] = routed("dual entropy-router r05: pixels -> entropy map kernel -> gate + select + quant_conv + assign (one op), K=1024",
+                         B2, min(B2, 64), (pre(base16, B2), pre(base32, B2)), router=rent, images=imgs, no_conv_too=True)
+    del imgs
+    # configs[3]: TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77): the whole batch on one GPU, and one rank's share of 8
+    r3 = seeded(TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu"), 6104)
+    for key, B3 in (("cfg3", 16 if small else 1024), ("cfg3_per_rank_of_8", 8 if small else 128)):
+        out[key] = routed("triple feature-router: fused gate -> select + quant_conv + assign (one op), K=1024", B3, min(B3, 32),
+                          (pre(base8, B3), pre(base16, B3), pre(base32, B3)), router=r3)
+        torch.cuda.empty_cache()
+    # configs[4]: K = 16384 stress, dense VectorQuantize2 assign: fp16-MFMA filter path vs the exact fp32-MFMA chain
+    with torch.no_grad():
+        K4, B4 = 16384, (4 if small else 512)
+        E4_np = synth.codebook_trained(K4, D)
+        E4 = torch.from_numpy(E4_np).to(dev)
+        z4 = tile_images(torch.from_numpy(synth.z_tokens(E4_np, 4 if small else 16, 32, 32, 2005)).to(dev), B4)
+        pf, pe = _CodebookPrep(), _CodebookPrep()
+        o4 = (torch.empty_like(z4), torch.empty((B4, 32, 32), dtype=torch.int64, device=dev), torch.empty(2, device=dev))
+        tf = _ev_ms(lambda: vq_assign(z4, E4, pf, None, mode=_lib.MODE_FILTER, out=o4), 5 if small else 30, warm=2)
+        zq_f, c_f = o4[0].clone(), o4[1].clone()
+        te = _ev_ms(lambda: vq_assign(z4, E4, pe, None, mode=_lib.MODE_EXACT, out=o4), 2 if small else 3, warm=1)
+        ns4 = min(B4, 8)
+        oo = oracle.vq_assign_nchw(z4[:ns4].cpu().numpy(), E4_np, None)
+        fl = 2.0 * K4 * D * B4 * 1024
+        out["cfg4"] = {"workload": "K=16384 stress: dense VectorQuantize2 assign, 32x32x256 latents; fp16-MFMA filter + exact resolution vs the "
+                                   "all-exact fp32-MFMA chain", "B": B4, "ms": tf, "images_per_s": B4 / (tf * 1e-3), "ms_exact_mode": te,
+                       "tflops_equiv": fl / (tf * 1e-3) / 1e12, "tflops_exact_mode": fl / (te * 1e-3) / 1e12,
+                       "frac": {"filter_vs_fp16_mfma_2500": fl / (tf * 1e-3) / 1e12 / 2500.0,
+                                "exact_vs_fp32_mfma_157": fl / (te * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                "filter_hbm": (B4 * 1024 * 2056 + K4 * D * 4) / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "modes_bit_identical": bool(torch.equal(c_f, o4[1]) and torch.equal(zq_f, o4[0])),
+                       "checked_images": ns4, "code_mismatches": int((c_f[:ns4].cpu().numpy().reshape(ns4, -1) != oo["codes"]).sum()),
+                       "mismatches": {"zq": int((zq_f[:ns4].cpu().numpy() != oo["zq"]).sum())}}
+    torch.cuda.empty_cache()
+
+    def rnd(v):
+        if isinstance(v, float):
+            return float("%.5g" % v)
+        if isinstance(v, dict):
+            return {k: rnd(x) for k, x in v.items()}
+        return v
+    out = rnd(out)
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
+    out["all_parity_ok"] = all(c.get("code_mismatches", 0) == 0 and not any(c.get("mismatches", {}).values())
+                               and c.get("h_err_over_bound", 0.0) <= 1.0 and c.get("loss_rel_err", 0.0) <= 1e-5
+                               and c.get("entropy_max_abs_err", 0.0) <= 1e-5 and c.get("modes_bit_identical", True)
+                               for k, c in out.items() if isinstance(c, dict))
+    return out
+
 # ------------------------------------------------------------------------------------------------
 def run_rank(a):
     import numpy as np
@@ -715,7 +1001,13 @@ def run_rank(a):
         dist.init_process_group(backend, rank=rank, world_size=world)   # needs no GPU: the rendezvous comes first
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    local = local % torch.cuda.device_count()      # (a 1-GPU box can still exercise the N > 1 code path)
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and (world > ndev or local >= ndev):
+        # one process per GPU (the reference: Lightning DDP, train.py:227-233): RCCL cannot put two ranks on one device, and a
+        # silent modulo would report a scaling figure measured on fewer GPUs than claimed
+        raise SystemExit("bench.py: %d ranks (local rank %d) but %d visible GPU(s): the RCCL run needs one GPU per rank "
+                         "(DVQ_BENCH_BACKEND=gloo folds ranks onto the visible devices, for tests only)" % (world, local, ndev))
+    local = local % ndev                           # gloo tests only: a 1-GPU box can still exercise the N > 1 code path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_xch = world == 1 and os.environ.get("DVQ_BENCH_FORCE_EXCHANGE") == "1"   # 1-rank RCCL group: exchange overhead probe
@@ -729,6 +1021,20 @@ def run_rank(a):
 
     from dynamicvectorquantization_amd.encode import CodeExchange, StreamSlots
     from dynamicvectorquantization_amd.quantize import _CodebookPrep
+
+    # pre-flight record: which physical device every rank drives (so a SCALE record can show that RCCL saw N distinct GPUs)
+    pr = torch.cuda.get_device_properties(local)
+    ident = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": local, "device_name": pr.name,
+             "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+             "device_uuid": str(getattr(pr, "uuid", "")) or None, "host": socket.gethostname()}
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    distinct_devices = len({(d["host"], d["device_uuid"] or d["pci_bus_id"]) for d in idents})
+    backend_name = (dist.get_backend() if dist.is_initialized() else None)
+    if world > 1 and backend == "nccl" and distinct_devices != world:
+        raise SystemExit("bench.py: %d ranks drive only %d distinct GPUs: %s" % (world, distinct_devices, idents))
 
     wl = (WeakDual if a.scaling == "weak" else StrongTriple)(a, rank, world, dev)
     wl.prep_dom = _CodebookPrep()
@@ -788,6 +1094,32 @@ def run_rank(a):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # per block: the slowest rank
         dts = [float(v) for v in tt.tolist()]
     dt = float(np.median(dts))
+
+    # the exchange alone: pack kernel -> all-gather -> unpack kernel, serial on one stream (HIP events), max over ranks.  Inside the
+    # timed region it is launched async and completed two or three steps later (hidden under the next batches' pass 1); this is
+    # what an UN-hidden exchange would add to a step (DESIGN.md section 6 states both predictions).
+    exchange_ms = None
+    if xchs:
+        torch.cuda.synchronize()
+        o0 = wl.slots[0]
+        x = CodeExchange(o0.codes, o0.grain, K, wl.Bglobal, numel_per_image=H * W * D)    # its own buffers: the slots' results stay for the parity check
+        with torch.cuda.stream(streams[0]):
+            for _ in range(3):
+                x.start(o0.codes, o0.grain, o0.loss)
+                x.finish()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nx_it = 50
+            e0.record()
+            for _ in range(nx_it):
+                x.start(o0.codes, o0.grain, o0.loss)
+                x.finish()
+            e1.record()
+        torch.cuda.synchronize()
+        exchange_ms = e0.elapsed_time(e1) / nx_it
+        if world > 1:
+            tx = torch.tensor([exchange_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+            exchange_ms = float(tx.item())
 
     parity = None
     if not a.no_parity:
@@ -864,9 +1196,9 @@ def run_rank(a):
                 torch.cuda.synchronize()
                 dts2.append(time.perf_counter() - t2)
             dt2 = float(np.median(dts2))
-            leg = {"path": path, "workload": wl2.describe(), "steps": k2, "repeats": R, "ms_per_step": dt2 / k2 * 1e3,
+            leg = {"path": path, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
                    "ms_per_step_min_max": [min(dts2) / k2 * 1e3, max(dts2) / k2 * 1e3],
-                   "value": wl2.Bglobal * k2 / dt2, "unit": "images/s", "note": note}
+                   "value": wl2.Bglobal * k2 / dt2, "unit": "images/s"}
             if not a.no_parity:
                 p2 = wl2.parity(wl2.slots[(n2[0] - 1) % S])
                 bad2 = sum(v for k_, v in p2.items() if k_.endswith("_mismatches"))
@@ -963,43 +1295,41 @@ def run_rank(a):
     else:
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
-    roof.update({"kernel": wl.dominant_kernel_name(), "traffic_source": tsrc,
-                 "kernel_ms": dom_ms, "kernel_ms_note": "HIP events on the launch stream around the pass-1 launch alone (profiling "
-                 "mode on a workspace declared clean: no other kernel is inside the bracket), one launch at a time after "
-                 "the timed region. Inside the timed region consecutive steps overlap on config.streams HIP streams, so a "
-                 "kernel trace of THIS command shows stretched, overlapping per-kernel durations; the trace of the same "
-                 "command with --streams 1 (profiles/r05_bench_kernel_stats.csv) is the one this figure agrees with "
-                 "(kernel_ms_rocprof, when that summary was made from these sources)",
+    roof.update({"kernel": wl.dominant_kernel_name(), "kernel_ms": dom_ms, "kernel_ms_rocprof": rocprof_ms,
                  "serial_over_kernel": (serial_ms / dom_ms) if (serial_ms and dom_ms) else None,
-                 "op_kernels": "pass 1 -> resolver -> list kernel (exact list, loss finalize, counter clean-up); no counter-zero "
-                               "kernel in the steady state (DVQ_MODE_WS_CLEAN)",
-                 "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
-                 "algorithmic_note": "SURVEY.md 8d count of the VQ forward per launch of this kernel: every position read once "
-                                     "(1 KiB), z_q written once (1 KiB; not in --path tokens: 1032 + 4 B per token), int64 "
-                                     "code, mask; codebook once",
-                 "hbm_gbps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_tflops_equiv": tfs,
-                 "kernel_ms_rocprof": rocprof_ms, "whole_op_ms": op_ms})
+                 "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops, "fp16_mfma_frac_of_2500": tfs / 2500.0,
+                 "whole_op_ms": op_ms, "target_frac": 0.70, "target_met": bool(gbs / HBM_PEAK_GBS >= 0.70)})
+    # (what the fields mean -- the brackets, the byte count, where `traffic` and `kernel_ms_rocprof` come from -- is DESIGN.md
+    # section 5; the line itself stays short enough for the driver's record to hold all of it)
+    configs = None
+    if (rank == 0 and world == 1 and a.scaling == "weak" and a.path == "routed" and a.mode == "filter" and not force_xch
+            and a.configs != "off" and not a.no_parity):
+        mode_c = a.configs if a.configs != "auto" else ("full" if a.batch is None else "small")
+        del wl.slots[1:]
+        torch.cuda.empty_cache()
+        configs = configs_block(dev, small=(mode_c == "small"))
     if rank == 0:
+        par = ("one process per GPU, image-parallel x%d; per step ONE packed all-gather of codes / grain / loss pair (%s), "
+               "async under the next batches" % (world, backend_name)) if xchs else "single GPU: no exchange runs"
         out = {
             "metric": "images encoded/sec (VQ hot path: gate + routing + VQ assign), 256x256 inputs, K=%d" % K,
             "value": wl.Bglobal * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "ms_per_step_min": min(dts) / a.steps * 1e3, "ms_per_step_max": max(dts) / a.steps * 1e3,
-            "ms_per_step_blocks": [d / a.steps * 1e3 for d in dts],
             "serial_ms_per_step": serial_ms,
             "serial_ms_per_step_min_max": [min(serial_blocks), max(serial_blocks)] if serial_blocks else None,
-            "serial_steps_per_block": n_ser if serial_blocks else a.steps,
             "serial_value": wl.Bglobal / (serial_ms * 1e-3) if world == 1 else None, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": wl.Bglobal, "assign_mode": a.mode, "path": a.path,
-                       "source_sha16": source_sha16(), "inputs": "one input set per stream slot (seeds differ)",
-                       "spinup_steps": a.spinup, "streams": S, "repeats": R, "setup_seconds_slowest_rank": setup_s,
-                       "timing": "median of `repeats` back-to-back blocks of exactly `steps` steps, each bracketed by barrier + "
-                                 "synchronize, max over ranks per block", "host_issue_ms_per_step": t_issue / a.steps * 1e3,
-                       "parallelism": "image-parallel x%d, one packed RCCL all-gather of codes / grain / loss pair "
-                                      "per step" % world},
+                       "source_sha16": source_sha16(), "spinup_steps": a.spinup, "streams": S, "repeats": R,
+                       "setup_seconds_slowest_rank": setup_s, "host_issue_ms_per_step": t_issue / a.steps * 1e3,
+                       "parallelism": par, "backend": backend_name, "world": world, "distinct_devices": distinct_devices,
+                       "ranks": [{k: d[k] for k in ("rank", "local_rank", "device_index", "pci_bus_id", "device_uuid", "device_name")}
+                                 for d in idents]},
             "roofline": roof,
         }
+        if exchange_ms is not None:
+            out["exchange_ms_per_step"] = exchange_ms          # pack -> all-gather -> unpack, un-hidden (serial, max over ranks)
         if parity is not None:
             bad = sum(v for k, v in parity.items() if k.endswith("_mismatches"))
             out["parity_checked"] = bool(bad == 0 and parity["loss_rel_err"] <= 1e-5 and parity.get("exchange_ok", True))
@@ -1011,9 +1341,11 @@ def run_rank(a):
             out["model_order"] = model_order
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
+        if configs is not None:
+            out["configs"] = configs                           # last: a truncated record keeps the END of the line
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, separators=(",", ":")), flush=True)
         os.dup2(2, 1)
     if world > 1:
         dist.barrier()

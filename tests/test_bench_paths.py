@@ -50,3 +50,18 @@ def test_default_bench_reports_the_model_order_too():
         assert f["path"] == path and f["ms_per_step"] > 0 and f["parity_checked"] is True and f["parity"]["code_mismatches"] == 0
         assert f["parity"]["tokens_resolved_with_a_conv"] > 0
     assert "model_order" not in _run("--no-model-order", "--no-parity")
+    # every BASELINE config in the reference's own op order, measured and checked in the same line
+    c = d["configs"]
+    assert c["all_parity_ok"] is True, c
+    for key in ("cfg0", "cfg1", "cfg2", "cfg3", "cfg3_per_rank_of_8", "cfg4"):
+        e = c[key]
+        assert e["ms"] > 0 and e["code_mismatches"] == 0 and e["checked_images"] > 0, (key, e)
+        assert not any(e.get("mismatches", {}).values()), (key, e)
+    assert c["cfg2"]["entropy_max_abs_err"] <= 1e-5 and set(c["cfg2"]["stage_ms"]) == {"entropy_map", "assign_op", "pass1"}
+    assert set(c["cfg1"]["stage_ms"]) == {"router_gate", "assign_op", "pass1"} and c["cfg1"]["loss_rel_err"] <= 1e-5
+    assert c["cfg4"]["modes_bit_identical"] is True
+    # the pre-flight record of a single-GPU run
+    cfg = d["config"]
+    assert cfg["world"] == 1 and cfg["distinct_devices"] == 1 and cfg["backend"] is None and len(cfg["ranks"]) == 1
+    assert cfg["ranks"][0]["device_index"] == 0 and cfg["ranks"][0]["device_name"] and "no exchange" in cfg["parallelism"]
+    assert "exchange_ms_per_step" not in d

@@ -205,6 +205,12 @@ def test_bench_launcher_eight_ranks_on_one_device():
         assert d["n_gpus"] == 8 and d["config"]["global_batch"] == nimg
         assert d["parity_checked"] is True and d["code_mismatches"] == 0 and d["parity"]["exchange_ok"] is True
         assert d["parity"]["images_checked"] == nimg
+        # the pre-flight record: backend, world, every rank's device identity, the un-hidden exchange time
+        cfg = d["config"]
+        assert cfg["backend"] == "gloo" and cfg["world"] == 8 and len(cfg["ranks"]) == 8
+        assert [r["rank"] for r in cfg["ranks"]] == list(range(8)) and all(r["device_name"] and r["pci_bus_id"] for r in cfg["ranks"])
+        assert cfg["distinct_devices"] == 1          # eight ranks folded onto the one visible GPU: allowed under gloo ONLY
+        assert d["exchange_ms_per_step"] > 0
         print("8 ranks on one device, %s: slowest rank's set-up %.1f s, %.3f ms per step (not a scaling figure)"
               % (" ".join(extra), d["config"]["setup_seconds_slowest_rank"], d["ms_per_step"]))
         assert d["config"]["setup_seconds_slowest_rank"] < 600
