@@ -657,6 +657,7 @@ int dvq_entropy_map_f32(const float *images, int B, int H, int W, int patch, flo
     if (!images || !out) { dvq_set_error("dvq_entropy_map_f32: null pointer"); return DVQ_EINVAL; }
     if (B <= 0 || H <= 0 || W <= 0) { dvq_set_error("dvq_entropy_map_f32: sizes must be positive"); return DVQ_EINVAL; }
     if (patch != 16 || H % 16 != 0 || W % 16 != 0) { dvq_set_error("dvq_entropy_map_f32: patch=%d H=%d W=%d (patch 16, H and W multiples of 16)", patch, H, W); return DVQ_EUNSUPPORTED; }
+    if ((long)B * (H / 16) * (W / 16) >= (1L << 30)) { dvq_set_error("dvq_entropy_map_f32: %ld patches (at most 2^30 per call)", (long)B * (H / 16) * (W / 16)); return DVQ_EUNSUPPORTED; }
     return hip_rc(dvq_launch_entropy_map(images, B, H, W, out, (hipStream_t)stream), "entropy_map");
 }
 

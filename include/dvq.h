@@ -59,11 +59,18 @@ extern "C" {
                                  /* >= 131072 tokens.  Same output.                                         */
 
 /* Flag, OR-ed into `mode` of the filter-path ops (every dvq_vq_assign_* entry point; ignored in DVQ_MODE_EXACT): the caller
- * guarantees that this workspace is CLEAN -- it was zero-filled when it was allocated (hipMemsetAsync / torch.zeros over
- * its whole size), or the last call that used it was a filter-path op WITHOUT DVQ_MODE_FILTER_PASS1 that returned DVQ_OK --
- * and that no other stream is using it.  A filter-path op leaves its workspace clean (its last consumer workgroup puts every
- * live counter back to zero), so with the flag no zeroing kernel is launched: one kernel boundary (~5 us) less per op.
- * Without the flag the op zeroes what it needs first and any bytes are fine (the behaviour of earlier versions). */
+ * guarantees that this workspace is CLEAN FOR THIS CALL'S LAYOUT and that no other stream is using it.  Clean means one of:
+ *   (a) the whole workspace was zero-filled (hipMemsetAsync / torch.zeros over all of its bytes) and no op has used it since, or
+ *   (b) the last call that used it was a filter-path op WITHOUT DVQ_MODE_FILTER_PASS1 that returned DVQ_OK, through the SAME
+ *       entry point and with the SAME shape arguments (B, D, HW or hc / wc, K) as this call.
+ * (b) is shape-bound because the live words -- the 1-KiB counter block and the resolver's chunk tickets -- sit BEHIND the loss
+ * partials, whose size is a function of B * HW, and the number of tickets is a function of the queue capacity (also B * HW): an
+ * op leaves exactly ITS live words zero (its last consumer workgroup puts every counter back), not those of another shape's
+ * layout.  A workspace that is merely large enough but was last used with other shape arguments is NOT clean: passing the flag
+ * then lets pass 1 index its lists with stale counters (out-of-bounds device writes).  Keep one workspace per (stream, entry
+ * point, shape) -- what the Python classes do, quantize._CodebookPrep.workspace -- or drop the flag when the shape changes.
+ * With the flag no zeroing kernel is launched: one kernel boundary (~5 us) less per op.  Without it the op zeroes what it needs
+ * first and any bytes are fine (the behaviour of versions before 0.5.0). */
 #define DVQ_MODE_WS_CLEAN 0x100
 
 /* gate kinds for the router select / routed assign */
