@@ -208,13 +208,14 @@ int dvq_vq_assign_flat_f32(const float *z, const float *codebook, const void *pr
 // ---- the 1x1 quant_conv fused into the assign (filter mode; D = 256) --------------------------------------------------
 static int conv_desc(const char *fn, const void *qconv_prep, float *h_buf, int h_all, int D, DvqConv *cv)
 {
-    if (!qconv_prep || !h_buf) { dvq_set_error("%s: qconv_prep and h_buf are required", fn); return DVQ_EINVAL; }
+    if (!qconv_prep) { dvq_set_error("%s: qconv_prep is required", fn); return DVQ_EINVAL; }
+    if (h_all && !h_buf) { dvq_set_error("%s: h_all needs an h_buf", fn); return DVQ_EINVAL; }
     if (D != 256) { dvq_set_error("%s: the fused conv exists for D = 256 (got %d): use dvq_qconv_f32 + dvq_vq_assign_nchw_f32", fn, D); return DVQ_EUNSUPPORTED; }
     if (((uintptr_t)qconv_prep & 255) != 0 || ((uintptr_t)h_buf & 3) != 0) { dvq_set_error("%s: qconv_prep must be 256-byte aligned", fn); return DVQ_EINVAL; }
     cv->meta = (const QconvMeta *)qconv_prep;
     cv->wimg = (const char *)qconv_prep + 256;
     cv->bias = (const float *)((const char *)qconv_prep + 256 + (size_t)(D / 32) * qconv_tile_bytes(D));
-    cv->h_buf = h_buf;
+    cv->h_buf = h_all ? h_buf : nullptr;                     // (without h_all the op touches no h_buf: nullable since 0.6.0)
     cv->h_all = h_all ? 1 : 0;
     return DVQ_OK;
 }

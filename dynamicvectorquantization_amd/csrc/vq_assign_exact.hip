@@ -24,7 +24,8 @@
 
 // ROUTED: token = output position of a routed batch (dvq_filter.h: DvqRouted), read from the encoder branch that
 // won its cell.
-// FOLDCONV (list mode of the conv-folded filter path, vq_fold.hip): z / the branches hold the conv's INPUT; a wave first
+// FOLDCONV (list mode of the filter path behind a 1x1 quant_conv -- folded into the codebook, vq_fold.hip, or computed in pass 1's
+// prologue): z / the branches hold the conv's INPUT; a wave first
 // computes h = W x + bias for its 32 tokens (qconv.hip's split-fp16 arithmetic on the matrix cores, weight fragments straight
 // from the L2-resident images; bit-identical to dvq_qconv_f32 and to the resolver's h) and moves the accumulators into the
 // (even / odd channel per lane half) layout of zr by one cross-half exchange per register pair.  A rare path: one workgroup
@@ -157,6 +158,12 @@ __global__ __launch_bounds__(256, FOLDCONV ? 1 : 2) void vq_assign_exact_kernel(
                     zr[16 * t8 + 8 * a + 4 + m] = h ? keep : recv;
                 }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        // (the conv-fused op's test form: the h this kernel scores replaces what pass 1 wrote for the token)
+        if (cv.h_all && cv.h_buf != nullptr && valid) {
+            float *hp = cv.h_buf + zqbase;
+#pragma unroll
+            for (int s = 0; s < S; ++s) hp[(size_t)2 * s * HWo] = zr[s];
         }
     } else {
 #pragma unroll

@@ -948,25 +948,8 @@ __device__ __forceinline__ void pass1_body(
         int pos = atomicAdd(&counters[DVQ_C_EXACT], 1);
         exact_list[pos] = n;
     }
-    auto spill_h = [&]() {                                  // CONV: the exact-list kernel reads this token's h from cv.h_buf
-        float *hp = cv.h_buf + token_base();
-#pragma unroll
-        for (int s = 0; s < S16; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
-    };
-    auto spill_h_cell = [&]() {                             // ... for every position of this lane's cell (rows Wout apart)
-        const int rr = sel_rep > 0 ? sel_rep : 1;
-        for (int ry = 0; ry < rr; ++ry)
-            for (int rx = 0; rx < rr; ++rx) {
-                float *hp = cv.h_buf + token_base() + (size_t)ry * rv.Wout + rx;
-#pragma unroll
-                for (int s = 0; s < S16; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) hp[(size_t)(16 * s + j) * HW] = zf[s][j];
-            }
-    };
-    if (CONV && valid && hopeless && !cv.h_all) spill_h();
+    // (CONV: the exact-list kernel computes the conv output of its tokens itself, from the conv's input -- round 6; through round 5
+    // pass 1 spilled their rows to a full-size [B, D, HW] scratch tensor, 256 MiB per stream at B = 256)
     float lsum = 0.0f;
     float m_tok = 1.0f;
     if (valid && !hopeless) {
@@ -1089,7 +1072,6 @@ __device__ __forceinline__ void pass1_body(
                         exact_list[pos] = n + ry * rv.Wout + rx;
                     }
             }
-            if (CONV && !cv.h_all) spill_h_cell();
             lsum = -(float)(sel_rep * sel_rep - 1) * lsum;  // ... for every copy of the cell (their terms equal this lane's bit for bit)
             slot = -1;
         }
@@ -2607,9 +2589,8 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     }
     if (rc || pass1_only) return rc;
     const int HWout = routed ? rv->HWout : HW, Wout = routed ? rv->Wout : 0;
-    // (h_all: pass 1 already wrote every token's row)
     rc = launch_resolver_d(D, img, meta, en_all, E, HWout, K, zq, codes, partials ? partials + np1 : nullptr,
-                           w, Wout, (cv != nullptr && !cv->h_all) ? cv->h_buf : nullptr, fd, st, partials, np1);
+                           w, Wout, nullptr, fd, st, partials, np1);
     if (rc) return rc;
     double *partials3 = partials ? partials + np1 + w.cap / RES_SLOTS : nullptr;
     // the list kernel is the last of the op: it also sums the partials into loss[0..1] and cleans the counter block; the
@@ -2622,10 +2603,11 @@ int dvq_launch_filter(const float *z, const void *prep, const float *E, const fl
     if (fd != nullptr)
         return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
                                      w.exact_list, list_count, tail, rv, st, &fd->cv);
-    // conv fused in: the tokens on the list have their conv output in cv->h_buf (dense layout), written by pass 1
+    // conv fused into pass 1: the same -- the list kernel's conv is qconv.hip's arithmetic, what pass 1's prologue computes too (and
+    // with h_all it writes the h it scored over pass 1's row of the token)
     if (cv != nullptr)
-        return dvq_launch_exact_list(cv->h_buf, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
-                                     w.exact_list, list_count, tail, nullptr, st);
+        return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
+                                     w.exact_list, list_count, tail, rv, st, cv);
     return dvq_launch_exact_list(z, (const float *)prep, E, mask, D, HWout, K, N, zq, codes, partials3,
                                  w.exact_list, list_count, tail, rv, st);
 }

@@ -74,7 +74,6 @@ class _CodebookPrep:
         self.track_users = False # set by training-mode forwards: the image may be rebuilt while other streams read it
         self._users = {}         # stream handle -> event after that stream's last use
         self._ws = {}            # (B, D, HW, K, mode, device, stream) -> uint8 tensor
-        self._hbuf = {}          # (shape, device, stream) -> f32 tensor: h rows of exact-list tokens (ops with the conv fused in)
         self._last_ws = None
         self._retired = []       # images replaced outside training: kept alive for readers other streams may still have queued
         self._fold = {}          # id(conv) -> (key, buffer, (stream, event)): the conv folded into this codebook (vq_fold.hip)
@@ -82,7 +81,6 @@ class _CodebookPrep:
     def invalidate(self):
         self.key = None
         self._padded = None
-        self._hbuf.clear()       # the [B, D, *spatial] scratch tensors of the fused-conv ops (one per shape and stream) are re-made on demand
 
     def get(self, codebook):
         K, D = codebook.shape
@@ -203,19 +201,6 @@ class _CodebookPrep:
         self._last_ws = (key, ws)
         return ws
 
-    def h_scratch(self, shape, device):
-        """[B, D, *spatial] f32 buffer of the ops with the quant_conv fused in, PER STREAM like the workspaces (pass 1 and the
-        resolver write the conv output of their exact-list tokens there and the list kernel of the same op reads them back).
-        Memory: a full feature map per (shape, stream) -- 256 MiB at B = 256 on a 32 x 32 grid -- of which a handful of rows
-        is ever touched; at most 8 are cached and `invalidate()` frees them.  The fold form (fold=True) needs none."""
-        key = (tuple(shape), device, _lib.stream_ptr(device))
-        hb = self._hbuf.get(key)
-        if hb is None:
-            if len(self._hbuf) >= 8:
-                self._hbuf.clear()
-            hb = self._hbuf[key] = torch.empty(tuple(shape), dtype=torch.float32, device=device)
-        return hb
-
     def fallback_count(self):
         """(tokens queued for the resolver, tokens sent to the full exact pass) of the last
         filter-mode call through this object (syncs)"""
@@ -233,16 +218,15 @@ class _CodebookPrep:
 
 
 def _conv_args(conv, prep, shape, device, h_buf):
-    """(prepared conv buffer, h_buf, h_all) for the ops with the 1x1 quant_conv fused in.  h_buf [B, D, *spatial]: pass 1 writes
-    there the conv output of the few tokens it hands to the exact-list kernel (ALL tokens when the caller gives the tensor:
-    tests); without one a scratch tensor cached on the codebook's prep, one per stream, is used."""
+    """(prepared conv buffer, h_buf or None, h_all) for the ops with the 1x1 quant_conv fused in.  h_buf [B, D, *spatial] (tests,
+    the bench's parity check): the op also writes there the conv output it scored, for EVERY token.  Without one the op needs no
+    scratch at all (round 6: the exact-list kernel computes the conv output of its few tokens itself; through round 5 a full-size
+    scratch tensor per stream -- 256 MiB at B = 256 -- received their rows)."""
     from . import qconv as _qconv
     if not _qconv.usable(conv) or conv.in_channels != 256:
         raise _lib.DvqError("fused quant_conv: needs a 1x1 nn.Conv2d(256, 256) on the GPU (other sizes: quant_conv + vq_assign)")
     h_all = h_buf is not None
-    if h_buf is None:
-        h_buf = prep.h_scratch(shape, device)
-    elif tuple(h_buf.shape) != tuple(shape) or h_buf.dtype != torch.float32 or not h_buf.is_contiguous() or h_buf.device != device:
+    if h_all and (tuple(h_buf.shape) != tuple(shape) or h_buf.dtype != torch.float32 or not h_buf.is_contiguous() or h_buf.device != device):
         raise ValueError("h_buf must be a contiguous f32 tensor %s on %s" % (tuple(shape), device))
     return _qconv._prep_of(conv).get(conv), h_buf, h_all
 
@@ -376,7 +360,7 @@ def vq_assign(z, codebook, prep, mask=None, beta=0.25, want_zq=True, want_loss=T
             pbuf = prep.get(codebook)
             ws.check(mode, _lib_handle.dvq_vq_assign_qconv_f32(
                 z.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(), pbuf.data_ptr(), _lib.ptr(mask), B, D, HW, K, float(beta),
-                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), hb.data_ptr(), int(h_all), *ws.begin(mode),
+                _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss), _lib.ptr(hb), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(z.device)), "dvq_vq_assign_qconv_f32")
         return zq, codes, loss
     if HW == 1:
@@ -478,7 +462,7 @@ def vq_assign_routed_dual(h_coarse, h_fine, codebook, prep, gate=None, entropy=N
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_dual_f32(
                 g.data_ptr(), kind, thr, h_coarse.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(), codebook.data_ptr(),
                 pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(), _lib.ptr(loss),
-                indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), hb.data_ptr(), int(h_all), *ws.begin(mode),
+                indices.data_ptr(), cmask.data_ptr(), _lib.ptr(gate_out), _lib.ptr(hb), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_dual_f32")
         return res
     with _lib.on_device(h_fine.device):
@@ -536,7 +520,7 @@ def vq_assign_routed_triple(h_coarse, h_median, h_fine, codebook, prep, gate, be
             ws.check(mode, _lib_handle.dvq_vq_assign_routed_qconv_triple_f32(
                 g.data_ptr(), kind, h_coarse.data_ptr(), h_median.data_ptr(), h_fine.data_ptr(), qbuf.data_ptr(),
                 codebook.data_ptr(), pbuf.data_ptr(), B, D, hc, wc, K, float(beta), _lib.ptr(zq), codes.data_ptr(),
-                _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), hb.data_ptr(), int(h_all), *ws.begin(mode),
+                _lib.ptr(loss), indices.data_ptr(), cmask.data_ptr(), _lib.ptr(hb), int(h_all), *ws.begin(mode),
                 _lib.stream_ptr(h_fine.device)), "dvq_vq_assign_routed_qconv_triple_f32")
         return res
     with _lib.on_device(h_fine.device):

@@ -237,9 +237,11 @@ DVQ_API int dvq_qconv_select_f32(int num_branches, const void *gate, int gate_ki
  * bit-exact GIVEN that h.  D = 256 and DVQ_MODE_FILTER (or DVQ_MODE_FILTER_PASS1) only -- other sizes: dvq_qconv_* followed
  * by the assign (DVQ_EUNSUPPORTED otherwise).
  *   qconv_prep   the buffer dvq_qconv_prepare_f32 filled
- *   h_buf        [B, D, HW] floats, REQUIRED: receives the conv output of the tokens pass 1 hands to the exact-list kernel
- *                (non-finite or out-of-range latents, queue overflow), which reads them from there; with h_all != 0 the
- *                conv output of EVERY token (how the tests check the contract above).  Other rows are not touched.
+ *   h_buf        NULL, or with h_all != 0 [B, D, HW] floats that receive the conv output the op scored, for EVERY token (how the
+ *                tests and bench.py check the contract above).  Since 0.6.0 the op needs no scratch: the tokens pass 1 or the
+ *                resolver hand to the exact-list kernel (non-finite or out-of-range latents, queue or candidate overflow) get
+ *                their conv output computed by that kernel, from the conv's input, with dvq_qconv_f32's arithmetic (0.3.0 -
+ *                0.5.0 REQUIRED a full-size h_buf for their rows: 256 MiB per stream at B = 256).  h_all == 0: h_buf is ignored.
  *   everything else as dvq_vq_assign_nchw_f32 / dvq_vq_assign_routed_{dual,triple}_f32 (x / h_coarse.. = the conv's INPUT)
  */
 DVQ_API int dvq_vq_assign_qconv_f32(const float *x, const void *qconv_prep, const float *codebook, const void *prep,

@@ -459,10 +459,11 @@ def test_conv_weight_images_are_ordered_across_streams(dev):
 @pytest.mark.parametrize("routed", [False, True])
 def test_fused_conv_resolver_overflow_hands_h_to_the_exact_list(dev, oracle_mod, routed):
     """with the conv fused in, the tokens the RESOLVER sends to the exact list (more than RES_CAND = 512
-    candidate pairs per 32 queued tokens: a codebook with many duplicate codes) must reach the exact-list kernel with their
-    conv output:
-    the resolver writes the record's h into h_buf before it appends the token.  Without an h_buf tensor (scratch = torch.empty,
-    never written by pass 1 for those rows) the op has to give the same bits as with h_all, and as qconv followed by the assign."""
+    candidate pairs per 32 queued tokens: a codebook with many duplicate codes) must be evaluated on their conv output.  Since
+    round 6 the exact-list kernel computes that output itself from the conv's input (no scratch tensor exists any more; with an
+    h_buf it writes the h it scored over pass 1's row of the token): without an h_buf the op has to give the same bits as with
+    one, the h_buf has to be the h every token was scored with (oracle GIVEN it), and -- when the conv kernels agree bit for
+    bit -- the same as qconv followed by the assign."""
     from dynamicvectorquantization_amd import synth
     from dynamicvectorquantization_amd.qconv import quant_conv
     from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
@@ -477,9 +478,7 @@ def test_fused_conv_resolver_overflow_hands_h_to_the_exact_list(dev, oracle_mod,
         prep = _CodebookPrep()
         hb = torch.empty((B, D, 32, 32), device=dev)
         r_all = vq_assign_routed_dual(t(hc), t(hf), t(E), prep, entropy=t(ent), threshold=THR, conv=conv, h_buf=hb)
-        # poison what the scratch rows may hold: a stale h from another batch must not leak into the result
         prep2 = _CodebookPrep()
-        prep2.h_scratch((B, D, 32, 32), dev).fill_(float("nan"))
         r = vq_assign_routed_dual(t(hc), t(hf), t(E), prep2, entropy=t(ent), threshold=THR, conv=conv)
         torch.cuda.synchronize()
         queued, listed = prep2.fallback_count()
@@ -494,7 +493,6 @@ def test_fused_conv_resolver_overflow_hands_h_to_the_exact_list(dev, oracle_mod,
         h = quant_conv(conv, t(x))
         zq0, codes0, loss0 = vq_assign(h, t(E), _CodebookPrep(), None)
         prep = _CodebookPrep()
-        prep.h_scratch((B, D, 16, 16), dev).fill_(float("nan"))
         zq, codes, loss = vq_assign(t(x), t(E), prep, None, conv=conv)
         torch.cuda.synchronize()
         queued, listed = prep.fallback_count()
