@@ -131,10 +131,8 @@ def _load():
         lib.dvq_tuning_set.argtypes = [ctypes.c_char_p, i32]
         lib.dvq_tuning_buffers.restype = i32
         lib.dvq_tuning_buffers.argtypes = [vp, vp]
-        lib.dvq_tuning_pipe_stamps.restype = i32
-        lib.dvq_tuning_pipe_stamps.argtypes = [vp]
         # tools/ only: DVQ_TUNE="key=value,..." sets A/B switches of the tuning build for a whole process (e.g. bench.py under
-        # tools/ab_lib.sh); the product library exports no such symbol and this branch is not taken
+        # tools/archive/ab_lib.sh); the product library exports no such symbol and this branch is not taken
         for kv in filter(None, os.environ.get("DVQ_TUNE", "").split(",")):
             k, v = kv.split("=")
             if lib.dvq_tuning_set(k.strip().encode(), int(v)) != 0:

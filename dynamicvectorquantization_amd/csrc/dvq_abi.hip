@@ -6,7 +6,7 @@
 #include "../../include/dvq.h"
 #include "dvq_filter.h"
 
-#define DVQ_VERSION 500   // 0.5.0: fused form of the filter path (resolver inside pass 1's launch), DVQ_MODE_WS_CLEAN
+#define DVQ_VERSION 600   // 0.6.0 (include/dvq.h lists what each version changed)
 #define DVQ_ROUTE_MAX_CELLS_ABI 1024   // = DVQ_ROUTE_MAX_CELLS (dvq_filter.h)
 
 static thread_local char g_err[512] = "";

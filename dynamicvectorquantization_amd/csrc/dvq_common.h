@@ -125,7 +125,7 @@ struct DvqLossTail {
 #define DVQ_SPLIT_MAX_BLOCKS 64   // ... which serves up to this many token blocks of 128 (beyond: no gain measured, profiles/r05_small_batch.json)
 // Cache policy of the streaming reads of a batch's latents / branch features: up to this many bytes of the FINEST tensor (the coarser
 // branches add a third) they are read with plain loads -- the 256-MB memory-side cache then serves what the producer wrote or the router
-// gate just read -- above it with the non-temporal hint.  profiles/r04_cache_policy.json: one batch at a time, plain loads pay up to
+// gate just read -- above it with the non-temporal hint.  profiles/archive/r04_cache_policy.json: one batch at a time, plain loads pay up to
 // ~150 MB (configs[1] -2.4 %, the gate op -5 %); with three batches in flight on three streams (how bench.py and a serving loop drive
 // the op) they pay only while all three working sets fit the cache together, hence 64 MiB (B = 64 at 32 x 32 x 256); B = 128 under
 // three streams loses 3 % with plain loads, B = 256 3 - 6 % even alone.

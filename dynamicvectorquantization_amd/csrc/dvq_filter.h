@@ -136,7 +136,7 @@ __device__ __forceinline__ float vmax3_raw(float a, float b, float c)
 // rep_g x rep_g output positions (rep = SC / sub, SC = sub of the fine type).
 // (Scoring only the unique tokens -- 640 of 1024 per image at fine ratio 0.5 -- was built three times in round 2 and
 // measured slower every time: the z_q lines are then assembled from 8-byte pieces by different instructions; see
-// DESIGN.md section 4.3 and profiles/r02_*dedup*.)
+// DESIGN.md section 4.3 and profiles/archive/r02_*dedup*.)
 // ---------------------------------------------------------------------------------------------
 #define DVQ_ROUTE_MAX_CELLS 1024
 

@@ -12,7 +12,7 @@
 // Privatising the sums in LDS ([K][33] fp32 per 32-channel slice, ds_add_f32, one global atomic per non-zero entry at the
 // end: 8 M instead of 67 M global atomics at B = 256) was built and measured in round 3: 370 us against this kernel's 288 --
 // a ds_add_f32 wave-instruction takes 192 cycles whatever its address pattern (tools/micro/lds_atomic_rate.hip: three
-// cycles per lane, 170 G adds/s over the chip, below the 233 G/s the L2 atomics reach here); profiles/r03_ema_lds_negative.json.
+// cycles per lane, 170 G adds/s over the chip, below the 233 G/s the L2 atomics reach here); profiles/archive/r03_ema_lds_negative.json.
 #include "dvq_common.h"
 
 // COMBINE: tokens of a tile that chose the same code are summed in LDS first and reach the global sums as ONE row of

@@ -47,7 +47,7 @@
 #define DVQ_WIDE_MIN_K 2048      // codebook size from which pass 1 takes the two-blocks-per-wave form (whole op at B = 256: -2 % at 1024, +8 % at 2048, +10 % at 4096 and 16384)
 #endif
 // (Round 3's timing-only ablation switches, the per-CU anti-phase lock, the early-DMA variant and the per-workgroup clock stamps
-// left this file in round 4: their results are in profiles/r03_pass1_*.json and DESIGN.md section 5.1, the code in git history
+// left this file in round 4: their results are in profiles/archive/r03_pass1_*.json and DESIGN.md section 5.1, the code in git history
 // up to commit "Feature-router gate as a tiled GEMM".)
 
 // ---------------------------------------------------------------------------------------------
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restri
 // diagnostic of the tuning build only: per-token (best, second, 2W, code) of the production arithmetic for the bound audit
 // (tools/bound_audit.py --production).  Written to a buffer of its own; no output value is computed from it.
 __device__ float *g_dvq_tokdbg = nullptr;                  // [N][4]
-// ... and stage stamps of the split form's workgroups (100-MHz wall clock): [workgroup][8] (tools/split_timeline.py)
+// ... and stage stamps of the split form's workgroups (100-MHz wall clock): [workgroup][8] (tools/archive/split_timeline.py)
 __device__ unsigned long long *g_dvq_stamps = nullptr;
 #define DVQ_STAMP(i) do { if (SPLIT && g_dvq_stamps != nullptr && threadIdx.x == 0) g_dvq_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 // ... and of the resolver's workgroups, behind those: [4096 + workgroup][8]
@@ -267,7 +267,7 @@ __device__ unsigned long long *g_dvq_stamps = nullptr;
 // NT: the latents are read with the non-temporal hint (a launch streams more than the 256-MB memory-side cache holds: keep L2 for
 // the code image and the codebook rows) or with plain loads (vq_assign_filter_cached_kernel: a batch whose features FIT that cache
 // was just written by the encoder / read by the router gate, and plain loads are served from it: -6 % on the configs[3] per-GPU
-// step, profiles/r04_cache_policy.json)
+// step, profiles/archive/r04_cache_policy.json)
 // FLAT: the latents are ROW-MAJOR [N, D] (a token's channels contiguous: quantize2_list.py:153-170, channel_last inputs,
 // VQEmbedding.forward) -- the same tensor as [B = N, D, HW = 1], but read and written as what it is: a lane's 8 channels of a
 // k-step are 32 contiguous bytes = two 16-byte accesses (32 loads and 32 stores per lane instead of 128 each; with lane = token
@@ -763,10 +763,10 @@ __device__ __forceinline__ void pass1_body(
         // Per tile: barrier -> the first four A-fragment reads are issued -> the running top-2 is updated with the PREVIOUS
         // tile's scores (plain VALU work that hides the LDS latency of those reads) -> the accumulators are re-seeded ->
         // MFMA chain.  A wave's instruction ISSUE, not the matrix pipe, bounds this loop: about 1330 cycles per tile, of which
-        // the pipe is busy 512; a workgroup alone on a CU takes as long as two sharing it (profiles/r03_pass1_antiphase_ab.json,
+        // the pipe is busy 512; a workgroup alone on a CU takes as long as two sharing it (profiles/archive/r03_pass1_antiphase_ab.json,
         // r03_pass1_loop_ablation.json).  Moving the top-2 update into the shadow of the MFMAs (one code half behind them, no
         // second accumulator set) changed nothing, as that model predicts: 42.7k vs 42.6k cycles per loop
-        // (profiles/r03_pass1_half_tile_pipelining.json; git history has the code).
+        // (profiles/archive/r03_pass1_half_tile_pipelining.json; git history has the code).
         f32x4 acc16[2][2];
         auto top2 = [&](int tt) {
 #pragma unroll
@@ -2212,24 +2212,15 @@ int dvq_launch_exact_list(const float *z, const float *prep, const float *E, con
 struct DvqTune {
     int sel_staged;      // routed op on a 32-wide output grid: coarser branches through LDS (SEL = 2) instead of per-lane loads
     int res_slices;      // resolver slices over the code tiles, 0 = by codebook size
-    int pipe;            // pass 1 in the persistent role-alternating form (vq_assign_pipe.hip) where it applies
     int flat;            // HW == 1 (row-major [N, D]) through the row-major form of pass 1 (0: through the NCHW kernel, for the A/B)
     int split;           // small batches: several workgroups per token block (SPLIT form of pass 1); 0: never (for the A/B)
 };
-#ifndef DVQ_PIPE_DEFAULT
-#define DVQ_PIPE_DEFAULT 0
-#endif
-bool dvq_pipe_supported(int D, int HW, int K, long N, const DvqRouted *rv);
-int dvq_launch_pipe(const float *z, const char *img16, const DvqF16Meta *meta, const float *E, const float *mask,
-                    int HW, int K, long N, float *zq, long long *codes, double *partials, int npart, int *counters,
-                    int *exact_list, char *records, int rec_cap, const DvqRouted *rv, hipStream_t st);
 #ifdef DVQ_TUNING
-static DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1, 1};
+static DvqTune g_tune = {1, 0, 1, 1};
 extern "C" __attribute__((visibility("default"))) int dvq_tuning_set(const char *key, int value)
 {
     if (!strcmp(key, "sel_staged")) g_tune.sel_staged = value;
     else if (!strcmp(key, "res_slices")) g_tune.res_slices = value;
-    else if (!strcmp(key, "pipe")) g_tune.pipe = value;
     else if (!strcmp(key, "flat")) g_tune.flat = value;
     else if (!strcmp(key, "split")) g_tune.split = value;
     else return -1;
@@ -2244,7 +2235,7 @@ extern "C" __attribute__((visibility("default"))) int dvq_tuning_buffers(void *s
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dvq_tokdbg), &tokdbg, sizeof(void *));
 }
 #else
-static constexpr DvqTune g_tune = {1, 0, DVQ_PIPE_DEFAULT, 1, 1};
+static constexpr DvqTune g_tune = {1, 0, 1, 1};
 #endif
 
 static bool dvq_flat_form_enabled() { return g_tune.flat != 0; }
@@ -2483,12 +2474,6 @@ static int launch_pass1(const float *z, const char *img, const DvqF16Meta *meta,
             return -1000;
         }
     }
-#ifdef DVQ_TUNING
-    // tuning build: the persistent role-alternating form (vq_assign_pipe.hip; measured slower so far, see its header)
-    if (g_tune.pipe && !force_wide && dvq_pipe_supported(D, HW, K, N, rv) && (rv == nullptr || staged_select_ok(*rv)))
-        return dvq_launch_pipe(z, img16, meta, E, mask, HW, K, N, zq, codes, partials, nb1, w.counters, w.exact_list,
-                               w.records, w.cap / DVQ_QSHARDS, rv, st);
-#endif
     if (rv != nullptr) {                                     // select fused in
         if (const int ks = split_slices(K, N); ks > 1 && w.split != nullptr) {   // small batch: several workgroups per token block
             static unsigned long long done_ss = 0;

@@ -26,14 +26,17 @@ _lib_handle = _lib.lib
 
 class _Workspace:
     """One workspace of the filter-path ops (loss partials, queue counters, record stamps, lists, records) and whether it is
-    CLEAN: zero-filled at allocation, and every filter-path op leaves it clean again (its last consumer workgroup puts the live
-    counters back to zero), so the steady state passes `DVQ_MODE_WS_CLEAN` and no zeroing kernel is launched (include/dvq.h).
+    CLEAN: every filter-path op leaves it clean (its last consumer workgroup puts the live counters back to zero), so from the
+    second op on the steady state passes `DVQ_MODE_WS_CLEAN` and no zeroing kernel is launched (include/dvq.h).  One workspace
+    per (stream, entry point, shape): the flag is shape-bound.
     `begin` marks it dirty until `end` has seen the call return DVQ_OK; the profiling mode MODE_FILTER_PASS1 leaves it dirty."""
     __slots__ = ("t", "clean")
 
     def __init__(self, nbytes, device):
-        self.t = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=device)
-        self.clean = True
+        # not zero-filled (a memset of the whole workspace, 4-5 MB and more, per new shape cost more than the ~5-us zero kernel the
+        # flag saves -- ADVICE r5): the FIRST filter-path op on it runs without the flag, zeroes what it needs and leaves it clean
+        self.t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        self.clean = False
 
     def begin(self, mode):
         """-> (pointer, bytes, mode [| MODE_WS_CLEAN]) for the ABI call"""
@@ -246,20 +249,28 @@ def _fold_args(conv, prep, codebook, want_loss, mode):
 
 
 _TORCH_RANDPERM = torch.randperm        # (tests and goldens pin the dead-code restart by replacing torch.randperm)
+_RESTART_GEN = None                     # (torch.initial_seed() it was made for, torch.Generator): _restart_pick's own stream of seeds
 
 
 def _restart_pick(n, k, device):
     """the first k entries of a uniform random permutation of range(n) -- what the reference's dead-code restart takes from
     `torch.randperm(n_vectors)` (quantize2_mask.py:93-96) -- without permuting all n: drawing indices independently and keeping
     first occurrences IS sequential sampling without replacement, i.e. the same distribution (`dvq_restart_pick_i64`: one small
-    workgroup, 2k counter-based draws, an LDS hash table; fewer than k distinct values among them does not happen for n >= 16 k,
-    and a slot that stayed empty would keep its own index).  The full
+    workgroup, 2k counter-based draws, an LDS hash table; fewer than k distinct values among them does not happen in practice for n >= 16 k;
+    a slot that stayed empty would keep its own index i, which may repeat a chosen one -- `distinct` is a practical, not a formal property).  The full
     permutation is a 262 144-key device sort, ~115 us of the 1.04-ms training step at B = 256 (rocprofv3: profiles/
     r05_train_step.json).  Small batches, CPU tensors and a caller that replaced torch.randperm (the tests pin the permutation
     that way) take torch.randperm itself."""
     if torch.randperm is not _TORCH_RANDPERM or n < 16 * k or k > 2048 or device.type != "cuda":
         return torch.randperm(n, device=device)[:k]
-    seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF     # the CPU generator: torch.manual_seed governs it
+    global _RESTART_GEN
+    if _RESTART_GEN is None or _RESTART_GEN[0] != torch.initial_seed():
+        # a generator of its own, seeded from torch.manual_seed's value: the pick is reproducible under torch.manual_seed and
+        # does not advance the global CPU generator (data-loader shuffles after it draw what they drew without it -- ADVICE r5)
+        g = torch.Generator()
+        g.manual_seed((torch.initial_seed() ^ 0x5DEECE66D) & 0x7FFFFFFFFFFFFFFF)
+        _RESTART_GEN = (torch.initial_seed(), g)
+    seed = int(torch.empty((), dtype=torch.int64).random_(generator=_RESTART_GEN[1]).item()) & 0x7FFFFFFFFFFFFFFF
     out = torch.empty(k, dtype=torch.int64, device=device)
     with _lib.on_device(device):
         _lib.check(_lib_handle.dvq_restart_pick_i64(seed, n, k, out.data_ptr(), _lib.stream_ptr(device)), "dvq_restart_pick_i64")

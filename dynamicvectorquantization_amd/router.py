@@ -246,12 +246,16 @@ class _GateWeightPrep:
     def invalidate(self):
         self.key = None
 
-    def get(self, w1, nb, C, gn=None):
+    def get(self, w1, nb, C, gn=None, owners=None):
         """gn: (weights, biases) of the branches' GroupNorms, coarse -> fine (None: no normalisation): their per-branch maxima
-        are prepared into the same buffer (`dvq_router_gate_prepare_norm_f32`) and refreshed when a parameter's version changes"""
+        are prepared into the same buffer (`dvq_router_gate_prepare_norm_f32`) and refreshed when a parameter's version changes.
+        owners: the module PARAMETERS the tensors were derived from (w1's, then the GroupNorms'): the cache is keyed on THEIR
+        (data_ptr, _version, dtype) -- a converted copy (non-fp32 or non-contiguous parameters) is a fresh temporary on every
+        call, whose address and version say nothing"""
         hidden = w1.shape[0]
-        key = (w1.data_ptr(), w1._version, tuple(w1.shape), w1.device)
-        gkey = None if gn is None else tuple((t.data_ptr(), t._version) for t in gn[0] + gn[1])
+        ow = owners if owners is not None else [w1] + (list(gn[0] + gn[1]) if gn is not None else [])
+        key = (ow[0].data_ptr(), ow[0]._version, ow[0].dtype, tuple(w1.shape), w1.device)
+        gkey = None if gn is None else tuple((t.data_ptr(), t._version, t.dtype) for t in ow[1:])
         if key == self.key and gkey != getattr(self, "gkey", None):
             self.key = None                              # (simplest: a changed GroupNorm parameter rebuilds the whole prep)
         if key != self.key:
@@ -322,7 +326,10 @@ def fused_router_gate(gate, gate_type, norms, branches, weight_prep=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()
     med = hs[1] if nb == 3 else None
-    prep = (weight_prep.get(w1, nb, C, gn=(gw, gb) if groups > 0 else None)
+    owners = None
+    if w1 is not None:
+        owners = [gate[0].weight] + ([n.weight for n in norms] + [n.bias for n in norms] if groups > 0 else [])
+    prep = (weight_prep.get(w1, nb, C, gn=(gw, gb) if groups > 0 else None, owners=owners)
             if (weight_prep is not None and w1 is not None) else None)
     with _lib.on_device(dev):
         _lib.check(_lib_handle.dvq_router_gate_f32(

@@ -26,6 +26,14 @@
  *     fma(0, 0, acc) = acc to the dot chain and + 0 to the norm's partial sums, whose 32-way
  *     grouping does not depend on D -- which is what the Python drop-in does
  *     (quantize.py: _padded_width); divide the returned loss mean by D / D_padded.
+ *
+ * Versions (dvq_version() = 100 major + minor; re-query every *_bytes function after an upgrade: buffer sizes are part of a version)
+ *   0.6.0  the conv-fused assigns (dvq_vq_assign_qconv_f32, dvq_vq_assign_routed_qconv_*_f32) take h_buf = NULL: no scratch tensor
+ *          (0.3 - 0.5 required a full-size one); dvq_entropy_map_f32 refuses more than 2^30 patches per call; DVQ_MODE_WS_CLEAN's
+ *          contract spelled out (valid for the same entry point and shape only).  No signature changed.
+ *   0.5.0  DVQ_MODE_WS_CLEAN (self-cleaning workspace), dvq_vq_assign_flat_f32, dvq_restart_pick_i64,
+ *          dvq_router_gate_prepare_norm_f32; DVQ_COUNTER_BYTES, the filter workspace (+ split buffer) and the gate's weight
+ *          prep (+ 256-byte tail) grew: buffers sized by a 0.4.x build are too small for 0.5 and later.
  */
 #ifndef DVQ_H_
 #define DVQ_H_
@@ -353,6 +361,8 @@ DVQ_API int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, in
  * out [k] int64 = k DISTINCT indices of [0, n), every index equally likely, in random order (the distribution of a permutation's
  * prefix: independent draws, first occurrences kept), a pure function of (seed, n, k); one small workgroup.
  * 1 <= k <= 2048, 16 k <= n < 2^32.  RNG parity with torch is not possible either way.
+ * (Distinctness is a practical, not a formal property: the kernel makes 2 k draws; should fewer than k different values occur among
+ * them -- probability below 1e-100 for n >= 16 k -- a slot that stayed empty keeps its own index i, which may repeat a chosen one.)
  */
 DVQ_API int dvq_restart_pick_i64(uint64_t seed, int64_t n, int k, int64_t *out, void *stream);
 

@@ -80,7 +80,7 @@ def test_size_queries_and_validation_without_gpu():
     assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 128, 1, 1, 0.25, 0, 1, 0, q, 0, q, 1 << 30, 1, 0) == -2      # D = 128
     assert b"256" in L.dvq_last_error_string()
     assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, q, 0, q, 1 << 30, 0, 0) == -1      # exact mode
-    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, 0, 0, q, 1 << 30, 1, 0) == -1      # no h_buf
+    assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1, 1, 0.25, 0, 1, 0, 0, 1, q, 1 << 30, 1, 0) == -1      # h_all without an h_buf (h_buf alone is optional since 0.6.0)
     assert L.dvq_vq_assign_qconv_f32(1, q, 1, 1, 0, 1, 256, 1024, 1024, 0.25, 0, 1, 0, q, 0, q, 16, 1, 0) == -3    # workspace
     assert L.dvq_vq_assign_routed_qconv_dual_f32(1, 0, 0.0, 1, 1, q, 1, 1, 1, 128, 4, 4, 64, 0.25, 0, 1, 0, 1, 1, 0, q, 0,
                                                  q, 1 << 30, 1, 0) == -2                                              # D = 128

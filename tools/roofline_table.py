@@ -79,7 +79,7 @@ s = timeit(lambda: vq_assign(zb, E16, p16, None, mode=_lib.MODE_FILTER_PASS1), n
 row("vq_assign_filter_wide_kernel<256> (pass 1, K=16384)", "configs[4] B=512", s, 512 * 1024 * 2060 + 16384 * 1024, 2.0 * 16384 * 256 * 512 * 1024, F16,
     "matrix-bound config")
 del zb, E16, p16
-# feature-router gate, triple B=128 and dual B=64: rocprof splits pool / MLP (profiles/r02_gate_kernels_*.txt); here the op
+# feature-router gate, triple B=128 and dual B=64: rocprof splits pool / MLP (profiles/archive/r02_gate_kernels_*.txt); here the op
 r3 = TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
 f3 = [t(synth.z_tokens(En, 128, 8 << i, 8 << i, 2124 - 10 * i)) for i in range(3)]
 with torch.no_grad():
