@@ -927,7 +927,9 @@ def configs_block(dev, small=False):
     jpath = os.path.join(ROOT, "tests", "golden", "entropy_thresholds_imagenet_train_patch-16.json")
     rent = DualGrainFixedEntropyRouter(jpath, 0.5)
     nimg = min(B2, 32)
-    imgs = tile_images(torch.from_numpy(synth.images_flat_noise(5000, nimg)[0]).to(dev), B2)
+    ibase = torch.from_numpy(synth.images_flat_noise(5000, nimg)[0]).to(dev)     # (tiled by whole patches: the flat / noise mixture stays what it is)
+    imgs = torch.cat([torch.roll(ibase, 16 * k, -1) for k in range((B2 + nimg - 1) // nimg)], 0)[:B2].contiguous()
+    del ibase
     out["cfg2"] = routed("dual entropy-router r05: pixels -> entropy map kernel -> gate + select + quant_conv + assign (one op), K=1024",
                          B2, min(B2, 64), (pre(base16, B2), pre(base32, B2)), router=rent, images=imgs, no_conv_too=True)
     del imgs

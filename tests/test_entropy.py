@@ -130,6 +130,38 @@ def test_fused_entropy_value_sweep_and_special_pixels(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 16, 16), (3, 48, 80), (5, 16, 48), (2, 240, 240), (70, 64, 64)])
+def test_fused_entropy_shapes_and_edges_of_the_far_path(dev, shape):
+    """round 6 (the kernel became persistent, two patches per wave): a single patch, odd patch counts (the last wave's second half
+    has no patch), rows of an odd number of patches (a wave's two patches sit in different rows of patches), more pairs than resident
+    waves can take in one go -- and gray values concentrated where the bins at distance 3 and 4 are all a patch has (nearest bin -4,
+    -3, 34, 35: the register path of the far bins), mixed with ordinary patches in the same wave"""
+    from dynamicvectorquantization_amd.entropy import Entropy
+    from oracle.entropy_torch import entropy_map
+    B, H, W = shape
+    rng = np.random.default_rng(100 + B + H)
+    img = rng.uniform(-1, 1, (B, 3, H, W)).astype(np.float32)
+    gh, gw = H // 16, W // 16
+    k = 0
+    for b in range(B):
+        for py in range(gh):
+            for px in range(gw):
+                k += 1
+                if k % 3 == 0:       # flat-ish patch just outside the bins: gray in (-0.145, -0.08) or (1.08, 1.145)
+                    v = rng.uniform(-0.145, -0.081) if k % 2 else rng.uniform(1.081, 1.145)
+                    img[b, :, py * 16:(py + 1) * 16, px * 16:(px + 1) * 16] = np.float32(v) / np.float32(0.9999)
+                    img[b, :, py * 16 + 3, px * 16 + 5] = np.float32(-0.9)      # and one pixel far outside
+                elif k % 7 == 0:     # far outside altogether: every bin 0 -> the 1e-40 epsilons decide
+                    img[b, :, py * 16:(py + 1) * 16, px * 16:(px + 1) * 16] = np.float32(-0.6)
+    x = torch.from_numpy(img)
+    with torch.no_grad():
+        a = Entropy(16, W, H)(x.to(dev)).cpu().numpy()
+        b_ = entropy_map(x, chunk=2).numpy()
+    assert a.shape == (B, gh, gw)
+    assert np.all(np.abs(a - b_) <= 1e-5 * np.maximum(1.0, np.abs(b_))), (float(np.abs(a - b_).max()), np.unravel_index(np.abs(a - b_).argmax(), a.shape))
+
+
+@pytest.mark.gpu
 def test_entropy_other_patch_sizes(dev):
     """patch sizes the fused kernel does not cover (the reference's calculate_entropy_thresholds.py takes --patch_size)
     run as tensor ops on the GPU: same values as the comparator ops, and patch 16 through both routes agrees"""

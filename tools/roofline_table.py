@@ -5,6 +5,7 @@ that kernel; multi-kernel ops are listed with what the bracket contains.  Prints
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import _pass1_ms          # pass 1 ALONE: counters zeroed in front of the bracket, workspace declared clean
 from dynamicvectorquantization_amd import synth, _lib
 from dynamicvectorquantization_amd.quantize import _CodebookPrep, vq_assign, vq_assign_routed_dual
 from dynamicvectorquantization_amd.router import (DualGrainFeatureRouter, TripleGrainFeatureRouter, route_select_dual_entropy,
@@ -58,14 +59,26 @@ prep = _CodebookPrep()
 for _ in range(300):                          # bring the part out of its idle power state before the first measurement
     vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None))
 torch.cuda.synchronize()
-s = timeit(lambda: vq_assign_routed_dual(hc, hf, E, prep, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1,
-                                         out=(zq, codes, None, grain, cmask, gate)))
-row("vq_assign_filter_kernel<256,2> (pass 1, select fused in, coarse branch through LDS)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
-    "bracket includes the 4.6-us counter-zero kernel; VQ-forward byte count (the kernel also does the select's work); issue-bound code loop between two HBM-bound phases (DESIGN 5.1)")
-s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)))
-row("vq_assign_filter_kernel<256,0> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "bracket includes the counter-zero kernel")
+pd = _CodebookPrep()
+s = 1e-3 * _pass1_ms(lambda: vq_assign_routed_dual(hc, hf, E, pd, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1,
+                                                   out=(zq, codes, None, grain, cmask, gate)), pd, n=100)
+row("vq_assign_filter_kernel<256,2,false,false> (pass 1, select fused in, coarse branch through LDS)", "configs[2] B=256 K=1024", s, vq_bytes, vq_flops, F16,
+    "the kernel alone (HIP events; workspace declared clean); VQ-forward byte count (the kernel also does the select's work); issue-bound code loop between two HBM-bound phases, at the socket's power cap (DESIGN 5.1)")
+from dynamicvectorquantization_amd import qconv as _qc
+_q, _ = np.linalg.qr(synth.normal(6012, (D, D), 0.0, 1.0).astype(np.float64))
+conv = torch.nn.Conv2d(D, D, 1).to(dev).eval()
+with torch.no_grad():
+    conv.weight.copy_(t(_q.astype(np.float32).reshape(D, D, 1, 1))); conv.bias.copy_(t(synth.normal(6013, (D,), 0.0, 0.1)))
+pc = _CodebookPrep()
+s = 1e-3 * _pass1_ms(lambda: vq_assign_routed_dual(hc, hf, E, pc, entropy=ent, threshold=THR, mode=_lib.MODE_FILTER_PASS1, conv=conv,
+                                                   out=(zq, codes, None, grain, cmask, gate)), pc, n=100)
+row("vq_assign_filter_kernel<256,1,true,false> (pass 1 with the select AND the 1x1 quant_conv fused in: the model order)", "configs[2] B=256 K=1024", s, vq_bytes,
+    vq_flops + 3 * 2.0 * D * D * N, F16, "flops incl. the conv's three split-fp16 terms")
+pdn = _CodebookPrep()
+s = 1e-3 * _pass1_ms(lambda: vq_assign(hf, E, pdn, cmask, mode=_lib.MODE_FILTER_PASS1, out=(zq, codes, None)), pdn, n=100)
+row("vq_assign_filter_kernel<256,0,false,false> (dense pass 1)", "B=256 K=1024", s, vq_bytes, vq_flops, F16, "the kernel alone")
 s_full = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_FILTER, out=(zq, codes, loss)))
-row("dense filter op (zero + pass 1 + resolver + list/finalize)", "B=256 K=1024", s_full, vq_bytes, vq_flops, F16)
+row("dense filter op (pass 1 + resolver + list/finalize; no zero kernel in the steady state)", "B=256 K=1024", s_full, vq_bytes, vq_flops, F16)
 s = timeit(lambda: vq_assign(hf, E, prep, cmask, mode=_lib.MODE_EXACT, out=(zq, codes, loss)), n=10, warm=3)
 row("vq_assign_exact_kernel<256> (fp32 MFMA chain)", "B=256 K=1024", s, vq_bytes, vq_flops, F32)
 s = timeit(lambda: route_select_dual_entropy(ent, THR, hc, hf, out=(h_dual, grain, cmask, gate)))
@@ -85,13 +98,13 @@ f3 = [t(synth.z_tokens(En, 128, 8 << i, 8 << i, 2124 - 10 * i)) for i in range(3
 with torch.no_grad():
     s = timeit(lambda: r3(h_fine=f3[2], h_median=f3[1], h_coarse=f3[0]))
 feat_bytes3 = sum(x.numel() * 4 for x in f3)
-row("gate_pool_kernel + router_gate_kernel<3,1> (triple gate op)", "configs[3] per-rank B=128", s, feat_bytes3,
-    3 * 2.0 * 768 * 768 * 128 * 64, F16, "bytes = the branch features once; flops = the 3-term split hidden layer; pool 35-37 us at the HBM read rate, MLP 49-51 us bound by the weight-fragment stream of one CU")
+row("gate_pool_kernel + gate_gemm_kernel<3,48> + gate_finalize_kernel (triple gate op)", "configs[3] per-rank B=128", s, feat_bytes3,
+    3 * 2.0 * 768 * 768 * 128 * 64, F16, "bytes = the branch features once; flops = the 3-term split hidden layer; per kernel: tools/gate_trace.sh")
 r2 = DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu").to(dev).eval()
 f2 = [t(synth.z_tokens(En, 64, 16 << i, 16 << i, 2112 - 10 * i)) for i in range(2)]
 with torch.no_grad():
     s = timeit(lambda: r2(h_fine=f2[1], h_coarse=f2[0]))
-row("gate_pool_kernel + router_gate_kernel<2,2> (dual gate op)", "configs[1] B=64", s, sum(x.numel() * 4 for x in f2),
+row("gate_pool_kernel + gate_gemm_kernel<2,32> + gate_finalize_kernel (dual gate op)", "configs[1] B=64", s, sum(x.numel() * 4 for x in f2),
     3 * 2.0 * 512 * 512 * 64 * 256, F16)
 # quant_conv
 from dynamicvectorquantization_amd.qconv import quant_conv, quant_conv_select
@@ -103,11 +116,15 @@ npos = 64 * 1024
 row("qconv_kernel<256,SEL> (select + 1x1 conv, split-fp16 MFMA)", "configs[1] B=64", s, npos * D * 4 * 2, 3 * 2.0 * 256 * 256 * npos, F16)
 # entropy map
 from dynamicvectorquantization_amd.entropy import Entropy
-img = t(synth.images_flat_noise(5000, 64)[0])
 ef = Entropy(16, 256, 256).to(dev)
-with torch.no_grad():
-    s = timeit(lambda: ef(img), n=20, warm=5)
-row("entropy_map_kernel", "B=64 images 3x256x256", s, img.numel() * 4 + 64 * 256 * 4, note="bound by exp / log throughput: 32 bins x 256 pixels per patch")
+_ib = t(synth.images_flat_noise(5000, 32)[0])
+for BB in (64, 256):
+    img = torch.cat([torch.roll(_ib, 16 * k, -1) for k in range(BB // 32)], 0).contiguous()
+    with torch.no_grad():
+        s = timeit(lambda: ef(img), n=200, warm=200)
+    row("entropy_map_kernel", "B=%d images 3x256x256" % BB, s, img.numel() * 4 + BB * 256 * 4,
+        note="vector-instruction issue + LDS histogram round trips beside the image read (csrc/entropy_map.hip)")
+del img
 # EMA statistics
 cs, vs = torch.zeros(K, device=dev), torch.zeros(K, D, device=dev)
 cod = torch.randint(0, K, (B, 32, 32), device=dev)
