@@ -190,7 +190,7 @@ DVQ_API int dvq_route_select_triple_f32(const void *gate, int gate_dtype,
  * token, read from the branch that won its cell (the grain is derived from the gate inside the kernel), scored,
  * and written; h_dual / h_triple is never materialised and indices / cmask / gate_out come out as by-products.
  * (The 2x2 / 4x4 positions of a coarse cell are copies of one vector and so get the same code; scoring each unique
- * vector once was built and measured slower -- DESIGN.md section 4.3.)  Same per-token arithmetic as the dense op:
+ * vector once was built and measured slower -- DESIGN.md section 8.)  Same per-token arithmetic as the dense op:
  * codes, z_q, indices, cmask identical bit for bit to select + assign, loss within 1e-5.
  *   gate      DVQ_GATE_F32 / DVQ_GATE_I64: [B, hc, wc, G]; DVQ_GATE_ENTROPY (dual only): entropy [B, hc, wc]
  *             with `threshold` (gate = [(e <= thr), (e > thr)], written to gate_out [B, hc, wc, 2] if non-NULL)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the small-batch form of pass 1 (DESIGN 4.3c: several workgroups per token block, each on a slice of the code tiles,
+"""GPU (-m gpu): the small-batch form of pass 1 (DESIGN 4.2: several workgroups per token block, each on a slice of the code tiles,
 fence-free hand-off to the workgroup that merges) -- every op that takes it for <= 8192 positions must give the bits of DVQ_MODE_EXACT
 (itself pinned to the oracle / the reference goldens elsewhere) and of the oracle directly, call after call on one workspace with
 fresh data (a stale slice entry would show as a wrong code), at every slice count (K decides how many slices a block gets)."""
