@@ -41,7 +41,7 @@ EXPORTS = (
     "dvq_fold_prep_bytes", "dvq_fold_prepare_f32", "dvq_vq_assign_fold_f32", "dvq_vq_assign_routed_fold_dual_f32",
     "dvq_vq_assign_routed_fold_triple_f32", "dvq_debug_fold_scores_f32",
     "dvq_entropy_gate_f32", "dvq_route_select_dual_f32", "dvq_route_select_dual_entropy_f32", "dvq_route_select_triple_f32",
-    "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_restart_pick_i64", "dvq_router_gate_workspace_bytes", "dvq_router_gate_prep_bytes", "dvq_router_gate_prepare_f32", "dvq_router_gate_prepare_norm_f32", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
+    "dvq_entropy_map_f32", "dvq_ema_accumulate_nchw_f32", "dvq_restart_pick_i64", "dvq_ema_update_f32", "dvq_router_gate_workspace_bytes", "dvq_router_gate_prep_bytes", "dvq_router_gate_prepare_f32", "dvq_router_gate_prepare_norm_f32", "dvq_router_gate_f32", "dvq_permute_dual_count_i64", "dvq_permute_dual_forward_i64", "dvq_permute_dual_backward_i64",
 )
 
 
@@ -157,6 +157,8 @@ def _load():
     lib.dvq_route_select_triple_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.dvq_ema_accumulate_nchw_f32.restype = i32
     lib.dvq_ema_accumulate_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.dvq_ema_update_f32.restype = i32
+    lib.dvq_ema_update_f32.argtypes = [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
     lib.dvq_restart_pick_i64.restype = i32
     lib.dvq_restart_pick_i64.argtypes = [ctypes.c_uint64, i64, i32, vp, vp]
     lib.dvq_router_gate_workspace_bytes.restype = sz

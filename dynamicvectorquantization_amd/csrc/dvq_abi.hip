@@ -70,6 +70,9 @@ size_t dvq_router_gate_ws_bytes(int nb, int B, int C, int hc, int wc, int groups
 size_t dvq_router_gate_prep_bytes_impl(int nb, int C, int Hid);
 int dvq_launch_router_gate_prepare(const float *W1, int nb, int C, int Hid, void *prep, hipStream_t st);
 int dvq_launch_restart_pick(unsigned long long seed, long long n, int k, long long *out, hipStream_t st);
+int dvq_launch_ema_update(const float *stats_sum, const float *stats_count, float decay, float eps, int K, int D,
+                          const float *cs_old, float *cs_new, float *embed_ema, float *weight, int restart, const float *restart_rows,
+                          const float *z, int HW, const long long *pick, hipStream_t st);
 int dvq_launch_router_gate_prepare_norm(const float *const *gn_w, const float *const *gn_b, int nb, int C, int Hid, void *prep,
                                         hipStream_t st);
 int dvq_launch_router_gate(int nb, const float *const *h, const float *const *gn_w, const float *const *gn_b,
@@ -571,6 +574,20 @@ int dvq_restart_pick_i64(uint64_t seed, int64_t n, int k, int64_t *out, void *st
         dvq_set_error("dvq_restart_pick_i64: k=%d n=%lld (1 <= k <= 2048, 16 k <= n < 2^32)", k, (long long)n); return DVQ_EUNSUPPORTED;
     }
     return hip_rc(dvq_launch_restart_pick((unsigned long long)seed, (long long)n, k, (long long *)out, (hipStream_t)stream), "restart_pick");
+}
+
+int dvq_ema_update_f32(const float *stats_sum, const float *stats_count, float decay, float eps, int K, int D,
+                       const float *cluster_size_ema, float *cluster_size_out, float *embed_ema, float *weight,
+                       int restart, const float *restart_rows, const float *z, int B, int HW, const int64_t *pick, void *stream)
+{
+    if (!stats_sum || !stats_count || !cluster_size_ema || !cluster_size_out || !embed_ema || !weight) { dvq_set_error("dvq_ema_update_f32: null pointer"); return DVQ_EINVAL; }
+    if (K <= 0 || D <= 0) { dvq_set_error("dvq_ema_update_f32: sizes must be positive"); return DVQ_EINVAL; }
+    if (cluster_size_out == cluster_size_ema) { dvq_set_error("dvq_ema_update_f32: cluster_size_out must not alias cluster_size_ema (every workgroup sums the OLD counts)"); return DVQ_EINVAL; }
+    if (restart < 0 || restart > 2) { dvq_set_error("dvq_ema_update_f32: restart must be 0, 1 or 2"); return DVQ_EINVAL; }
+    if (restart == 1 && !restart_rows) { dvq_set_error("dvq_ema_update_f32: restart = 1 needs restart_rows"); return DVQ_EINVAL; }
+    if (restart == 2 && (!z || !pick || B <= 0 || HW <= 0)) { dvq_set_error("dvq_ema_update_f32: restart = 2 needs z [B, D, HW] and pick [K]"); return DVQ_EINVAL; }
+    return hip_rc(dvq_launch_ema_update(stats_sum, stats_count, decay, eps, K, D, cluster_size_ema, cluster_size_out, embed_ema, weight,
+                                        restart, restart_rows, z, HW, (const long long *)pick, (hipStream_t)stream), "ema_update");
 }
 
 size_t dvq_router_gate_workspace_bytes(int num_branches, int B, int C, int hc, int wc, int num_groups, int hidden)

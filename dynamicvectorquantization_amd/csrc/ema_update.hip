@@ -389,3 +389,69 @@ int dvq_launch_restart_pick(unsigned long long seed, long long n, int k, long lo
     hipLaunchKernelGGL(restart_pick_kernel, dim3(1), dim3(1024), shm, st, seed, n, k, hbits, out);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Everything of the training-mode codebook update AFTER the statistics, as one kernel (quantize2_mask.py:89-115): the two EMA
+// updates (`cluster_size_ema.mul_(decay).add_(..., alpha = 1 - decay)`, the same for `embed_ema`), the dead-code restart (codes
+// whose updated count fell below 1 take a restart vector and count 1) and `_update_embedding` (n = sum of the counts,
+// weight = embed_ema / (n (count + eps) / (n + K eps))).  As torch ops these were ~20 launches of 4-5 us on K x D = 1 MiB of data
+// -- 65 us of kernels and as much again in gaps per 0.8-ms training step (profiles/r05_train_step.json).
+// One wave per code row.  Every workgroup computes n itself from the OLD counts (4 KiB of reads): the new counts therefore go to a
+// separate array (`cluster_size_out`; the caller copies it over the buffer afterwards) -- written in place, a fast workgroup's
+// new count would enter a slow one's sum decayed twice.  embed_ema is updated in place (a row has one owner).
+// Restart rows: from `restart_rows` [K, D] (data-parallel runs broadcast rank 0's), or gathered here from the NCHW latents at
+// token index pick[j].  fp32 operation order as the reference's expressions; the sum n is accumulated in double (the reference's
+// fp32 tree differs by ~1e-7 relative: tolerance parity, 1e-5).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_update_kernel(const float *__restrict__ stats_sum, const float *__restrict__ stats_count,
+                                                         float decay, float alpha, float eps, int K, int D,
+                                                         const float *__restrict__ cs_old, float *__restrict__ cs_new,
+                                                         float *__restrict__ embed_ema, float *__restrict__ weight, int restart,
+                                                         const float *__restrict__ restart_rows, const float *__restrict__ z, int HW,
+                                                         const long long *__restrict__ pick)
+{
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto new_count = [&](int j, bool &dead) -> float {
+        const float c = __fadd_rn(__fmul_rn(cs_old[j], decay), __fmul_rn(alpha, stats_count[j]));
+        dead = restart != 0 && c < 1.0f;
+        return dead ? 1.0f : c;
+    };
+    double s = 0.0;
+    for (int j = tid; j < K; j += 256) { bool dd; s += (double)new_count(j, dd); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float n = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    const float denom = __fadd_rn(n, __fmul_rn((float)K, eps));
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= K) return;
+    bool dead;
+    const float c = new_count(j, dead);
+    if (lane == 0) cs_new[j] = c;
+    const float norm = __fmul_rn(n, __fadd_rn(c, eps)) / denom;
+    const float *rr = nullptr;
+    size_t rstride = 1;
+    if (dead) {
+        if (restart == 1) rr = restart_rows + (size_t)j * D;
+        else { const long long p = pick[j]; const long long b = p / HW; rr = z + ((size_t)b * D) * HW + (size_t)(p - b * HW); rstride = (size_t)HW; }
+    }
+    for (int ch = lane; ch < D; ch += 64) {
+        const size_t i = (size_t)j * D + ch;
+        float e = __fadd_rn(__fmul_rn(embed_ema[i], decay), __fmul_rn(alpha, stats_sum[i]));
+        if (dead) e = rr[(size_t)ch * rstride];
+        embed_ema[i] = e;
+        weight[i] = e / norm;
+    }
+}
+
+int dvq_launch_ema_update(const float *stats_sum, const float *stats_count, float decay, float eps, int K, int D,
+                          const float *cs_old, float *cs_new, float *embed_ema, float *weight, int restart, const float *restart_rows,
+                          const float *z, int HW, const long long *pick, hipStream_t st)
+{
+    const float alpha = (float)(1.0 - (double)decay);        // what `alpha = 1 - self.decay` (Python doubles) becomes as an fp32 scalar
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, stats_sum, stats_count, decay, alpha, eps, K,
+                       D, cs_old, cs_new, embed_ema, weight, restart, restart_rows, z, HW, pick);
+    return (int)hipGetLastError();
+}

@@ -760,6 +760,46 @@ class VQEmbedding(nn.Embedding):
             self._restart_dead_codes(vectors, self._draw_restart_vectors(vectors))
 
     @torch.no_grad()
+    def _ema_step(self, vectors, idxs, nchw=None):
+        """`_update_buffers` + `_update_embedding` (quantize2_mask.py:66-115) for NCHW latents on the GPU: the statistics kernel,
+        the (single) all-reduce, the restart pick, then ONE kernel for the two EMA updates, the dead-code restart and the
+        normalised weight (`dvq_ema_update_f32`; as torch ops ~20 launches of 4-5 us per step).  Anything else -- CPU tensors,
+        fewer input vectors than codes (the reference tiles them with noise), a replaced torch.randperm with too few vectors for
+        the pick kernel -- takes the two methods one after the other."""
+        n_embed, embed_dim = self.weight.shape[0] - 1, self.weight.shape[-1]
+        ok = (nchw is not None and nchw.is_cuda and nchw.dtype == torch.float32 and self.weight.is_cuda
+              and self.weight.dtype == torch.float32 and self.weight.is_contiguous()
+              and self.embed_ema.is_contiguous() and self.embed_ema.dtype == torch.float32)
+        n_vectors = idxs.numel()
+        if not ok or (self.restart_unused_codes and n_vectors < n_embed):
+            self._update_buffers(vectors, idxs, nchw=nchw)
+            self._update_embedding()
+            return
+        idxs = idxs.reshape(-1)
+        cluster_size, vectors_sum, flat = self._cluster_sums(vectors, idxs, nchw)
+        ddp = dist.is_available() and dist.is_initialized()
+        if ddp:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        z = nchw.contiguous()
+        B, HW = z.shape[0], z[0, 0].numel()
+        restart, rows, pick = 0, None, None
+        if self.restart_unused_codes:
+            pick = _restart_pick(n_vectors, n_embed, z.device).contiguous()
+            restart = 2
+            if ddp:                                          # every rank restarts from rank 0's vectors (quantize2_mask.py:100)
+                rows = vectors[torch.div(pick, HW, rounding_mode="floor"), pick % HW].contiguous()
+                dist.broadcast(rows, 0)
+                restart = 1
+        cs_new = torch.empty_like(self.cluster_size_ema)
+        with _lib.on_device(z.device):
+            _lib.check(_lib_handle.dvq_ema_update_f32(
+                vectors_sum.data_ptr(), cluster_size.data_ptr(), float(self.decay), float(self.eps), n_embed, embed_dim,
+                self.cluster_size_ema.data_ptr(), cs_new.data_ptr(), self.embed_ema.data_ptr(), self.weight.data_ptr(),
+                restart, _lib.ptr(rows), z.data_ptr(), B, HW, _lib.ptr(pick), _lib.stream_ptr(z.device)), "dvq_ema_update_f32")
+        self.cluster_size_ema.copy_(cs_new)
+        self._prep.invalidate()
+
+    @torch.no_grad()
     def _draw_restart_vectors(self, vectors):
         """n_embed input vectors in random order (tiled with noise if the batch has fewer), the same on
         every rank (quantize2_mask.py:93-100)"""
@@ -872,10 +912,10 @@ class VectorQuantize2(_CodebookOps, nn.Module):
             with torch.no_grad():
                 if self.accept_image_fmap or need_transpose:     # channel-major -> token rows (a view)
                     ztok = z.reshape(z.shape[0], z.shape[1], -1).permute(0, 2, 1)
-                    self.codebook._update_buffers(ztok, codes.reshape(-1), nchw=z.detach())
+                    self.codebook._ema_step(ztok, codes.reshape(-1), nchw=z.detach())
                 else:
                     self.codebook._update_buffers(z, codes.reshape(-1))
-                self.codebook._update_embedding()
+                    self.codebook._update_embedding()
         if self.accept_image_fmap or need_transpose:
             x_q = zq
             x_code = codes                               # [B, H, W] / [B, N]

@@ -28,7 +28,7 @@
  *     (quantize.py: _padded_width); divide the returned loss mean by D / D_padded.
  *
  * Versions (dvq_version() = 100 major + minor; re-query every *_bytes function after an upgrade: buffer sizes are part of a version)
- *   0.6.0  the conv-fused assigns (dvq_vq_assign_qconv_f32, dvq_vq_assign_routed_qconv_*_f32) take h_buf = NULL: no scratch tensor
+ *   0.6.0  dvq_ema_update_f32 (new); the conv-fused assigns (dvq_vq_assign_qconv_f32, dvq_vq_assign_routed_qconv_*_f32) take h_buf = NULL: no scratch tensor
  *          (0.3 - 0.5 required a full-size one); dvq_entropy_map_f32 refuses more than 2^30 patches per call; DVQ_MODE_WS_CLEAN's
  *          contract spelled out (valid for the same entry point and shape only).  No signature changed.
  *   0.5.0  DVQ_MODE_WS_CLEAN (self-cleaning workspace), dvq_vq_assign_flat_f32, dvq_restart_pick_i64,
@@ -365,6 +365,23 @@ DVQ_API int dvq_ema_accumulate_nchw_f32(const float *z, const int64_t *codes, in
  * them -- probability below 1e-100 for n >= 16 k -- a slot that stayed empty keeps its own index i, which may repeat a chosen one.)
  */
 DVQ_API int dvq_restart_pick_i64(uint64_t seed, int64_t n, int k, int64_t *out, void *stream);
+
+/*
+ * The rest of the training-mode codebook update as ONE kernel (quantize2_mask.py:89-115; ~20 small torch kernels in the reference):
+ *   cluster_size' = cluster_size_ema * decay + (1 - decay) * stats_count          (:89)
+ *   embed_ema     = embed_ema * decay + (1 - decay) * stats_sum                   (:90)
+ *   restart != 0: codes with cluster_size' < 1 take their restart row and count 1   (:102-105)
+ *   n = sum(cluster_size'); weight[j, :] = embed_ema[j, :] / (n * (cluster_size'[j] + eps) / (n + K * eps))   (:107-115)
+ * stats_sum [K, D] / stats_count [K]: this step's statistics (dvq_ema_accumulate_nchw_f32, all-reduced by the caller).
+ * cluster_size_ema [K] is READ, the new counts go to cluster_size_out [K] (must not alias: every workgroup sums the old counts;
+ * copy it over the buffer afterwards); embed_ema [K, D] is updated in place; weight: rows 0 .. K-1 of a [>= K, D] tensor are written.
+ * restart: 0 none; 1 rows from restart_rows [K, D] (data-parallel: rank 0's, broadcast by the caller); 2 rows gathered from the NCHW
+ * latents z [B, D, HW] at token index pick[j] in [0, B * HW) (dvq_restart_pick_i64).  fp32, the reference's operation order; the sum n is
+ * accumulated in double: equal to the reference within rounding (1e-5).
+ */
+DVQ_API int dvq_ema_update_f32(const float *stats_sum, const float *stats_count, float decay, float eps, int K, int D,
+                               const float *cluster_size_ema, float *cluster_size_out, float *embed_ema, float *weight,
+                               int restart, const float *restart_rows, const float *z, int B, int HW, const int64_t *pick, void *stream);
 
 /*
  * Fused feature-router gate (inference), the forward of DualGrainFeatureRouter

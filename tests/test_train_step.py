@@ -53,3 +53,47 @@ def test_ema_accumulate_vs_float64(dev):
     m2 = VectorQuantize2(K, D).to(dev).train()
     m2(z)
     assert torch.isfinite(m2.codebook.weight).all() and float(m2.codebook.cluster_size_ema.sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("restart", [0, 1, 2])
+def test_ema_update_kernel_against_the_reference_expressions(dev, restart):
+    """dvq_ema_update_f32 (round 6: the EMA updates, the dead-code restart and _update_embedding as one kernel) against the
+    reference's own expressions (quantize2_mask.py:89-115) as torch ops on the CPU: restart rows given (the data-parallel form:
+    rank 0's rows), gathered from the NCHW latents by token index, or no restart; counts chosen so that a third of the codes is dead"""
+    from dynamicvectorquantization_amd import _lib
+    K, D, B, HW = 96, 256, 3, 64
+    g = torch.Generator().manual_seed(11 + restart)
+    decay, eps = 0.99, 1e-5
+    cs = torch.rand(K, generator=g) * 3.0                     # EMA counts: a third below 1 after the update
+    emb = torch.randn(K, D, generator=g)
+    cnt = torch.randint(0, 5, (K,), generator=g).float()
+    vsum = torch.randn(K, D, generator=g) * cnt[:, None]
+    z = torch.randn(B, D, HW, generator=g)
+    pick = torch.randperm(B * HW, generator=g)[:K]
+    rows = z.permute(0, 2, 1).reshape(-1, D)[pick].contiguous()
+    # reference expressions
+    cs_r = cs.clone().mul_(decay).add_(cnt, alpha=1 - decay)
+    emb_r = emb.clone().mul_(decay).add_(vsum, alpha=1 - decay)
+    if restart:
+        dead = cs_r < 1
+        emb_r = torch.where(dead[:, None], rows, emb_r)
+        cs_r = cs_r.masked_fill(dead, 1.0)
+        assert 5 < int(dead.sum()) < K - 5
+    n = cs_r.sum()
+    w_r = emb_r / (n * (cs_r + eps) / (n + K * eps)).reshape(-1, 1)
+    t = lambda a: a.to(dev).contiguous()
+    cs_d, emb_d, w_d, out = t(cs), t(emb), torch.full((K + 1, D), 7.0, device=dev), torch.empty(K, device=dev)
+    vs_d, cn_d, z_d, pk_d, rw_d = t(vsum), t(cnt), t(z), t(pick), t(rows)
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib.dvq_ema_update_f32(vs_d.data_ptr(), cn_d.data_ptr(), decay, eps, K, D, cs_d.data_ptr(), out.data_ptr(),
+                                               emb_d.data_ptr(), w_d.data_ptr(), restart, rw_d.data_ptr() if restart == 1 else None,
+                                               z_d.data_ptr() if restart == 2 else None, B, HW, pk_d.data_ptr() if restart == 2 else None,
+                                               _lib.stream_ptr(dev)), "dvq_ema_update_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(cs_d.cpu(), cs)                          # the old counts are read, not written
+    assert torch.allclose(out.cpu(), cs_r, rtol=1e-6, atol=1e-7) and torch.allclose(emb_d.cpu(), emb_r, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(w_d[:K].cpu(), w_r, rtol=1e-5, atol=1e-6) and bool((w_d[K] == 7.0).all())     # the padding row is not touched
+    # argument checks: aliasing the count arrays is refused (every workgroup sums the OLD counts)
+    assert _lib.lib.dvq_ema_update_f32(vs_d.data_ptr(), cn_d.data_ptr(), decay, eps, K, D, cs_d.data_ptr(), cs_d.data_ptr(),
+                                       emb_d.data_ptr(), w_d.data_ptr(), 0, None, None, 0, 0, None, _lib.stream_ptr(dev)) == -1
