@@ -1,0 +1,19 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from dynamicvectorquantization_amd import synth
+from dynamicvectorquantization_amd.entropy import Entropy
+dev = torch.device("cuda:0")
+base = torch.from_numpy(synth.images_flat_noise(5000, 32)[0]).to(dev)
+pad = torch.empty(int(sys.argv[1]) if len(sys.argv) > 1 else 1, dtype=torch.uint8, device=dev)
+img = torch.cat([torch.roll(base, 16 * k, -1) for k in range(8)], 0).contiguous()
+ent = Entropy(16, 256, 256).to(dev)
+res = []
+for rep in range(4):
+    for _ in range(10): ent(img)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): ent(img)
+    e1.record(); torch.cuda.synchronize()
+    res.append(round(e0.elapsed_time(e1) * 10, 1))
+print(hex(img.data_ptr()), res)
