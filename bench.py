@@ -1309,7 +1309,12 @@ def run_rank(a):
         mode_c = a.configs if a.configs != "auto" else ("full" if a.batch is None else "small")
         del wl.slots[1:]
         torch.cuda.empty_cache()
-        configs = configs_block(dev, small=(mode_c == "small"))
+        try:
+            configs = configs_block(dev, small=(mode_c == "small"))
+        except Exception as ex:                                  # the headline line must survive a failure of the side measurements
+            import traceback
+            traceback.print_exc()
+            configs = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300]), "all_parity_ok": False}
     if rank == 0:
         par = ("one process per GPU, image-parallel x%d; per step ONE packed all-gather of codes / grain / loss pair (%s), "
                "async under the next batches" % (world, backend_name)) if xchs else "single GPU: no exchange runs"
