@@ -425,29 +425,29 @@ class WeakDual:
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_dual
         path = self.a.path
         if self.a.mode == "exact":
-            ev[0].record()
+            if ev: ev[0].record()
             vq_assign(o.h_dual if o.h_dual is not None else o.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT, out=(o.zq, o.codes, o.loss))
-            ev[1].record()
+            if ev: ev[1].record()
         elif path in ("select", "model2"):
             src = o.h_dual if path == "select" else o.h_full
-            ev[0].record()
+            if ev: ev[0].record()
             vq_assign(src, self.E, self.prep_dom, o.cmask, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                       out=(o.zq, o.codes, None))
-            ev[1].record()
+            if ev: ev[1].record()
         elif path in ("model", "tokens_model", "tokens_fold", "model_fold"):
-            ev[0].record()
+            if ev: ev[0].record()
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                                   out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate), conv=self.conv,
                                   fold=path in ("tokens_fold", "model_fold"))
-            ev[1].record()
+            if ev: ev[1].record()
         else:
-            ev[0].record()
+            if ev: ev[0].record()
             vq_assign_routed_dual(o.h_coarse, o.h_fine, self.E, self.prep_dom, entropy=o.ent,
                                   threshold=THR_R05, beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                                   out=(o.zq, o.codes, None, o.grain, o.cmask, o.gate))
-            ev[1].record()
+            if ev: ev[1].record()
 
     def dominant_tokens(self):
         """tokens one launch of `dominant` processes"""
@@ -654,7 +654,7 @@ class StrongTriple:
     def dominant(self, o, ev):
         from dynamicvectorquantization_amd import _lib
         from dynamicvectorquantization_amd.quantize import vq_assign, vq_assign_routed_triple
-        ev[0].record()
+        if ev: ev[0].record()
         if self.a.path == "select" or self.a.mode == "exact":
             vq_assign(o.h_triple if o.h_triple is not None else o.h_fine, self.E, self.prep_dom, o.cmask,
                       beta=0.25, mode=_lib.MODE_EXACT if self.a.mode == "exact" else _lib.MODE_FILTER_PASS1,
@@ -663,7 +663,7 @@ class StrongTriple:
             vq_assign_routed_triple(o.h_coarse, o.h_median, o.h_fine, self.E, self.prep_dom, o.logits,
                                     beta=0.25, mode=_lib.MODE_FILTER_PASS1,
                                     out=(o.zq, o.codes, None, o.grain, o.cmask))
-        ev[1].record()
+        if ev: ev[1].record()
 
     def dominant_tokens(self):
         return self.B * self.H * self.W
@@ -1265,7 +1265,38 @@ def run_rank(a):
             lw[1].clean = True
         wl.dominant(wl.slots[0], dom_ev[i] if i >= 0 else scratch)
     torch.cuda.synchronize()
-    dom_ms = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
+    dom_ms_bracketed = float(np.mean([s.elapsed_time(e) for s, e in dom_ev]))
+    dom_ms = dom_ms_bracketed
+    if a.mode == "filter":
+        # The same kernel BACK TO BACK: NP launches between ONE pair of events, each through a _CodebookPrep (workspace) of its
+        # own that was zeroed and declared clean in front of the bracket -- so the bracket holds NP pass-1 kernels and nothing
+        # else, and the event / first-launch latency (4-7 % of a single-launch bracket; rocprofv3's per-kernel duration has none)
+        # is amortised.  This is `roofline.kernel_ms`; the single-launch bracket stays beside it as `kernel_ms_bracketed`.
+        NP = 8
+        keep = wl.prep_dom
+        preps = [_CodebookPrep() for _ in range(NP)]
+
+        def zero_all():
+            for pp in preps:
+                lw = getattr(pp, "_last_ws", None)
+                if lw is not None and hasattr(lw[1], "clean"):
+                    lw[1].t[:min(lw[1].t.numel(), 4 << 20)].zero_()
+                    lw[1].clean = True
+        blocks = []
+        for r in range(-2, 12):
+            zero_all()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for pp in preps:
+                wl.prep_dom = pp
+                wl.dominant(wl.slots[0], None)
+            e1.record()
+            torch.cuda.synchronize()
+            if r >= 0:
+                blocks.append(e0.elapsed_time(e1) / NP)
+        wl.prep_dom = keep
+        del preps
+        dom_ms = float(np.median(blocks))
     N = wl.dominant_tokens()                                  # tokens per launch of the dominant kernel
     per_token = D * 4 + 8 + 4 + (D * 4 if a.path not in ("tokens", "tokens_model", "tokens_fold") else 0)   # z read + int64 code + mask (+ z_q write)
     alg_bytes = N * per_token + K * D * 4                     # codebook once per launch
@@ -1297,7 +1328,8 @@ def run_rank(a):
     else:
         roof = {"bound": "mfma", "achieved": tfs, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / FP32_MFMA_PEAK_TF, "traffic": traffic}
-    roof.update({"kernel": wl.dominant_kernel_name(), "kernel_ms": dom_ms, "kernel_ms_rocprof": rocprof_ms,
+    roof.update({"kernel": wl.dominant_kernel_name(), "kernel_ms": dom_ms, "kernel_ms_bracketed": dom_ms_bracketed,
+                 "kernel_ms_rocprof": rocprof_ms,
                  "serial_over_kernel": (serial_ms / dom_ms) if (serial_ms and dom_ms) else None,
                  "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops, "fp16_mfma_frac_of_2500": tfs / 2500.0,
                  "whole_op_ms": op_ms, "target_frac": 0.70, "target_met": bool(gbs / HBM_PEAK_GBS >= 0.70)})
