@@ -910,7 +910,7 @@ def configs_block(dev, small=False):
         st0["assign_op"] = _ev_ms(lambda: vqg(h0), nsteps)
         o0 = oracle.vq_assign_nchw(h0.cpu().numpy(), E_np, None)
         ol0 = float(oracle.vq_loss(o0["sqerr"], o0["numel"], 0.25))
-        out["cfg0"] = {"workload": "fixed-granularity VQModel.encode: 1x1 quant_conv -> VectorQuantizer2, B=4, 16x16x256, K=1024", "B": B0,
+        out["cfg0"] = {"workload": "VQModel.encode: quant_conv -> VectorQuantizer2, 16x16x256, K=1024", "B": B0,
                        "ms": ms0, "images_per_s": B0 / (ms0 * 1e-3), "stage_ms": st0, "share": {k: v / ms0 for k, v in st0.items()},
                        "frac": {"assign_op": (B0 * 256 * 2056 + K * D * 4) / (st0["assign_op"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                        "checked_images": B0, "code_mismatches": int((info0[2].cpu().numpy().reshape(B0, -1) != o0["codes"]).sum()),
@@ -920,7 +920,7 @@ def configs_block(dev, small=False):
     # configs[1]: DualGrainVQModel.encode with the feature router (dqvae_dual_feat.py:59-68), B = 64
     B1 = 8 if small else 64
     r2 = seeded(DualGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu"), 6102)
-    out["cfg1"] = routed("dual feature-router: fused gate -> select + quant_conv + assign (one op), K=1024", B1, B1,
+    out["cfg1"] = routed("dual feature router: gate -> select+quant_conv+assign (one op)", B1, B1,
                          (pre(base16, B1), pre(base32, B1)), router=r2)
     # configs[2]: DualGrainVQModel.encode with the entropy router (dqvae_dual_entropy.py:124-134): PIXELS -> Entropy -> gate -> ...
     B2 = 16 if small else 256
@@ -930,13 +930,13 @@ def configs_block(dev, small=False):
     ibase = torch.from_numpy(synth.images_flat_noise(5000, nimg)[0]).to(dev)     # (tiled by whole patches: the flat / noise mixture stays what it is)
     imgs = torch.cat([torch.roll(ibase, 16 * k, -1) for k in range((B2 + nimg - 1) // nimg)], 0)[:B2].contiguous()
     del ibase
-    out["cfg2"] = routed("dual entropy-router r05: pixels -> entropy map kernel -> gate + select + quant_conv + assign (one op), K=1024",
+    out["cfg2"] = routed("dual entropy router r05: pixels -> entropy map -> gate+select+quant_conv+assign (one op)",
                          B2, min(B2, 64), (pre(base16, B2), pre(base32, B2)), router=rent, images=imgs, no_conv_too=True)
     del imgs
     # configs[3]: TripleGrainVQModel.encode (dqvae_triple_feat.py:68-77): the whole batch on one GPU, and one rank's share of 8
     r3 = seeded(TripleGrainFeatureRouter(256, "group-32", "2layer-fc-SiLu"), 6104)
     for key, B3 in (("cfg3", 16 if small else 1024), ("cfg3_per_rank_of_8", 8 if small else 128)):
-        out[key] = routed("triple feature-router: fused gate -> select + quant_conv + assign (one op), K=1024", B3, min(B3, 32),
+        out[key] = routed("triple feature router: gate -> select+quant_conv+assign (one op)", B3, min(B3, 32),
                           (pre(base8, B3), pre(base16, B3), pre(base32, B3)), router=r3)
         torch.cuda.empty_cache()
     # configs[4]: K = 16384 stress, dense VectorQuantize2 assign: fp16-MFMA filter path vs the exact fp32-MFMA chain
@@ -953,8 +953,7 @@ def configs_block(dev, small=False):
         ns4 = min(B4, 8)
         oo = oracle.vq_assign_nchw(z4[:ns4].cpu().numpy(), E4_np, None)
         fl = 2.0 * K4 * D * B4 * 1024
-        out["cfg4"] = {"workload": "K=16384 stress: dense VectorQuantize2 assign, 32x32x256 latents; fp16-MFMA filter + exact resolution vs the "
-                                   "all-exact fp32-MFMA chain", "B": B4, "ms": tf, "images_per_s": B4 / (tf * 1e-3), "ms_exact_mode": te,
+        out["cfg4"] = {"workload": "K=16384 dense assign: fp16-MFMA filter + exact resolution vs all-exact fp32-MFMA chain", "B": B4, "ms": tf, "images_per_s": B4 / (tf * 1e-3), "ms_exact_mode": te,
                        "tflops_equiv": fl / (tf * 1e-3) / 1e12, "tflops_exact_mode": fl / (te * 1e-3) / 1e12,
                        "frac": {"filter_vs_fp16_mfma_2500": fl / (tf * 1e-3) / 1e12 / 2500.0,
                                 "exact_vs_fp32_mfma_157": fl / (te * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
@@ -962,6 +961,36 @@ def configs_block(dev, small=False):
                        "modes_bit_identical": bool(torch.equal(c_f, o4[1]) and torch.equal(zq_f, o4[0])),
                        "checked_images": ns4, "code_mismatches": int((c_f[:ns4].cpu().numpy().reshape(ns4, -1) != oo["codes"]).sum()),
                        "mismatches": {"zq": int((zq_f[:ns4].cpu().numpy() != oo["zq"]).sum())}}
+    torch.cuda.empty_cache()
+    # SURVEY 8f rows that no config's encode reaches: the permuter (f1) and the training-mode quantizer (f2), timed at configs[2]'s size
+    try:
+        from dynamicvectorquantization_amd.permuter import DualGrainSeperatePermuter
+        Bn = 16 if small else 256
+        perm = DualGrainSeperatePermuter(coarse_hw=16, fine_hw=32, content_pad_code=K, content_eos_code=K + 1)
+        codes_p = torch.randint(0, K, (Bn, 16, 16), device=dev).repeat_interleave(2, 1).repeat_interleave(2, 2).contiguous()
+        grain_p = torch.from_numpy(synth.grain_gate_dual(4002, Bn, 16, 16).argmax(-1)).to(dev)
+        with torch.no_grad():
+            t_perm = _ev_ms(lambda: perm(codes_p, grain_p, max_len=perm.max_lengths()), nsteps)
+        vqt = VectorQuantize2(K, D).to(dev).train()
+        with torch.no_grad():
+            vqt.codebook.weight[:-1].copy_(E)
+            vqt.codebook.embed_ema.copy_(E)
+            vqt.codebook.cluster_size_ema.fill_(10.0)
+        xt = tile_images(torch.from_numpy(base32).to(dev), Bn).requires_grad_(True)
+        mt = torch.ones((Bn, 1, 32, 32), device=dev)
+        gq = torch.full_like(xt, 1e-6)
+
+        def train_step():
+            q, loss, _ = vqt(xt, codebook_mask=mt)
+            torch.autograd.backward([q, loss], [gq, torch.ones_like(loss)])
+            xt.grad = None
+        t_train = _ev_ms(train_step, 10 if small else 50, warm=5)
+        # f1: DualGrainSeperatePermuter.forward (no host sync); f2: VectorQuantize2 in training mode (assign + EMA statistics + restart +
+        # codebook update) and its backward
+        out["next_rows"] = {"B": Bn, "permuter_forward_ms": t_perm, "train_forward_backward_ms": t_train}
+        del vqt, xt, mt, gq
+    except Exception as ex:                                      # side measurement: never fatal
+        out["next_rows"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     torch.cuda.empty_cache()
 
     def rnd(v):

@@ -60,6 +60,7 @@ def test_default_bench_reports_the_model_order_too():
     assert c["cfg2"]["entropy_max_abs_err"] <= 1e-5 and set(c["cfg2"]["stage_ms"]) == {"entropy_map", "assign_op", "pass1"}
     assert set(c["cfg1"]["stage_ms"]) == {"router_gate", "assign_op", "pass1"} and c["cfg1"]["loss_rel_err"] <= 1e-5
     assert c["cfg4"]["modes_bit_identical"] is True
+    assert c["next_rows"]["permuter_forward_ms"] > 0 and c["next_rows"]["train_forward_backward_ms"] > 0, c["next_rows"]
     # the pre-flight record of a single-GPU run
     cfg = d["config"]
     assert cfg["world"] == 1 and cfg["distinct_devices"] == 1 and cfg["backend"] is None and len(cfg["ranks"]) == 1
