@@ -173,44 +173,56 @@ __global__ __launch_bounds__(256) void ema_zero_kernel(float *__restrict__ a, si
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same statistics with a BIG tile (round 5): 1024 tokens x 32 channels per workgroup, the tile in LDS (128 KiB: one workgroup per
-// CU), the tokens of the tile chained by code (LDS atomicExch on a [K] head table), one float-atomic row per (code PRESENT in the
-// tile, 32 channels).  The kernel above is bound by the L2 float-atomic rate (67 M adds at B = 256 = 308 us: 0.87 TB/s of the guide's
-// 1.3 TB/s for 256-byte contiguous adds) and a 64-token tile has nothing to combine when the codes are spread (62 distinct codes of
-// 64); 1024 tokens hold K (1 - e^-1) = 647 distinct codes of K = 1024, so 37 % of the adds disappear -- more with the 2 x 2 / 4 x 4
-// copies of coarse cells and a skewed codebook.  Needs HW % 4 == 0 (16-byte loads along the tokens), D % 32 == 0, K <= 4096.
+// The same statistics with a BIG tile whose tokens are SORTED by code (N >= 65 536 tokens, K <= 4096, HW % 4 == 0, D % 16 == 0).
+// The kernel above is bound by the L2 float-atomic rate (67 M adds at B = 256 = 308 us) and a 64-token tile has nothing to combine
+// when the codes are spread.  Round 5 took 1024 tokens x 32 channels (128 KiB of LDS, one 16-wave workgroup per CU) with the tile's
+// tokens chained by code (LDS atomicExch on a head table): 647 distinct codes of K = 1024 per tile, 37 % fewer adds, 205 us.
+// Round 6: 2048 tokens x 16 channels (the same 128 KiB): 885 distinct codes -- 57 % of the adds disappear -- and a (code, 16
+// channels) row of atomics is one full 64-byte request.  With linked chains that shape ran 192 -> 127 us on uniform codes but
+// 208 -> 311 us with 10 % of the tokens on one code (a 205-link chain is 205 dependent LDS round trips on ONE lane group while the
+// workgroup waits), so the tile's tokens are counting-sorted by code in LDS instead (count with a returning LDS atomic = rank inside
+// the code, exclusive scan over the K counts, scatter), once per token block and reused by the slices a workgroup walks of it: a
+// code's tokens are a contiguous index range, read four at a time (two LDS round trips per four tokens), and a code with more than
+// EMS_LONG tokens in the tile is summed by ALL lane groups and added up in LDS -- ONE row of atomics per (hot code, item).
+// Measured, B = 256, K = 1024 (tools/ema_time.py, same box; round-5 kernel -> this one): uniform codes 194 -> 126 us, dual-grain
+// codes 168 -> 127, 10 % of the tokens on one code 209 -> 123, 50 % 664 -> 117, one code for everything 1230 -> 77.
 // ---------------------------------------------------------------------------------------------
-#ifndef EMA_BIG
-#define EMA_BIG 1                // 0: the 64-token kernel everywhere (A/B)
-#endif
-#define EMA_BT 1024              // tokens per tile
-#define EMA_BC 32                // channels per tile
-#define EMA_BSTR (EMA_BT + 4)    // floats per channel row in LDS
-#ifndef EMA_BTHREADS
-#define EMA_BTHREADS 1024         // 16 waves: the chain walk below is a chain of dependent LDS reads, it lives on waves in flight
-#endif
-__global__ __launch_bounds__(EMA_BTHREADS) void ema_accumulate_big_kernel(const float *__restrict__ z, const long long *__restrict__ codes,
-                                                                 int D, int HW, long N, int K, float *__restrict__ cluster_size,
-                                                                 float *__restrict__ vectors_sum)
+#define EMS_BT 2048
+#define EMS_BC 16
+#define EMS_STR (EMS_BT + 4)
+static_assert(EMS_BC == 16 && EMS_BT % 256 == 0 && EMS_BT * EMS_BC == 32768, "the walk's lane mapping (four 16-channel groups per wave) and the 128 load pieces assume this tile");
+#define EMS_LONG 128             // a code with more tokens than this in a tile is summed by ALL lane groups, 32 tokens each
+__global__ __launch_bounds__(1024) void ema_accumulate_sorted_kernel(const float *__restrict__ z, const long long *__restrict__ codes,
+                                                                    int D, int HW, long N, int K, float *__restrict__ cluster_size,
+                                                                    float *__restrict__ vectors_sum)
 {
-    constexpr int NT = EMA_BTHREADS, NWV = NT / 64, PPW = 128 / NWV;     // 128 wave-pieces of the tile, PPW per wave
+    constexpr int NT = 1024, NWV = NT / 64, PPW = 128 / NWV, PPC = EMS_BT / 256, CPI = 64 / EMS_BC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *tile = (float *)smem;                                         // [EMA_BC][EMA_BSTR]
-    short *nxt = (short *)(smem + (size_t)EMA_BC * EMA_BSTR * 4);        // [EMA_BT] next token of the same code, -1 = end
-    int *head = (int *)((char *)nxt + EMA_BT * 2);                       // [K] last token of the tile with this code, -1 = none
+    float *tile = (float *)smem;                                         // [EMS_BC][EMS_STR]
+    short *order = (short *)(smem + (size_t)EMS_BC * EMS_STR * 4);       // [EMS_BT] the tile's tokens, by code
+    short *rank = order + EMS_BT;                                        // [EMS_BT] rank of a token among the tile's tokens of its code
+    short *code_s = rank + EMS_BT;                                       // [EMS_BT] code, -1 = none
+    int *start = (int *)(code_s + EMS_BT);                               // [K + 1] counts, then offsets into order[]
+    __shared__ int wtot[NWV];
+    __shared__ int nlong, longk[EMS_BT / EMS_LONG];                      // codes with more than EMS_LONG tokens in the tile
+    __shared__ float red[NWV * EMS_BC];                                  // their per-wave partial sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // persistent: a workgroup walks items (token block, 32-channel slice) with stride gridDim.x, and the NEXT item's tile is on
-    // its way into registers while this item's chains are walked (one workgroup per CU: nobody else would hide the loads)
-    const int nslice = D / EMA_BC;
-    const long nitems = ((N + EMA_BT - 1) / EMA_BT) * nslice;
+    const int nslice = D / EMS_BC;
+    const long nitems = ((N + EMS_BT - 1) / EMS_BT) * nslice;            // item = (token block, 16-channel slice), token-block major
+    const long per = (nitems + gridDim.x - 1) / gridDim.x;
+    const long item0 = (long)blockIdx.x * per, item1 = item0 + per < nitems ? item0 + per : nitems;
     f32x4 v[PPW];
+    // the slices of a token block in an order rotated by the block's index (a bijection per block, so the workgroups that share a
+    // block still cover disjoint slices): workgroups walk their blocks in step, and without the rotation every one of them would
+    // be adding into the SAME 16 channels of the code rows at the same time (atomics on one address serialise)
+    auto slice_of = [&](long item) -> int { return (int)((item % nslice + 5 * (item / nslice)) % nslice); };
     auto fetch = [&](long item) {
-        const long tok0 = (item / nslice) * EMA_BT;
-        const int c0 = (int)(item % nslice) * EMA_BC;
+        const long tok0 = (item / nslice) * EMS_BT;
+        const int c0 = slice_of(item) * EMS_BC;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int q = wave * PPW + i;                                // piece: channel q / 4, tokens (q % 4) * 256 + 4 lane ..
-            const int ch = q >> 2, t4 = (q & 3) * 256 + 4 * lane;
+            const int q = wave * PPW + i;                                // piece: channel q / PPC, tokens (q % PPC) * 256 + 4 lane ..
+            const int ch = q / PPC, t4 = (q % PPC) * 256 + 4 * lane;
             long n = tok0 + t4;
             n = n < N ? n : (N - 4 > 0 ? N - 4 : 0);                     // (HW % 4 == 0: N is a multiple of 4)
             const long b = n / HW;
@@ -218,60 +230,135 @@ __global__ __launch_bounds__(EMA_BTHREADS) void ema_accumulate_big_kernel(const 
             v[i] = __builtin_nontemporal_load((const f32x4 *)(z + ((size_t)b * D + c0 + ch) * HW + hw));
         }
     };
-    long item = blockIdx.x;
-    if (item < nitems) fetch(item);
-    for (; item < nitems; item += gridDim.x) {
-        const long tok0 = (item / nslice) * EMA_BT;
-        const int c0 = (int)(item % nslice) * EMA_BC;
-        for (int i = tid; i < K; i += NT) head[i] = -1;
-        __syncthreads();                                                 // head[] is initialised (and the previous item's walk is over)
-        for (int t = tid; t < EMA_BT; t += NT) {
-            const long n = tok0 + t;
-            const long long cj = (n < N) ? codes[n] : -1;
-            short nx = (short)-2;                                        // not in any chain
-            if (cj >= 0 && cj < K) nx = (short)atomicExch(&head[(int)cj], t);
-            nxt[t] = nx;
+    if (item0 < item1) fetch(item0);
+    long sorted_tb = -1;
+    for (long item = item0; item < item1; ++item) {
+        const long tb = item / nslice;
+        const long tok0 = tb * EMS_BT;
+        const int c0 = slice_of(item) * EMS_BC;
+        if (tb != sorted_tb) {                                           // (the previous item's walk ended with a barrier)
+            for (int i = tid; i <= K; i += NT) start[i] = 0;
+            if (tid == 0) nlong = 0;
+            __syncthreads();
+            for (int t = tid; t < EMS_BT; t += NT) {
+                const long n = tok0 + t;
+                const long long cj = (n < N) ? codes[n] : -1;
+                const bool ok = cj >= 0 && cj < K;
+                code_s[t] = ok ? (short)cj : (short)-1;
+                rank[t] = ok ? (short)atomicAdd(&start[(int)cj], 1) : (short)0;
+            }
+            __syncthreads();
+            // exclusive scan of the K counts in place (a thread owns four consecutive entries); start[K] = the tile's valid tokens
+            {
+                int a[4], tot = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * tid + j;
+                    a[j] = k < K ? start[k] : 0;
+                    tot += a[j];
+                    if (a[j] > EMS_LONG) longk[atomicAdd(&nlong, 1)] = k;     // (at most EMS_BT / EMS_LONG of them)
+                }
+                int inc = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+                if (lane == 63) wtot[wave] = inc;
+                __syncthreads();
+                int base = inc - tot;
+                for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int k = 4 * tid + j; if (k < K) start[k] = base; base += a[j]; }
+                if (tid == NT - 1) start[K] = base;                      // (4 * 1024 >= K: the last thread's running sum is the total)
+            }
+            __syncthreads();
+            for (int t = tid; t < EMS_BT; t += NT) {
+                const int c = code_s[t];
+                if (c >= 0) order[start[c] + rank[t]] = (short)t;
+            }
+            sorted_tb = tb;
         }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int q = wave * PPW + i;
-            const int ch = q >> 2, t4 = (q & 3) * 256 + 4 * lane;
-            *(f32x4 *)(tile + ch * EMA_BSTR + t4) = v[i];
+            const int ch = q / PPC, t4 = (q % PPC) * 256 + 4 * lane;
+            *(f32x4 *)(tile + ch * EMS_STR + t4) = v[i];
         }
-        __syncthreads();
-        if (item + gridDim.x < nitems) fetch(item + gridDim.x);
-        // one (code, channel) per lane: 2 codes x 32 channels per wave-instruction; walk the code's chain, ONE atomic per present
-        // code.  Four codes per lane at a time: the walks are chains of dependent LDS reads (head -> value, next -> ...),
-        // interleaved they overlap each other's latency.
-        const int ch = lane & 31, hsel = lane >> 5;
-        const float *row = tile + ch * EMA_BSTR;
-        constexpr int STEP = 2 * NWV;
-        const bool count_here = (item % nslice) == 0;
-        for (int k0 = 2 * wave + hsel; k0 < K; k0 += 4 * STEP) {
-            int t[4], cnt[4];
+        __syncthreads();                                                 // tile and order[] are complete
+        if (item + 1 < item1) fetch(item + 1);                           // the next tile is on its way while this one is walked
+        // lane = (code of the instruction's four, channel); four instructions' codes per lane at a time (independent LDS loads)
+        const int ch = lane % EMS_BC, hsel = lane / EMS_BC;
+        const float *row = tile + ch * EMS_STR;
+        constexpr int STEP = CPI * NWV;
+        const bool count_here = c0 == 0;
+        for (int k0 = CPI * wave + hsel; k0 < K; k0 += 4 * STEP) {
+            int s[4], e[4], n0[4];
             float sum[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + u * STEP;
-                t[u] = k < K ? head[k] : -1;
+                s[u] = k < K ? start[k] : 0;
+                e[u] = k < K ? start[k + 1] : 0;
+                n0[u] = e[u] - s[u];
+                if (n0[u] > EMS_LONG) { e[u] = s[u]; n0[u] = 0; }     // a long run: everybody's work, below
                 sum[u] = 0.0f;
-                cnt[u] = 0;
             }
-            while (t[0] >= 0 || t[1] >= 0 || t[2] >= 0 || t[3] >= 0) {
+            // four tokens of a code per step: their four index reads are independent of each other, and so are the four value reads
+            // behind them (two LDS round trips per four tokens, however long the run)
+            while (s[0] < e[0] || s[1] < e[1] || s[2] < e[2] || s[3] < e[3]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (t[u] >= 0) { sum[u] += row[t[u]]; t[u] = nxt[t[u]]; ++cnt[u]; }
+                    if (s[u] < e[u]) {
+                        const int last = e[u] - 1;
+                        const int i1 = s[u] + 1 < last ? s[u] + 1 : last, i2 = s[u] + 2 < last ? s[u] + 2 : last,
+                                  i3 = s[u] + 3 < last ? s[u] + 3 : last;
+                        const int t0 = order[s[u]], t1 = order[i1], t2 = order[i2], t3 = order[i3];
+                        const float r0 = row[t0], r1 = row[t1], r2 = row[t2], r3 = row[t3];
+                        const int left = e[u] - s[u];
+                        sum[u] += (r0 + (left > 1 ? r1 : 0.0f)) + ((left > 2 ? r2 : 0.0f) + (left > 3 ? r3 : 0.0f));
+                        s[u] += 4;
+                    }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + u * STEP;
-                if (cnt[u] > 0) {
+                if (n0[u] > 0) {
                     atomicAdd(&vectors_sum[(size_t)k * D + c0 + ch], sum[u]);
-                    if (count_here && ch == 0) atomicAdd(&cluster_size[k], (float)cnt[u]);
+                    if (count_here && ch == 0) atomicAdd(&cluster_size[k], (float)n0[u]);
                 }
             }
         }
-        __syncthreads();                                                 // tile / head / nxt are free for the next item
+        // the long runs (a hot code of a collapsing codebook: more than EMS_LONG of the tile's 2048 tokens): every lane group sums 32-token
+        // pieces of the run, the workgroup adds the pieces up in LDS, ONE row of atomics per (code, item) -- atomics on one address
+        // serialise at the memory side, and with a hot code every workgroup of the launch is adding into the same row
+        const int nl = nlong;
+        for (int li = 0; li < nl; ++li) {
+            const int k = longk[li];
+            const int s0 = start[k], e0 = start[k + 1];
+            float sm = 0.0f;
+            for (int p0 = s0 + 32 * (CPI * wave + hsel); p0 < e0; p0 += 32 * CPI * NWV) {
+                const int p1 = p0 + 32 < e0 ? p0 + 32 : e0;
+                for (int i = p0; i < p1; i += 4) {
+                    const int last = p1 - 1;
+                    const int i1 = i + 1 < last ? i + 1 : last, i2 = i + 2 < last ? i + 2 : last, i3 = i + 3 < last ? i + 3 : last;
+                    const int t0 = order[i], t1 = order[i1], t2 = order[i2], t3 = order[i3];
+                    const float r0 = row[t0], r1 = row[t1], r2 = row[t2], r3 = row[t3];
+                    const int left = p1 - i;
+                    sm += (r0 + (left > 1 ? r1 : 0.0f)) + ((left > 2 ? r2 : 0.0f) + (left > 3 ? r3 : 0.0f));
+                }
+            }
+            sm += __shfl_xor(sm, 16);                                    // the wave's four lane groups (EMS_BC = 16 channels each)
+            sm += __shfl_xor(sm, 32);
+            if (lane < EMS_BC) red[wave * EMS_BC + lane] = sm;
+            __syncthreads();
+            if (tid < EMS_BC) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) t += red[w * EMS_BC + tid];
+                atomicAdd(&vectors_sum[(size_t)k * D + c0 + tid], t);
+                if (count_here && tid == 0) atomicAdd(&cluster_size[k], (float)(e0 - s0));
+            }
+            __syncthreads();                                             // red[] is free again
+        }
+        __syncthreads();                                                 // tile / order / start are free for the next item
     }
 }
 
@@ -286,17 +373,17 @@ int dvq_launch_ema_accumulate(const float *z, const long long *codes, int D, int
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(ema_zero_kernel, dim3(blocks), dim3(256), 0, st, cluster_size, (size_t)K, vectors_sum, n);
     }
-    if (K <= 4096 && (HW & 3) == 0 && (D & 31) == 0 && N >= 64 * EMA_BT && EMA_BIG) {
-        static unsigned long long done = 0;
-        const size_t shm = (size_t)EMA_BC * EMA_BSTR * 4 + EMA_BT * 2 + (size_t)K * 4;
-        int rc = dvq_allow_dynamic_lds((const void *)ema_accumulate_big_kernel, (int)shm, &done);
+    if (K <= 4096 && (HW & 3) == 0 && (D & 15) == 0 && N >= 32 * EMS_BT) {
+        static unsigned long long done_s = 0;
+        const size_t shm = (size_t)EMS_BC * EMS_STR * 4 + (size_t)EMS_BT * 6 + ((size_t)K + 1) * 4;
+        int rc = dvq_allow_dynamic_lds((const void *)ema_accumulate_sorted_kernel, (int)shm, &done_s);
         if (rc) return rc;
         int ncu = 256, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        const long nitems = ((N + EMA_BT - 1) / EMA_BT) * (D / EMA_BC);
+        const long nitems = ((N + EMS_BT - 1) / EMS_BT) * (D / EMS_BC);
         const unsigned grid = (unsigned)(nitems < ncu ? nitems : (ncu > 0 ? ncu : 256));
-        hipLaunchKernelGGL(ema_accumulate_big_kernel, dim3(grid), dim3(EMA_BTHREADS), shm, st, z,
-                           codes, D, HW, N, K, cluster_size, vectors_sum);
+        hipLaunchKernelGGL(ema_accumulate_sorted_kernel, dim3(grid), dim3(1024), shm, st, z, codes, D, HW, N, K, cluster_size,
+                           vectors_sum);
     } else if (K <= 8192)
         hipLaunchKernelGGL(ema_accumulate_kernel<true>, dim3((unsigned)((N + 63) / 64)), dim3(256), (size_t)K * sizeof(int), st, z,
                            codes, D, HW, N, K, cluster_size, vectors_sum);
