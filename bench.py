@@ -984,10 +984,13 @@ def configs_block(dev, small=False):
             q, loss, _ = vqt(xt, codebook_mask=mt)
             torch.autograd.backward([q, loss], [gq, torch.ones_like(loss)])
             xt.grad = None
-        t_train = _ev_ms(train_step, 10 if small else 50, warm=5)
+        # median of three blocks: a block that meets an allocator miss or a clock dip reads 15-20 % high (seen once in four runs)
+        t_blocks = sorted(_ev_ms(train_step, 10 if small else 30, warm=5) for _ in range(3))
+        t_train = t_blocks[1]
         # f1: DualGrainSeperatePermuter.forward (no host sync); f2: VectorQuantize2 in training mode (assign + EMA statistics + restart +
         # codebook update) and its backward
-        out["next_rows"] = {"B": Bn, "permuter_forward_ms": t_perm, "train_forward_backward_ms": t_train}
+        out["next_rows"] = {"B": Bn, "permuter_forward_ms": t_perm, "train_forward_backward_ms": t_train,
+                            "train_forward_backward_ms_blocks": t_blocks}
         del vqt, xt, mt, gq
     except Exception as ex:                                      # side measurement: never fatal
         out["next_rows"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}

@@ -396,55 +396,112 @@ __global__ void vq_loss_finalize_kernel(const double *__restrict__ partials, int
 // ---------------------------------------------------------------------------------------------
 // codebook prep: f32 tile images + exact-order norms
 // ---------------------------------------------------------------------------------------------
-__global__ void codebook_prep_f32_kernel(const float *__restrict__ E, int K, int D,
-                                         float *__restrict__ tiles, float *__restrict__ en_all)
+// One workgroup per CPW codes of a tile (8: a K = 1024 codebook is 128 workgroups; 32 from 256 tiles on).  A thread owns octets of
+// channels of one code: coalesced row reads, 32-byte image stores.  The squared norms keep the ATen order of the oracle
+// (oracle/dvq_oracle.c: dvq_oracle_sumsq): 32 accumulators a[m] = sum over k0 of e[k0 + m]^2 in k0 order, then
+// ((a[l] + a[l+8]) + a[l+16]) + a[l+24] summed over l = 0..7 in order -- through LDS, one (code, m) pair per thread.
+// Round 6: the scan the fp16 section needs (max |e|, max norm, finiteness: codebook_meta_partial_kernel until now, a second pass
+// over the codebook) rides along: a workgroup parks (max |e|, max en, bad, 0) in the tile's 32 floats of padding, slot
+// 32 D + 32 + 4 * (workgroup within the tile); no kernel reads the padding of the image.  The prep is rebuilt at every training step.
+template <int CPW>
+__global__ __launch_bounds__(256) void codebook_prep_f32_kernel(const float *__restrict__ E, int K, int D,
+                                                                float *__restrict__ tiles, float *__restrict__ en_all,
+                                                                float *__restrict__ etamax)
 {
-    const int T = dvq_num_tiles(K);
-    const size_t tile_floats = dvq_tile_floats(D);
-    const size_t total = (size_t)T * tile_floats;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        int t = (int)(i / tile_floats);
-        int r = (int)(i - (size_t)t * tile_floats);
-        float v = 0.0f;
-        if (r < 32 * D) {
-            int kg = r / 256, c = (r >> 3) & 31, p = r & 7;
-            int k = kg * 8 + 2 * (p & 3) + (p >> 2);
-            int code = t * 32 + c;
-            if (code < K) v = E[(size_t)code * D + k];
-        } else if (r < 32 * D + 32) {
-            int code = t * 32 + (r - 32 * D);
-            if (code < K) {
-                // ATen-order sum of squares (oracle/dvq_oracle.c: dvq_oracle_sumsq)
-                const float *e = E + (size_t)code * D;
-                float a[32];
-                for (int m = 0; m < 32; ++m) a[m] = 0.0f;
-                for (int k0 = 0; k0 < D; k0 += 32)
-                    for (int m = 0; m < 32; ++m) a[m] = __fadd_rn(a[m], sq_rn(e[k0 + m]));
-                float s = 0.0f;
-                for (int l = 0; l < 8; ++l) {
-                    float tl = __fadd_rn(__fadd_rn(__fadd_rn(a[l], a[l + 8]), a[l + 16]), a[l + 24]);
-                    s = (l == 0) ? tl : __fadd_rn(s, tl);
-                }
-                v = s;
-            }
-            en_all[t * 32 + (r - 32 * D)] = v;
+    extern __shared__ float sq[];                            // [CPW][D] squares, then [CPW][32] partial sums
+    __shared__ float s_amax[4];
+    __shared__ int s_bad[4];
+    constexpr int SUBS = 32 / CPW;
+    const int t = blockIdx.x / SUBS, sub = blockIdx.x % SUBS, tid = threadIdx.x;
+    float *tile = tiles + (size_t)t * dvq_tile_floats(D);
+    const int KG = D / 8;
+    float amax = 0.0f;
+    int bad = 0;
+    if (blockIdx.x == 0 && tid == 0) *etamax = 0.0f;         // the fp16 section's residual bound: raised by codebook_prep_f16_kernel
+    for (int u = tid; u < CPW * KG; u += 256) {
+        const int cl = u / KG, kg = u - cl * KG, c = sub * CPW + cl;
+        const int code = t * 32 + c;
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (code < K) ? E[(size_t)code * D + 8 * kg + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float av = fabsf(e[j]);
+            bad |= !(av < __builtin_inff());
+            amax = fmaxf(amax, av);
+            sq[cl * D + 8 * kg + j] = sq_rn(e[j]);
         }
-        tiles[i] = v;
+        const f32x4 o0 = {e[0], e[2], e[4], e[6]}, o1 = {e[1], e[3], e[5], e[7]};     // p -> k = 8 kg + 2 (p & 3) + (p >> 2)
+        *(f32x4 *)(tile + kg * 256 + c * 8) = o0;
+        *(f32x4 *)(tile + kg * 256 + c * 8 + 4) = o1;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+        bad |= __shfl_xor(bad, off);
+    }
+    if ((tid & 63) == 0) { s_amax[tid >> 6] = amax; s_bad[tid >> 6] = bad; }
+    __syncthreads();
+    float a4[(CPW * 32 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (CPW * 32 + 255) / 256; ++i) {
+        const int pr = tid + 256 * i, cl = pr >> 5, m = pr & 31;
+        float a = 0.0f;
+        if (cl < CPW)
+            for (int k0 = 0; k0 < D; k0 += 32) a = __fadd_rn(a, sq[cl * D + k0 + m]);
+        a4[i] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (CPW * 32 + 255) / 256; ++i)
+        if (tid + 256 * i < CPW * 32) sq[tid + 256 * i] = a4[i];
+    __syncthreads();
+    if (tid < 64) {                                          // wave 0: lane cl < CPW finishes a code; then the workgroup's partial maxima
+        float v = 0.0f;
+        int wbad = 0;
+        if (tid < CPW) {
+            const float *a = sq + tid * 32;
+            float sum = 0.0f;
+            for (int l = 0; l < 8; ++l) {
+                const float tl = __fadd_rn(__fadd_rn(__fadd_rn(a[l], a[l + 8]), a[l + 16]), a[l + 24]);
+                sum = (l == 0) ? tl : __fadd_rn(sum, tl);
+            }
+            const int c = sub * CPW + tid, code = t * 32 + c;
+            v = (code < K) ? sum : 0.0f;
+            tile[32 * D + c] = v;
+            en_all[t * 32 + c] = v;
+            wbad = (code < K) && !(v < __builtin_inff());
+        }
+        float enmax = v;                                     // (a NaN norm: fmaxf drops it, the flag keeps it)
+        for (int off = 32; off > 0; off >>= 1) {
+            enmax = fmaxf(enmax, __shfl_xor(enmax, off));
+            wbad |= __shfl_xor(wbad, off);
+        }
+        if (tid == 0) {
+            const f32x4 part = {fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3])), enmax,
+                                (wbad | s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) ? 1.0f : 0.0f, 0.0f};
+            *(f32x4 *)(tile + 32 * D + 32 + 4 * sub) = part;
+        }
+        if (sub == 0 && tid >= 4 * SUBS && tid < 32) tile[32 * D + 32 + tid] = 0.0f;      // the rest of the padding
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host launchers (called from dvq_abi.hip)
 // ---------------------------------------------------------------------------------------------
+int dvq_prep_codes_per_workgroup(int K) { return dvq_num_tiles(K) >= 256 ? 32 : 8; }
+
 int dvq_launch_prep_f32(const float *E, int K, int D, void *prep, hipStream_t st)
 {
     float *tiles = (float *)prep;
     float *en_all = (float *)((char *)prep + dvq_prep_en_offset(K, D));
-    size_t total = (size_t)dvq_num_tiles(K) * dvq_tile_floats(D);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(codebook_prep_f32_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, tiles, en_all);
+    char *f16 = (char *)prep + dvq_prep_f16_offset(K, D);
+    f16 = (char *)(((uintptr_t)f16 + 255) / 256 * 256);
+    float *etamax = (float *)(f16 + 20);                     // DvqF16Meta::etamax (dvq_filter.h)
+    const int T = dvq_num_tiles(K);
+    if (dvq_prep_codes_per_workgroup(K) == 8)
+        hipLaunchKernelGGL(codebook_prep_f32_kernel<8>, dim3(T * 4), dim3(256), 8 * D * sizeof(float), st, E, K, D, tiles, en_all, etamax);
+    else
+        hipLaunchKernelGGL(codebook_prep_f32_kernel<32>, dim3(T), dim3(256), 32 * D * sizeof(float), st, E, K, D, tiles, en_all, etamax);
     return (int)hipGetLastError();
 }
 

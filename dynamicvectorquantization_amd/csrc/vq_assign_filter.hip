@@ -55,162 +55,103 @@
 //   image of tile t: [s < D/16][lane < 64][j < 8] halves = fp16(2^b E[32t + (lane&31)][16s + 8(lane>>5) + j])
 //   -> the A fragment of k-step s is ONE ds_read_b128 at s*1024 + lane*16 (lane-linear, conflict-free)
 // ---------------------------------------------------------------------------------------------
-// two steps (the codebook is rebuilt at every training step: a single workgroup scanning K x D took 74 us): META_BLOCKS workgroups
-// reduce slices to partial maxima, parked in the unused tail of the 256-byte meta slot; one wave finishes.
-static constexpr int META_BLOCKS = 16;                   // 3 floats each: 192 B = the slot's tail
-__global__ __launch_bounds__(1024) void codebook_meta_partial_kernel(const float *__restrict__ E, int K, int D,
-                                                                     const float *__restrict__ en_all,
-                                                                     DvqF16Meta *__restrict__ meta)
+// Round 6: ONE kernel behind the f32 prep (vq_assign_exact.hip: codebook_prep_f32_kernel), which leaves per-workgroup partial
+// maxima in the padding of its tiles -- until now six launches (partial scan, scan, two image kernels, residual norms: 42 us of
+// every training step for 1 MiB of codebook).  A workgroup owns CPW codes of a tile, as the f32 prep does: every workgroup
+// reduces the partials to the meta values itself (a few KiB from L2; maxima and an OR: any order gives the same bits) and workgroup 0
+// writes them; a thread converts octets of channels and stores them into BOTH images (the 32x32x16 order and the 16x16x32 order
+// hold the same fp16 values); the rounding residuals go through LDS so that a code's squared residual norm is summed in the order
+// it always was (lane-strided, xor tree); etamax was zeroed by the f32 prep.
+int dvq_prep_codes_per_workgroup(int K);                 // vq_assign_exact.hip
+template <int CPW>
+__global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__restrict__ E, int K, int D,
+                                                                const float *__restrict__ tiles32,
+                                                                const float *__restrict__ en_all,
+                                                                DvqF16Meta *__restrict__ meta, char *__restrict__ img,
+                                                                char *__restrict__ img16)
 {
-    __shared__ float s_max[1024];
-    __shared__ float s_en[1024];
-    __shared__ int s_bad[1024];
+    extern __shared__ float r2[];                            // [CPW][D] squared rounding residuals
+    __shared__ float s_a[4], s_e[4];
+    __shared__ int s_b[4];
+    constexpr int SUBS = 32 / CPW;
+    const int t = blockIdx.x / SUBS, sub = blockIdx.x % SUBS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = dvq_num_tiles(K);
     float amax = 0.0f, enmax = 0.0f;
     int bad = 0;
-    const size_t total = (size_t)K * D;
-    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (size_t)META_BLOCKS * 1024) {
-        float v = fabsf(E[i]);
-        bad |= !(v < __builtin_inff());
-        amax = fmaxf(amax, v);
-    }
-    for (int j = blockIdx.x * 1024 + threadIdx.x; j < K; j += META_BLOCKS * 1024) {
-        float v = en_all[j];
-        bad |= !(v < __builtin_inff());
-        enmax = fmaxf(enmax, v);
-    }
-    s_max[threadIdx.x] = amax;
-    s_en[threadIdx.x] = enmax;
-    s_bad[threadIdx.x] = bad;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + w]);
-            s_en[threadIdx.x] = fmaxf(s_en[threadIdx.x], s_en[threadIdx.x + w]);
-            s_bad[threadIdx.x] |= s_bad[threadIdx.x + w];
+    {
+        const size_t tf = dvq_tile_floats(D);
+        for (int i = tid; i < T * SUBS; i += 256) {
+            const f32x4 p = *(const f32x4 *)(tiles32 + (size_t)(i / SUBS) * tf + 32 * D + 32 + 4 * (i % SUBS));
+            amax = fmaxf(amax, p[0]);
+            enmax = fmaxf(enmax, p[1]);
+            bad |= p[2] != 0.0f;
         }
+        for (int off = 32; off > 0; off >>= 1) {
+            amax = fmaxf(amax, __shfl_xor(amax, off));
+            enmax = fmaxf(enmax, __shfl_xor(enmax, off));
+            bad |= __shfl_xor(bad, off);
+        }
+        if (lane == 0) { s_a[wave] = amax; s_e[wave] = enmax; s_b[wave] = bad; }
         __syncthreads();
+        amax = fmaxf(fmaxf(s_a[0], s_a[1]), fmaxf(s_a[2], s_a[3]));
+        enmax = fmaxf(fmaxf(s_e[0], s_e[1]), fmaxf(s_e[2], s_e[3]));
+        bad = s_b[0] | s_b[1] | s_b[2] | s_b[3];
     }
-    if (threadIdx.x == 0) {
-        float *part = (float *)((char *)meta + 64) + 3 * blockIdx.x;
-        part[0] = s_max[0];
-        part[1] = s_en[0];
-        part[2] = s_bad[0] ? 1.0f : 0.0f;
+    int bexp = 0;
+    if (amax > 0.0f) {
+        int e;
+        (void)frexpf(amax, &e);         // amax = m 2^e, m in [0.5, 1)
+        bexp = 15 - e;                  // 2^b amax in [2^14, 2^15)
     }
-}
-
-__global__ __launch_bounds__(64) void codebook_meta_kernel(DvqF16Meta *__restrict__ meta)
-{
-    const float *part = (const float *)((const char *)meta + 64);
-    if (threadIdx.x == 0) {
-        float amax = 0.0f, enmax = 0.0f;
-        int bad = 0;
-        for (int i = 0; i < META_BLOCKS; ++i) {
-            amax = fmaxf(amax, part[3 * i]);
-            enmax = fmaxf(enmax, part[3 * i + 1]);
-            bad |= part[3 * i + 2] != 0.0f;
-        }
-        int b = 0;
-        if (amax > 0.0f) {
-            int e;
-            (void)frexpf(amax, &e);     // amax = m 2^e, m in [0.5, 1)
-            b = 15 - e;                 // 2^b amax in [2^14, 2^15)
-        }
-        if (b > 100 || b < -100) bad = 1;
+    if (bexp > 100 || bexp < -100) bad = 1;
+    const float sb = ldexpf(1.0f, bad ? 0 : bexp);
+    if (blockIdx.x == 0 && tid == 0) {
         meta->ok = bad ? 0 : 1;
-        meta->b_exp = b;
-        meta->scale_b = ldexpf(1.0f, bad ? 0 : b);
+        meta->b_exp = bexp;
+        meta->scale_b = sb;
         meta->emax = sqrtf(enmax) * 1.00001f;
         meta->enmax = enmax;
-        meta->etamax = 0.0f;            // filled by codebook_eta_kernel
     }
-}
-
-__global__ __launch_bounds__(256) void codebook_prep_f16_kernel(const float *__restrict__ E, int K, int D,
-                                                                const DvqF16Meta *__restrict__ meta,
-                                                                const float *__restrict__ en_all,
-                                                                char *__restrict__ img)
-{
-    // tile t = [fp16 image: D/16 x 1 KiB][tail 256 B: seed[32] = -2^(b-1) en_j, the MFMA accumulator
+    // image of tile t = [fp16 image: D/16 x 1 KiB][tail 256 B: seed[32] = -2^(b-1) en_j, the MFMA accumulator
     // start value that turns the dot product into the score; codes >= K get a huge negative FINITE
     // seed (they never win, and packing the register index into the low mantissa bits cannot turn
     // them into NaNs as it would for -inf); pad[32]]
-    const float sb = meta->scale_b;
-    const int S16 = D / 16;
-    const size_t img_halves = (size_t)S16 * 512;
-    const size_t per_tile = img_halves + 128;              // in 2-byte units
-    const size_t total = (size_t)dvq_num_tiles(K) * per_tile;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        int t = (int)(i / per_tile);
-        int r = (int)(i - (size_t)t * per_tile);
-        char *tile = img + (size_t)t * per_tile * 2;
-        if (r < (int)img_halves) {
-            int s = r >> 9, lane = (r >> 3) & 63, j = r & 7;
-            int code = t * 32 + (lane & 31);
-            int k = 16 * s + 8 * (lane >> 5) + j;
-            float v = (code < K) ? E[(size_t)code * D + k] * sb : 0.0f;
-            ((_Float16 *)tile)[r] = (_Float16)v;           // round to nearest even
-        } else if (((r - (int)img_halves) & 1) == 0) {
-            int q = (r - (int)img_halves) >> 1;            // float index in the tail, 0..63
-            int code = t * 32 + q;
-            float v = 0.0f;
-            if (q < 32) v = (code < K) ? fmaxf(-0.5f * sb * en_all[code], DVQ_SEED_PAD) : DVQ_SEED_PAD;
-            ((float *)(tile + img_halves * 2))[q] = v;
+    //   32x32x16 order:  [s < D/16][lane < 64][j < 8] = fp16(2^b E[32t + (lane & 31)][16 s + 8 (lane >> 5) + j])
+    //   16x16x32 order (image "16"): fragment F = c2 * (D/32) + s' (c2 < 2 code halves, s' < D/32 k-steps of 32), lane l, j < 8:
+    //                    fp16(2^b E[32t + 16 c2 + (l & 15)][32 s' + 8 (l >> 4) + j]); same seeds tail.
+    const int KG = D / 8, S32 = D / 32;
+    const size_t tile_bytes = (size_t)D * 64 + 256;
+    char *t8 = img + (size_t)t * tile_bytes, *t16 = img16 + (size_t)t * tile_bytes;
+    for (int u = tid; u < CPW * KG; u += 256) {
+        const int cl = u / KG, o = u - cl * KG, c = sub * CPW + cl;
+        const int code = t * 32 + c;
+        f16x8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (code < K) ? E[(size_t)code * D + 8 * o + j] * sb : 0.0f;
+            const _Float16 hh = (_Float16)v;                 // round to nearest even
+            hv[j] = hh;
+            const float r = v - (float)hh;
+            r2[cl * D + 8 * o + j] = r * r;
         }
+        *(f16x8 *)(t8 + (((o >> 1) * 64 + 32 * (o & 1) + c) * 16)) = hv;
+        *(f16x8 *)(t16 + ((((c >> 4) * S32 + (o >> 2)) * 64 + 16 * (o & 3) + (c & 15)) * 16)) = hv;
     }
-}
-
-// The same tile in v_mfma_f32_16x16x32_f16 operand order (image "16"): fragment F = c2 * (D/32) + s' (c2 < 2 code halves,
-// s' < D/32 k-steps of 32), lane l, j < 8: fp16(2^b E[32t + 16 c2 + (l & 15)][32 s' + 8 (l >> 4) + j]); same seeds tail.
-__global__ __launch_bounds__(256) void codebook_prep_f16x_kernel(const float *__restrict__ E, int K, int D,
-                                                                 const DvqF16Meta *__restrict__ meta,
-                                                                 const float *__restrict__ en_all,
-                                                                 char *__restrict__ img)
-{
-    const float sb = meta->scale_b;
-    const int S32 = D / 32;
-    const size_t img_halves = (size_t)(D / 16) * 512;
-    const size_t per_tile = img_halves + 128;
-    const size_t total = (size_t)dvq_num_tiles(K) * per_tile;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        int t = (int)(i / per_tile);
-        int r = (int)(i - (size_t)t * per_tile);
-        char *tile = img + (size_t)t * per_tile * 2;
-        if (r < (int)img_halves) {
-            int F = r >> 9, lane = (r >> 3) & 63, j = r & 7;
-            int c2 = F / S32, sp = F - c2 * S32;
-            int code = t * 32 + 16 * c2 + (lane & 15);
-            int k = 32 * sp + 8 * (lane >> 4) + j;
-            float v = (code < K) ? E[(size_t)code * D + k] * sb : 0.0f;
-            ((_Float16 *)tile)[r] = (_Float16)v;
-        } else if (((r - (int)img_halves) & 1) == 0) {
-            int q = (r - (int)img_halves) >> 1;
-            int code = t * 32 + q;
-            float v = 0.0f;
-            if (q < 32) v = (code < K) ? fmaxf(-0.5f * sb * en_all[code], DVQ_SEED_PAD) : DVQ_SEED_PAD;
-            ((float *)(tile + img_halves * 2))[q] = v;
-        }
+    if (sub == 0 && tid < 64) {
+        const int code = t * 32 + tid;
+        float v = 0.0f;
+        if (tid < 32) v = (code < K) ? fmaxf(-0.5f * sb * en_all[code], DVQ_SEED_PAD) : DVQ_SEED_PAD;
+        ((float *)(t8 + (size_t)D * 64))[tid] = v;
+        ((float *)(t16 + (size_t)D * 64))[tid] = v;
     }
-}
-
-// etamax = max_j || 2^b e_j - fp16(2^b e_j) ||_2 (each residual is exact in fp32), rounded up.  A wave per code (coalesced rows).
-__global__ __launch_bounds__(256) void codebook_eta_kernel(const float *__restrict__ E, int K, int D,
-                                                           DvqF16Meta *__restrict__ meta)
-{
-    const float sb = meta->scale_b;
-    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    // etamax = max_j || 2^b e_j - fp16(2^b e_j) ||_2 (each residual is exact in fp32), rounded up.  A wave per code.
     float best = 0.0f;
-    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < K; j += gridDim.x * 4) {
-        const float *e = E + (size_t)j * D;
-        float s = 0.0f;
-        for (int k = lane; k < D; k += 64) {
-            float v = e[k] * sb;
-            float r = v - (float)(_Float16)v;
-            s += r * r;
-        }
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        best = fmaxf(best, s);
+    for (int cl = wave; cl < CPW; cl += 4) {
+        float sum = 0.0f;
+        for (int k = lane; k < D; k += 64) sum += r2[cl * D + k];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        best = fmaxf(best, sum);
     }
     if (lane == 0 && best > 0.0f) {
         float v = sqrtf(best) * 1.001f;     // (the summation order differs from a sequential sum by a few ulp: inside the 0.1 % margin)
@@ -2299,19 +2240,12 @@ int dvq_launch_prep_f16(const float *E, int K, int D, void *prep, hipStream_t st
     DvqF16Meta *meta = (DvqF16Meta *)base;
     char *img = base + 256;
     const float *en_all = (const float *)((char *)prep + dvq_prep_en_offset(K, D));
-    hipLaunchKernelGGL(codebook_meta_partial_kernel, dim3(META_BLOCKS), dim3(1024), 0, st, E, K, D, en_all, meta);
-    hipLaunchKernelGGL(codebook_meta_kernel, dim3(1), dim3(64), 0, st, meta);
-    size_t total = (size_t)dvq_num_tiles(K) * ((size_t)(D / 16) * 512 + 128);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(codebook_prep_f16_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all, img);
-    hipLaunchKernelGGL(codebook_prep_f16x_kernel, dim3(blocks), dim3(256), 0, st, E, K, D, meta, en_all,
-                       img + dvq_img16_offset(K, D));
-    {
-        int eb = (K + 3) / 4;
-        if (eb > 2048) eb = 2048;
-        hipLaunchKernelGGL(codebook_eta_kernel, dim3(eb), dim3(256), 0, st, E, K, D, meta);
-    }
+    const int T = dvq_num_tiles(K);
+    char *img16 = img + dvq_img16_offset(K, D);
+    if (dvq_prep_codes_per_workgroup(K) == 8)
+        hipLaunchKernelGGL(codebook_prep_f16_kernel<8>, dim3(T * 4), dim3(256), 8 * D * sizeof(float), st, E, K, D, (const float *)prep, en_all, meta, img, img16);
+    else
+        hipLaunchKernelGGL(codebook_prep_f16_kernel<32>, dim3(T), dim3(256), 32 * D * sizeof(float), st, E, K, D, (const float *)prep, en_all, meta, img, img16);
     return (int)hipGetLastError();
 }
 
