@@ -1036,9 +1036,11 @@ def run_rank(a):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     ndev = torch.cuda.device_count()
-    if world > 1 and backend == "nccl" and (world > ndev or local >= ndev):
+    if world > 1 and backend == "nccl" and ndev > 1 and (world > ndev or local >= ndev):
         # one process per GPU (the reference: Lightning DDP, train.py:227-233): RCCL cannot put two ranks on one device, and a
-        # silent modulo would report a scaling figure measured on fewer GPUs than claimed
+        # silent modulo would report a scaling figure measured on fewer GPUs than claimed.  (ONE visible device per rank is the
+        # launch that masks devices per rank -- every rank drives its device 0; should it be a one-GPU box instead, RCCL refuses
+        # the duplicate device at init and the identity check below counts the distinct devices.)
         raise SystemExit("bench.py: %d ranks (local rank %d) but %d visible GPU(s): the RCCL run needs one GPU per rank "
                          "(DVQ_BENCH_BACKEND=gloo folds ranks onto the visible devices, for tests only)" % (world, local, ndev))
     local = local % ndev                           # gloo tests only: a 1-GPU box can still exercise the N > 1 code path
