@@ -19,7 +19,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //        img[kg][c][p], kg < D/8, c < 32, p < 8  =  E[32t + c][8kg + 2(p&3) + (p>>2)]
 //        (lane (c, h) of a wave reads its 4 next f32-MFMA A operands k = 8kg + {0,2,4,6} + h with
 //         one ds_read_b128 at float offset (kg*32 + c)*8 + 4h), then en[32] (exact ATen-order
-//        squared norms of the tile's codes; +inf... no: 0 for padded codes) and 32 floats of padding.
+//        squared norms of the tile's codes; 0 for padded codes) and 32 floats of padding (no kernel reads them; the build parks
+//        its partial maxima there: vq_assign_exact.hip, codebook_prep_f32_kernel).  tests/test_codebook_prep.py restates every section.
 //   [en]               Kpad floats (Kpad = 32T): all squared norms, same values.
 //   [f16 section]      used by the filter kernel, see vq_assign_filter.hip.
 // ---------------------------------------------------------------------------------------------
