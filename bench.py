@@ -910,7 +910,7 @@ def configs_block(dev, small=False):
         st0["assign_op"] = _ev_ms(lambda: vqg(h0), nsteps)
         o0 = oracle.vq_assign_nchw(h0.cpu().numpy(), E_np, None)
         ol0 = float(oracle.vq_loss(o0["sqerr"], o0["numel"], 0.25))
-        out["cfg0"] = {"workload": "VQModel.encode: quant_conv -> VectorQuantizer2, 16x16x256, K=1024", "B": B0,
+        out["cfg0"] = {"workload": "VQModel.encode: quant_conv -> VectorQuantizer2 (one op; stages timed apart), 16x16x256, K=1024", "B": B0,
                        "ms": ms0, "images_per_s": B0 / (ms0 * 1e-3), "stage_ms": st0, "share": {k: v / ms0 for k, v in st0.items()},
                        "frac": {"assign_op": (B0 * 256 * 2056 + K * D * 4) / (st0["assign_op"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                        "checked_images": B0, "code_mismatches": int((info0[2].cpu().numpy().reshape(B0, -1) != o0["codes"]).sum()),

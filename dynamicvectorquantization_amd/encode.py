@@ -51,6 +51,17 @@ def _can_fuse_conv(quantize, quant_conv, *feats):
     return all(t.is_cuda and t.dtype == torch.float32 for t in feats)
 
 
+def _can_fuse_vqgan(quantize, quant_conv, h):
+    """VectorQuantizer2 (quantize_vqgan.py:213-341) in eval mode behind a fusable 1x1 conv on 256 channels, no remap, filter path:
+    quant_conv -> quantizer as one op (dvq_vq_assign_qconv_f32), as _can_route_conv allows it for VectorQuantize2"""
+    from .quantize import VectorQuantizer2
+    return (isinstance(quantize, VectorQuantizer2) and not quantize.training and quantize.remap is None
+            and quantize.assign_mode == _lib.MODE_FILTER and quantize.e_dim == 256 and h.shape[1] == 256
+            and quantize.embedding.weight.is_cuda and quantize.embedding.weight.dtype == torch.float32
+            and quant_conv.out_channels == 256 and quantize.n_e < (1 << 20) and _can_fuse_conv(quantize, quant_conv, h)
+            and not (torch.is_grad_enabled() and quantize.embedding.weight.requires_grad))
+
+
 def _can_fold(quantize, quant_conv, *feats):
     """the conv folded into the codebook (quantize.vq_assign*(fold=True)): the routed op's preconditions, a fusable conv of the
     codebook's width (64 / 128 / 256 channels), the filter path.  Loss-free: callers ask for it."""
@@ -173,6 +184,14 @@ def encode_fixed(quantize, h, quant_conv=None, fold=False):
         cb = quantize.codebook
         zq, codes, loss = vq_assign(h, cb.codes, cb._prep, None, beta=quantize.beta, mode=quantize.assign_mode, conv=quant_conv)
         return zq, loss[1], (None, None, codes)
+    if quant_conv is not None and h.dim() == 4 and _can_fuse_vqgan(quantize, quant_conv, h):
+        # the taming-style quantizer of the fixed-granularity VQModel (BASELINE configs[0]): the same ONE op; the loss
+        # beta * m + m is the same float whichever of the two means carries beta (legacy), IEEE addition being commutative
+        from .quantize import vq_assign
+        zq, codes, loss = vq_assign(h, quantize.embedding.weight, quantize._prep, None, beta=float(quantize.beta),
+                                    mode=quantize.assign_mode, conv=quant_conv)
+        idx = codes if quantize.sane_index_shape else codes.reshape(-1)
+        return zq, loss[1], (None, None, idx)
     if quant_conv is not None:
         h = qconv.quant_conv(quant_conv, h) if _can_fuse_conv(quantize, quant_conv, h) else quant_conv(h)
     return quantize(h)

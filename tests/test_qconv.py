@@ -245,6 +245,24 @@ def test_encode_with_quant_conv_end_to_end(dev, oracle_mod, golden_dir):
     assert torch.equal(inf_[2], cd) and torch.equal(qf, zqd)
     of = oracle_mod.vq_assign_nchw(hb2.cpu().numpy(), E, None)
     assert np.array_equal(cd.cpu().numpy().reshape(B, -1), of["codes"])
+    # ... and with the taming-style quantizer VQModel really has (BASELINE configs[0]: B = 4, 16 x 16; quantize_vqgan.py:271-312):
+    # one op too (round 6), flat or [B, H, W] indices, legacy or not; remap / grad-carrying calls keep the two-step path
+    from dynamicvectorquantization_amd.quantize import VectorQuantizer2
+    z4 = t(synth.z_tokens(E, 4, 16, 16, 505))
+    for legacy, sane in ((False, False), (True, True)):
+        vqg = VectorQuantizer2(K, D, beta=0.25, legacy=legacy, sane_index_shape=sane).to(dev).eval()
+        vqg.embedding.weight.data.copy_(t(E))
+        hb4 = torch.empty((4, D, 16, 16), device=dev)
+        with torch.no_grad():
+            qg, lg, ig = encode_fixed(vqg, z4, quant_conv=conv)
+            zq4, c4, l4 = vq_assign(z4, t(E), _CodebookPrep(), None, conv=conv, h_buf=hb4)
+            q2s, l2s, i2s = vqg(quant_conv(conv, z4))                 # the two-step order on the same conv kernel's output
+        assert tuple(ig[2].shape) == ((4, 16, 16) if sane else (4 * 256,))
+        assert torch.equal(ig[2].reshape(-1), c4.reshape(-1)) and torch.equal(qg, zq4) and float(lg) == float(l4[1])
+        assert torch.equal(ig[2].reshape(-1), i2s[2].reshape(-1)) and torch.equal(qg, q2s) and abs(float(lg) - float(l2s)) <= 1e-6 * float(l2s)
+        o4 = oracle_mod.vq_assign_nchw(hb4.cpu().numpy(), E, None)
+        assert np.array_equal(c4.cpu().numpy().reshape(4, -1), o4["codes"]) and np.array_equal(qg.cpu().numpy(), o4["zq"])
+        assert abs(float(lg) - float(oracle_mod.vq_loss(o4["sqerr"], o4["numel"], 0.25))) <= 1e-5 * float(lg)
     # 128 channels: select + conv kernel, then the dense assign (exact given that kernel's h)
     E1 = synth.codebook_trained(256, 128)
     conv1 = _conv(dev, 128, 520)
