@@ -43,6 +43,37 @@ def test_dynamic_symbol_table_is_exactly_the_abi():
     assert set(_declared()) <= set(syms)
 
 
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """the boundary is a C ABI, not a C++ one: include/dvq.h compiles as C99 with -pedantic and no warning, a C program that takes
+    the address of EVERY declared entry point links against libdvq.so with gcc alone (no hipcc, no C++ runtime on its side), and its
+    size queries answer without a GPU -- what a cgo / JNI / ctypes binding of the reference side would rely on"""
+    import shutil
+    import subprocess
+    from dynamicvectorquantization_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = _declared()
+    src = tmp_path / "abi_from_c.c"
+    src.write_text("#include \"dvq.h\"\n#include <stdio.h>\n"
+                   "typedef void (*entry_t)(void);\n"
+                   "static const entry_t entry[] = {" + ", ".join("(entry_t)%s" % n for n in names) + "};\n"
+                   "int main(void) {\n"
+                   "    size_t i, n = sizeof entry / sizeof entry[0];\n"
+                   "    for (i = 0; i < n; ++i) if (!entry[i]) return 2;\n"
+                   "    printf(\"%d %zu %zu\\n\", dvq_version(), n, dvq_codebook_prep_bytes(1024, 256));\n"
+                   "    return 0;\n}\n")
+    exe = tmp_path / "abi_from_c"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                         "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-o", str(exe)],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-1000:]
+    ver, n, prep = run.stdout.split()
+    assert int(ver) == _lib.lib.dvq_version() and int(n) == len(names) and int(prep) == _lib.lib.dvq_codebook_prep_bytes(1024, 256)
+
+
 def test_size_queries_and_validation_without_gpu():
     from dynamicvectorquantization_amd import _lib
     L = _lib.lib
