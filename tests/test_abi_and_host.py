@@ -74,6 +74,19 @@ def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
     assert int(ver) == _lib.lib.dvq_version() and int(n) == len(names) and int(prep) == _lib.lib.dvq_codebook_prep_bytes(1024, 256)
 
 
+def test_documents_name_only_entry_points_that_exist():
+    """every `dvq_*` identifier README / INTEGRATION / DESIGN / profiles/README spell out in full is declared in include/dvq.h
+    (patterns with braces or wildcards and prefixes ending in `_` are skipped); the tuning build's two extra exports, the
+    snippet's own Python function and two file stems are the only other names"""
+    decl = set(_declared())
+    other = {"dvq_tuning_set", "dvq_tuning_buffers", "dvq_forward", "dvq_filter", "dvq_oracle", "dvq_common", "dvq_abi"}
+    for doc in ("README.md", "INTEGRATION.md", "DESIGN.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        names = set(re.findall(r"(?<![A-Za-z0-9_*{}])(dvq_[a-z0-9_]+)(?![A-Za-z0-9_*{}])", text))
+        bad = sorted(n for n in names if n not in decl and n not in other and not n.endswith("_"))
+        assert not bad, (doc, bad)
+
+
 def test_size_queries_and_validation_without_gpu():
     from dynamicvectorquantization_amd import _lib
     L = _lib.lib
