@@ -87,6 +87,17 @@ def test_documents_name_only_entry_points_that_exist():
         assert not bad, (doc, bad)
 
 
+def test_documents_point_at_files_that_exist():
+    """every back-ticked path under tools/, profiles/, tests/, oracle/, include/, csrc/ that the documents cite in full exists
+    (`oracle/_ref` is the task's name for a compiled reference, which a Python reference does not have)"""
+    for doc in ("README.md", "INTEGRATION.md", "DESIGN.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        paths = set(re.findall(r"`((?:tools|profiles|tests|oracle|include|dynamicvectorquantization_amd|csrc|archive)/[A-Za-z0-9_./\-]+)`", text))
+        missing = [p for p in sorted(paths) if p != "oracle/_ref" and not any(
+            os.path.exists(os.path.join(ROOT, c)) for c in (p, os.path.join("dynamicvectorquantization_amd", p), os.path.join("profiles", p)))]
+        assert not missing, (doc, missing)
+
+
 def test_size_queries_and_validation_without_gpu():
     from dynamicvectorquantization_amd import _lib
     L = _lib.lib
