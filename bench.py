@@ -1001,6 +1001,8 @@ def configs_block(dev, small=False):
             return float("%.5g" % v)
         if isinstance(v, dict):
             return {k: rnd(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [rnd(x) for x in v]
         return v
     out = rnd(out)
     out["seconds"] = round(time.perf_counter() - t_start, 1)
@@ -1416,6 +1418,17 @@ def run_rank(a):
             out["cpu_baseline"] = cpu_baseline(wl.E_np, a.cpu_seconds)
         if configs is not None:
             out["configs"] = configs                           # last: a truncated record keeps the END of the line
+        def sig7(v):                                           # side blocks at 7 significant digits: the line stays inside the
+            if isinstance(v, float):                           # driver's record (value / ms_per_step keep every digit)
+                return float("%.7g" % v)
+            if isinstance(v, dict):
+                return {k: sig7(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return [sig7(x) for x in v]
+            return v
+        for k in list(out):
+            if k not in ("value", "ms_per_step"):
+                out[k] = sig7(out[k])
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out, separators=(",", ":")), flush=True)
