@@ -1486,9 +1486,9 @@ __device__ __forceinline__ double resolve_chunk(
     int *misc = (int *)(L + LL::MISC);
     double *red = (double *)(L + LL::RED);
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x, lane = tid & 63;                  // (re-derived after the enumeration loop, see there)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    int c = lane & 31, h = lane >> 5;
     *not_last = false;
     if (tid < RES_SLOTS) best[tid] = ~0ull;
     if (tid < 4) misc[tid] = 0;
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ double resolve_chunk(
     __syncthreads();
     DVQ_RSTAMP(2);
     const bool live = c < nlive;
-    const char *rec = srec + (live ? c : 0) * RB;
+    const char *rec = srec + (live ? c : 0) * RB;            // (FOLD: taken again after the enumeration loop)
     f16x8 zh[S16];
 #pragma unroll
     for (int s = 0; s < S16; ++s) {                    // same RNE f32 -> f16 conversion as pass 1
@@ -1594,7 +1594,14 @@ __device__ __forceinline__ double resolve_chunk(
             }
         }
     }
+    // the thread's ids from mbcnt instead of the registers that held them: kept live across the enumeration loop (256 registers,
+    // every one in use) they were this kernel's spills (2 - 7 dwords of scratch per lane)
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    tid = wave * 64 + lane;
+    c = lane & 31;
+    h = lane >> 5;
     if constexpr (FOLD) {
+        const char *rec = srec + (c < nlive ? c : 0) * RB;       // (shadows the first: the same address from the fresh ids)
         constexpr int T8 = D / 32, NT = (T8 + RW - 1) / RW;      // row tiles of the weight; this wave takes wave, wave + RW, ..
         constexpr int QIMG = S16 * 1024, QTILE = 2 * QIMG + 256;
         float amax = 0.0f;
@@ -1886,10 +1893,12 @@ __global__ __launch_bounds__(DVQ_RES_WAVES * 64, DVQ_RES_WAVES > 4 ? 1 : 2) void
     const int nlive = (total - base < RES_SLOTS) ? total - base : RES_SLOTS;
     DVQ_RSTAMP(1);
     bool not_last;
-    const double tot = resolve_chunk<D, FOLD>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, Wout, zq, codes, counters,
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar: thread 0 is found again below without
+    const double tot = resolve_chunk<D, FOLD>(L, base, nlive, t_begin, t_end, img, en_all, E, HW, Wout, zq, codes, counters,   // keeping threadIdx.x in a register)
                                               exact_list, records, nslice, chunk_sync + 2 * blockIdx.x, h_spill, cv,
                                               partials != nullptr, &not_last);
-    if (!not_last && partials != nullptr && threadIdx.x == 0) partials[blockIdx.x] = tot + p1_share();
+    const bool thread0 = wave0 == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0;
+    if (!not_last && partials != nullptr && thread0) partials[blockIdx.x] = tot + p1_share();
     DVQ_RSTAMP(6);
 }
 
